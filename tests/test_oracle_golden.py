@@ -1,0 +1,162 @@
+"""CPU: the oracle against the fixtures the reference itself produced (tools/gen_golden.py).
+
+This is what pins the oracle (everything that restates code under /root/reference).
+fp64 fixtures are matched to ~1e-10; fp32 fixtures to the fp32 noise floor of the
+reference itself (its own fp32-vs-fp64 per-step loss differs by
+6.6e-6..6.4e-5 relative).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses, nnref, train
+from oracle.pp import AlignFeature
+from tests import goldens
+
+TOL = {"f64": dict(rtol=1e-9, atol=1e-11), "f32": dict(rtol=2e-4, atol=2e-5)}
+DT = {"f64": torch.float64, "f32": torch.float32}
+
+
+@pytest.fixture(autouse=True)
+def _restore_dtype():
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+def build_pp(g):
+    spec = goldens.pp_spec(g)
+    if spec is None:
+        return torch.nn.Identity()
+    return AlignFeature(spec["align_idx"], spec["ref_pos"], spec["features"], spec["use_angle_value"])
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("name", goldens.KAT_CASES)
+def test_loss_func_kat(name, tag):
+    g = goldens.load(name, tag)
+    dtype = DT[tag]
+    torch.set_default_dtype(dtype)
+    k = int(g["k"])
+    sd = {n: p.requires_grad_(True) for n, p in goldens.state_dict(g, dtype=dtype).items()}
+    pp = build_pp(g)
+    lag = int(g["lag_idx"])
+    traj, w = np.array(g["traj"]), np.array(g["w"])
+    B = traj.shape[0] - lag
+    X = torch.tensor(traj[:B]).to(dtype)
+    wt = torch.tensor(w[:B]).to(dtype)
+    Xl = wl = a = None
+    if lag == 0:
+        X.requires_grad_()
+        a = torch.tensor(np.array(g["diag_coeff"])).to(dtype)
+    else:
+        Xl = torch.tensor(traj[lag:lag + B]).to(dtype)
+        wl = torch.tensor(w[lag:lag + B]).to(dtype)
+    loss, eig, npl, pen, cvec = losses.ef_loss(
+        sd, k, pp, X, wt, Xl, wl, alpha=float(g["alpha"]), eig_w=list(g["eig_w"]), diag_coeff=a,
+        beta=float(g["beta"]), lag_idx=lag, dt=float(g["dt"]), sort_eigvals=bool(g["sort"]))
+    loss.backward()
+    tol = TOL[tag]
+    np.testing.assert_allclose(float(loss), float(g["loss"]), **tol)
+    np.testing.assert_allclose(float(npl), float(g["npl"]), **tol)
+    np.testing.assert_allclose(float(pen), float(g["pen"]), **tol)
+    np.testing.assert_allclose(eig.numpy(), g["eig"], **tol)
+    assert list(cvec) == list(g["cvec"])
+    for n, p in sd.items():
+        ref = g["grad/" + n]
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=tol["rtol"] * 10, atol=tol["atol"] * 10 * scale, err_msg=n)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("name", goldens.EF_TRAIN_CASES)
+def test_ef_train_trace(name, tag):
+    g = goldens.load(name, tag)
+    dtype = DT[tag]
+    torch.set_default_dtype(dtype)
+    k = int(g["k"])
+    lag = int(g["lag_idx"])
+    a = torch.tensor(np.array(g["diag_coeff"])).to(dtype) if lag == 0 else None
+    np.random.seed(int(g["seed"]))  # the oracle must consume the RNG like the reference (two permutations)
+    res = train.train_ef(goldens.state_dict(g, dtype=dtype), k, build_pp(g), np.array(g["traj"]), np.array(g["w"]),
+                         alpha=float(g["alpha"]), eig_w=list(g["eig_w"]), diag_coeff=a, beta=float(g["beta"]),
+                         lag_idx=lag, dt=float(g["dt"]), learning_rate=float(g["lr"]), batch_size=int(g["batch_size"]),
+                         num_epochs=int(g["num_epochs"]))
+    np.testing.assert_array_equal(res["train_idx"], g["train_idx"])
+    np.testing.assert_array_equal(res["test_idx"], g["test_idx"])
+    tol = TOL[tag]
+    tr = np.stack([e[0].numpy() for e in res["loss_list"]])
+    te = np.stack([e[1].numpy() for e in res["loss_list"]])
+    np.testing.assert_allclose(tr, g["train_loss"], **tol)
+    np.testing.assert_allclose(te, g["test_loss"], **tol)
+    assert list(res["cvec"]) == list(g["cvec"])
+    for n, p in res["state_dict"].items():
+        np.testing.assert_allclose(p.numpy(), g["final/" + n], rtol=tol["rtol"] * 10, atol=tol["atol"] * 10, err_msg=n)
+    # learned-CV outputs (core.py:372-382): pp followed by the nets re-ordered by the last cvec
+    sd_re = nnref.reorder_eigenfunctions(res["state_dict"], res["cvec"])
+    probe = torch.tensor(np.array(g["traj"])[:64]).to(dtype)
+    cv = nnref.eigenfunctions_forward(sd_re, k, build_pp(g)(probe)).detach().numpy()
+    np.testing.assert_allclose(cv, g["colvar_probe"], rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("name", goldens.AE_TRAIN_CASES)
+def test_ae_train_trace(name, tag):
+    g = goldens.load(name, tag)
+    dtype = DT[tag]
+    torch.set_default_dtype(dtype)
+    sd0 = goldens.state_dict(g, dtype=dtype)
+    pp = build_pp(g)
+    # known answer of weighted_MSE_loss + its gradient at the initial weights
+    F = pp(torch.tensor(np.array(g["traj"])).to(dtype))
+    n0 = min(256, F.shape[0])
+    sd = {n: p.clone().requires_grad_(True) for n, p in sd0.items()}
+    l0 = losses.ae_loss(sd, F[:n0], torch.tensor(np.array(g["w"])[:n0]).to(dtype))
+    l0.backward()
+    tol = TOL[tag]
+    np.testing.assert_allclose(float(l0), float(g["loss0"]), **tol)
+    for n, p in sd.items():
+        np.testing.assert_allclose(p.grad.numpy(), g["grad/" + n], rtol=tol["rtol"] * 10, atol=tol["atol"] * 10, err_msg=n)
+    np.testing.assert_allclose(F.detach().numpy(), g["features"], **tol)
+    np.random.seed(int(g["seed"]))
+    res = train.train_ae(sd0, pp, np.array(g["traj"]), np.array(g["w"]), learning_rate=float(g["lr"]),
+                         batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]))
+    np.testing.assert_array_equal(res["train_idx"], g["train_idx"])
+    np.testing.assert_array_equal(res["test_idx"], g["test_idx"])
+    np.testing.assert_allclose(np.stack([e[0].numpy() for e in res["loss_list"]]), g["train_loss"], **tol)
+    np.testing.assert_allclose(np.stack([e[1].numpy() for e in res["loss_list"]]), g["test_loss"], **tol)
+    for n, p in res["state_dict"].items():
+        np.testing.assert_allclose(p.numpy(), g["final/" + n], rtol=tol["rtol"] * 10, atol=tol["atol"] * 10, err_msg=n)
+    probe = pp(torch.tensor(np.array(g["traj"])[:64]).to(dtype))
+    cv = nnref.encoder_forward(res["state_dict"], probe).detach().numpy()
+    np.testing.assert_allclose(cv, g["colvar_probe"], rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+
+
+def test_nn_structure():
+    g = np.load(goldens.GOLDEN + "/nn_structure.npz")
+    sd_ef = goldens.state_dict(g, "ef/")
+    sd_ae = goldens.state_dict(g, "ae/")
+    assert list(sd_ef.keys()) == [str(s) for s in g["ef_keys"]]
+    assert list(sd_ae.keys()) == [str(s) for s in g["ae_keys"]]
+    assert sum(v.numel() for v in sd_ef.values()) == int(g["ef_nparams"]) == 4443
+    assert sum(v.numel() for v in sd_ae.values()) == int(g["ae_nparams"]) == 3088
+    x30, x66 = torch.tensor(g["x30"]), torch.tensor(g["x66"])
+    np.testing.assert_allclose(nnref.eigenfunctions_forward(sd_ef, 3, x30).numpy(), g["ef_out"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(nnref.autoencoder_forward(sd_ae, x66).numpy(), g["ae_out"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(nnref.encoder_forward(sd_ae, x66).numpy(), g["enc_out"], rtol=1e-6, atol=1e-6)
+
+
+def test_split_matches_sklearn():
+    """split_indices restates sklearn's train_test_split as called at core.py:465,468,672."""
+    from sklearn.model_selection import train_test_split
+    for n, ratio, seed in [(5000, 0.2, 1), (4998, 0.2, 2), (257, 0.33, 3), (11, 0.2, 4)]:
+        np.random.seed(seed)
+        tr_ref, te_ref = train_test_split(np.arange(n), test_size=ratio)
+        np.random.seed(seed)
+        tr, te = train.split_indices(n, ratio)
+        np.testing.assert_array_equal(tr, tr_ref)
+        np.testing.assert_array_equal(te, te_ref)
+    # sizes printed by the executed notebooks (2d.ipynb:521-523,654-656; main.ipynb:484-486)
+    assert [len(x) for x in train.split_indices(5000, 0.2)] == [4000, 1000]
+    assert [len(x) for x in train.split_indices(4998, 0.2)] == [3998, 1000]
+    assert [len(x) for x in train.split_indices(150000, 0.2)] == [120000, 30000]

@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (it needs /root/reference).  The reference's Python
+files are imported read-only from where they lie; two cosmetic third-party imports the
+image lacks are satisfied by empty in-memory modules (``tensorboardX.SummaryWriter``
+used only for logging at core.py:143,559-561,738-739; ``openmm.unit`` imported at
+core.py:58 and never used).  Nothing of the reference is copied: the fixtures are
+inputs (seeded synthetic data + explicit initial weights) and the numbers the
+reference computes from them.
+
+Cases:
+  G1  loss_func known-answer tests  (EigenFunctionTask.loss_func, core.py:387-457)
+  G2  EigenFunctionTask.train traces (core.py:459-566)
+  G3  AutoEncoderTask.train traces   (core.py:668-744)
+  G4  colvarsfinder.nn structure     (nn.py:29-114,242-293)
+Every case is emitted for torch default dtype float32 and float64 with identical
+initial weights (drawn in fp32, then cast).
+
+The alignment/feature layer is NOT part of the reference (third-party molann, absent):
+cases with ``pp='align'`` pass the oracle's ``oracle.pp.AlignFeature`` to the reference
+as its opaque ``pp_layer`` - they pin the reference's loss/training code composed with
+that layer, not the layer itself.
+
+Usage:  python tools/gen_golden.py            (writes tests/golden/*.npz)
+"""
+
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+REF = "/root/reference"
+
+
+def import_reference():
+    tbx = types.ModuleType("tensorboardX")
+
+    class SummaryWriter:  # logging sink only
+        def __init__(self, *a, **k):
+            self.scalars = []
+
+        def add_scalar(self, tag, value, step):
+            self.scalars.append((tag, float(value), int(step)))
+
+    tbx.SummaryWriter = SummaryWriter
+    sys.modules.setdefault("tensorboardX", tbx)
+    omm = types.ModuleType("openmm")
+    omm.unit = types.ModuleType("openmm.unit")
+    omm.app = types.ModuleType("openmm.app")
+    sys.modules.setdefault("openmm", omm)
+    sys.modules.setdefault("openmm.unit", omm.unit)
+    sys.modules.setdefault("openmm.app", omm.app)
+    sys.path.insert(0, REF)
+    import colvarsfinder.core as core
+    import colvarsfinder.nn as rnn
+    assert core.__file__.startswith(REF), core.__file__
+    return core, rnn
+
+
+from oracle import nnref  # noqa: E402
+from oracle.pp import AlignFeature  # noqa: E402
+from tests.synth import make_molecule_traj, make_2d_traj, Traj  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def sd_np(sd):
+    return {f"sd/{k}": v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def build_pp(case):
+    if case["pp"] == "identity":
+        return torch.nn.Identity()
+    return AlignFeature(case["align_idx"], case["ref_pos"], case["features"], case.get("use_angle_value", False))
+
+
+def pp_meta(case):
+    if case["pp"] == "identity":
+        return {"pp": "identity"}
+    feats = case["features"]
+    return {
+        "pp": "align",
+        "align_idx": np.asarray(case["align_idx"], dtype=np.int64),
+        "ref_pos": np.asarray(case["ref_pos"], dtype=np.float64),
+        "feat_types": np.asarray([t for t, _ in feats]),
+        "feat_atoms": np.asarray([list(a) + [-1] * (4 - len(a)) if t != "position" else [-1] * 4 for t, a in feats],
+                                 dtype=np.int64),
+        "feat_pos_atoms": np.asarray(
+            [i for t, a in feats if t == "position" for i in a], dtype=np.int64),
+        "use_angle_value": np.asarray(case.get("use_angle_value", False)),
+    }
+
+
+def molecule_case(n_atoms, n_frames, seed, features="position", lag=False):
+    traj, w, ref = make_molecule_traj(n_atoms, n_frames, seed)
+    if features == "position":
+        feats = [("position", tuple(range(n_atoms)))]
+    else:  # mixed: positions of a subset + a few internal coordinates
+        feats = [("position", (0, 2, 3, 5)), ("bond", (0, 1)), ("bond", (2, 7)), ("angle", (1, 2, 3)),
+                 ("dihedral", (0, 1, 2, 3)), ("dihedral", (4, 5, 6, 7)), ("angle", (6, 8, 9))]
+    return dict(pp="align", traj=traj, w=w, align_idx=list(range(n_atoms)) if features == "position" else [0, 1, 2, 4, 5, 8],
+                ref_pos=ref if features == "position" else ref[[0, 1, 2, 4, 5, 8]], features=feats)
+
+
+def run_loss_kat(core, rnn, name, case, k, layer_dims, mode, dtype, alpha, eig_w, beta, sort, seed):
+    torch.set_default_dtype(dtype)
+    g = torch.Generator().manual_seed(seed)
+    sd0 = nnref.init_eigenfunctions(layer_dims, k, g, dtype)
+    model = rnn.EigenFunctions(layer_dims, k)
+    model.load_state_dict(sd0)
+    pp = build_pp(case)
+    traj, w = case["traj"], case["w"]
+    dt = 0.5
+    lag_idx = 0 if mode == "generator" else 3
+    tot_dim = traj[0].size
+    a = None
+    if mode == "generator":
+        rs = np.random.RandomState(seed + 7)
+        a = torch.tensor(1.0 / rs.choice([1.0, 12.0, 14.0, 16.0], size=tot_dim // (3 if traj.ndim == 3 else 1)).repeat(
+            3 if traj.ndim == 3 else 1), dtype=dtype)
+    with tempfile.TemporaryDirectory() as tmp:
+        task = core.EigenFunctionTask(Traj(traj, w, dt), pp, model, tmp, alpha, eig_w, diag_coeff=a, beta=beta,
+                                      lag_tau=lag_idx * dt, k=k, sort_eigvals_in_training=sort, verbose=False,
+                                      save_model_every_step=0)
+    B = traj.shape[0] - lag_idx
+    X = torch.tensor(traj[:B]).to(dtype)
+    wt = torch.tensor(w[:B]).to(dtype)
+    Xl = wl = None
+    if lag_idx == 0:
+        X.requires_grad_()
+    else:
+        Xl = torch.tensor(traj[lag_idx:lag_idx + B]).to(dtype)
+        wl = torch.tensor(w[lag_idx:lag_idx + B]).to(dtype)
+    loss, eig, npl, pen, cvec = task.loss_func(X, wt, Xl, wl)
+    loss.backward()
+    out = dict(kind="ef_loss", mode=mode, k=k, layer_dims=np.asarray(layer_dims), alpha=alpha, eig_w=np.asarray(eig_w, dtype=np.float64),
+               beta=beta, dt=dt, lag_idx=lag_idx, sort=sort, traj=traj, w=w,
+               loss=float(loss), eig=eig.detach().numpy().astype(np.float64), npl=float(npl), pen=float(pen),
+               cvec=np.asarray(cvec, dtype=np.int64), y=model(pp(X)).detach().numpy())
+    if a is not None:
+        out["diag_coeff"] = a.numpy().astype(np.float64)
+    out.update(sd_np(sd0))
+    out.update({f"grad/{n}": p.grad.numpy() for n, p in model.named_parameters()})
+    out.update(pp_meta(case))
+    tag = "f32" if dtype == torch.float32 else "f64"
+    np.savez_compressed(os.path.join(OUT, f"{name}_{tag}.npz"), **out)
+    print(f"  {name}_{tag}: loss={float(loss):.9g} eig={eig.tolist()} cvec={list(cvec)}")
+
+
+def run_ef_train(core, rnn, name, case, k, layer_dims, mode, dtype, alpha, eig_w, beta, lr, bs, epochs, seed, lag_idx=0, dt=0.5):
+    torch.set_default_dtype(dtype)
+    g = torch.Generator().manual_seed(seed)
+    sd0 = nnref.init_eigenfunctions(layer_dims, k, g, dtype)
+    model = rnn.EigenFunctions(layer_dims, k)
+    model.load_state_dict(sd0)
+    pp = build_pp(case)
+    traj, w = case["traj"], case["w"]
+    tot_dim = traj[0].size
+    a = None
+    if mode == "generator":
+        lag_idx = 0
+        rs = np.random.RandomState(seed + 7)
+        per = 3 if traj.ndim == 3 else 1
+        a = torch.tensor(1.0 / rs.choice([1.0, 12.0, 14.0, 16.0], size=tot_dim // per).repeat(per), dtype=dtype)
+    with tempfile.TemporaryDirectory() as tmp:
+        task = core.EigenFunctionTask(Traj(traj, w, dt), pp, model, tmp, alpha, eig_w, diag_coeff=a, beta=beta,
+                                      lag_tau=lag_idx * dt, learning_rate=lr, k=k, batch_size=bs, num_epochs=epochs,
+                                      test_ratio=0.2, verbose=False, save_model_every_step=0)
+        np.random.seed(seed)
+        task.train()
+    # the split the reference drew (second of two permutations, core.py:465-468)
+    np.random.seed(seed)
+    n = traj.shape[0] - lag_idx
+    n_test = int(np.ceil(0.2 * n))
+    np.random.permutation(n)
+    perm = np.random.permutation(n)
+    probe = torch.tensor(traj[:64]).to(dtype)
+    cv = task.colvar_model()(probe).detach().numpy()
+    out = dict(kind="ef_train", mode=mode, k=k, layer_dims=np.asarray(layer_dims), alpha=alpha, eig_w=np.asarray(eig_w, dtype=np.float64),
+               beta=beta, dt=dt, lag_idx=lag_idx, lr=lr, batch_size=bs, num_epochs=epochs, seed=seed, traj=traj, w=w,
+               train_idx=perm[n_test:], test_idx=perm[:n_test],
+               train_loss=np.stack([e[0].numpy() for e in task.loss_list]),
+               test_loss=np.stack([e[1].numpy() for e in task.loss_list]),
+               cvec=np.asarray(task._cvec, dtype=np.int64), colvar_probe=cv,
+               train_loss_df=task.train_loss_df.to_numpy(), test_loss_df=task.test_loss_df.to_numpy(),
+               loss_names=np.asarray(list(task.train_loss_df.columns)))
+    if a is not None:
+        out["diag_coeff"] = a.numpy().astype(np.float64)
+    out.update(sd_np(sd0))
+    out.update({f"final/{n}": p.detach().numpy() for n, p in model.state_dict().items()})
+    out.update(pp_meta(case))
+    tag = "f32" if dtype == torch.float32 else "f64"
+    np.savez_compressed(os.path.join(OUT, f"{name}_{tag}.npz"), **out)
+    print(f"  {name}_{tag}: last train row {out['train_loss'][-1, -1]}")
+
+
+def run_ae_train(core, rnn, name, case, e_dims, d_dims, dtype, lr, bs, epochs, seed):
+    torch.set_default_dtype(dtype)
+    g = torch.Generator().manual_seed(seed)
+    sd0 = nnref.init_autoencoder(e_dims, d_dims, g, dtype)
+    model = rnn.AutoEncoder(e_dims, d_dims)
+    model.load_state_dict(sd0)
+    pp = build_pp(case)
+    traj, w = case["traj"], case["w"]
+    with tempfile.TemporaryDirectory() as tmp:
+        task = core.AutoEncoderTask(Traj(traj, w, 0.5), pp, model, tmp, learning_rate=lr, batch_size=bs, num_epochs=epochs,
+                                    test_ratio=0.2, verbose=False, save_model_every_step=0)
+        feat = task._feature_traj.detach().numpy()
+        # known-answer for weighted_MSE_loss + grads at the initial weights (core.py:652-666)
+        Fb = task._feature_traj[:min(256, len(w))]
+        wb = task._weights[:min(256, len(w))]
+        l0 = task.weighted_MSE_loss(Fb, wb)
+        l0.backward()
+        grads0 = {f"grad/{n}": p.grad.detach().numpy().copy() for n, p in model.named_parameters()}
+        model.zero_grad(set_to_none=True)
+        np.random.seed(seed)
+        task.train()
+    np.random.seed(seed)
+    n = traj.shape[0]
+    n_test = int(np.ceil(0.2 * n))
+    perm = np.random.permutation(n)
+    probe = torch.tensor(traj[:64]).to(dtype)
+    cv = task.colvar_model()(probe).detach().numpy()
+    out = dict(kind="ae_train", e_dims=np.asarray(e_dims), d_dims=np.asarray(d_dims), lr=lr, batch_size=bs, num_epochs=epochs,
+               seed=seed, traj=traj, w=w, train_idx=perm[n_test:], test_idx=perm[:n_test], features=feat,
+               loss0=float(l0),
+               train_loss=np.stack([e[0].numpy() for e in task.loss_list]),
+               test_loss=np.stack([e[1].numpy() for e in task.loss_list]),
+               colvar_probe=cv, train_loss_df=task.train_loss_df.to_numpy(), test_loss_df=task.test_loss_df.to_numpy())
+    out.update(sd_np(sd0))
+    out.update(grads0)
+    out.update({f"final/{n}": p.detach().numpy() for n, p in model.state_dict().items()})
+    out.update(pp_meta(case))
+    tag = "f32" if dtype == torch.float32 else "f64"
+    np.savez_compressed(os.path.join(OUT, f"{name}_{tag}.npz"), **out)
+    print(f"  {name}_{tag}: loss0={float(l0):.9g} last train {out['train_loss'][-1, -1]:.9g}")
+
+
+def run_nn_structure(rnn):
+    torch.set_default_dtype(torch.float32)
+    ef = rnn.EigenFunctions([30, 20, 20, 20, 1], 3)
+    ae = rnn.AutoEncoder([66, 20, 20, 20, 2], [2, 10, 10, 66])
+    g = torch.Generator().manual_seed(5)
+    sd_ef = nnref.init_eigenfunctions([30, 20, 20, 20, 1], 3, g)
+    sd_ae = nnref.init_autoencoder([66, 20, 20, 20, 2], [2, 10, 10, 66], g)
+    ef.load_state_dict(sd_ef)
+    ae.load_state_dict(sd_ae)
+    x30 = torch.randn(17, 30, generator=g)
+    x66 = torch.randn(17, 66, generator=g)
+    out = dict(kind="nn",
+               ef_keys=np.asarray(list(ef.state_dict().keys())), ae_keys=np.asarray(list(ae.state_dict().keys())),
+               ef_nparams=sum(p.numel() for p in ef.parameters()), ae_nparams=sum(p.numel() for p in ae.parameters()),
+               ef_modules=np.asarray([n for n, _ in ef.named_modules()]), ae_modules=np.asarray([n for n, _ in ae.named_modules()]),
+               ef_cv1_names=np.asarray([n for n, _ in ef.get_params_of_cv(1)]),
+               ae_cv1_names=np.asarray([n for n, _ in ae.get_params_of_cv(1)]),
+               ae_cv1_shapes=np.asarray([list(p.shape) + [0] * (2 - p.dim()) for _, p in ae.get_params_of_cv(1)]),
+               ae_cv1_last_w=ae.get_params_of_cv(1)[-2][1].detach().numpy(),
+               x30=x30.numpy(), x66=x66.numpy(), ef_out=ef(x30).detach().numpy(), ae_out=ae(x66).detach().numpy(),
+               enc_out=ae.encoder(x66).detach().numpy(), ae_encoded_dim=ae.encoded_dim)
+    out.update({f"ef/{k}": v.numpy() for k, v in sd_ef.items()})
+    out.update({f"ae/{k}": v.numpy() for k, v in sd_ae.items()})
+    np.savez_compressed(os.path.join(OUT, "nn_structure.npz"), **out)
+    print("  nn_structure: ef params", out["ef_nparams"], "ae params", out["ae_nparams"])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    core, rnn = import_reference()
+    print("reference imported from", core.__file__)
+    run_nn_structure(rnn)
+
+    t2, w2 = make_2d_traj(600, seed=11)
+    id2 = dict(pp="identity", traj=t2, w=w2)
+    mol10 = molecule_case(10, 300, seed=21)
+    mol22 = molecule_case(22, 256, seed=22)
+    mix10 = molecule_case(10, 300, seed=23, features="mixed")
+
+    for dtype in (torch.float32, torch.float64):
+        # G1: loss_func KATs
+        run_loss_kat(core, rnn, "kat_gen_id2_k1", id2, 1, [2, 20, 20, 20, 1], "generator", dtype, 10.0, [1.0], 1.0, True, 101)
+        run_loss_kat(core, rnn, "kat_gen_id2_k3", id2, 3, [2, 12, 12, 1], "generator", dtype, 20.0, [1.0, 0.7, 0.4], 2.0, True, 102)
+        run_loss_kat(core, rnn, "kat_tr_id2_k2", id2, 2, [2, 20, 20, 20, 1], "transfer", dtype, 20.0, [1.0, 0.2], 1.0, True, 103)
+        run_loss_kat(core, rnn, "kat_gen_mol10_k2", mol10, 2, [30, 20, 20, 20, 1], "generator", dtype, 20.0, [1.0, 0.2], 1.0, True, 104)
+        run_loss_kat(core, rnn, "kat_gen_mol22_k3", mol22, 3, [66, 20, 20, 20, 1], "generator", dtype, 20.0, [1.0, 0.75, 0.5], 1.0, True, 105)
+        run_loss_kat(core, rnn, "kat_tr_mol10_k2", mol10, 2, [30, 20, 20, 20, 1], "transfer", dtype, 20.0, [1.0, 0.2], 1.0, True, 106)
+        run_loss_kat(core, rnn, "kat_gen_mix10_k2", mix10, 2, [20, 16, 16, 1], "generator", dtype, 15.0, [1.0, 0.5], 1.5, False, 107)
+        # G2: train traces
+        run_ef_train(core, rnn, "train_gen_id2_k1", id2, 1, [2, 20, 20, 20, 1], "generator", dtype, 10.0, [1.0], 1.0, 5e-3, 100, 3, 201)
+        run_ef_train(core, rnn, "train_tr_id2_k2", id2, 2, [2, 20, 20, 20, 1], "transfer", dtype, 20.0, [1.0, 0.2], 1.0, 5e-3, 100, 3, 202, lag_idx=2)
+        run_ef_train(core, rnn, "train_gen_mol22_k3", mol22, 3, [66, 20, 20, 20, 1], "generator", dtype, 20.0, [1.0, 0.75, 0.5], 1.0, 1e-3, 64, 3, 203)
+        run_ef_train(core, rnn, "train_tr_mol10_k2", mol10, 2, [30, 20, 20, 20, 1], "transfer", dtype, 20.0, [1.0, 0.2], 1.0, 2e-3, 64, 3, 204, lag_idx=1)
+        # G3: autoencoder traces
+        run_ae_train(core, rnn, "train_ae_id2", id2, [2, 20, 20, 20, 1], [1, 20, 20, 2], dtype, 5e-3, 100, 4, 301)
+        run_ae_train(core, rnn, "train_ae_mol22", mol22, [66, 20, 20, 20, 2], [2, 10, 10, 66], dtype, 1e-3, 64, 3, 302)
+    torch.set_default_dtype(torch.float32)
+
+
+if __name__ == "__main__":
+    main()
