@@ -1,0 +1,119 @@
+"""ctypes binding of ``libcvf_hip.so`` (C ABI declared in ``include/cvf.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream; every compute call goes
+through the C ABI with raw device pointers.  There is no CPU or eager-PyTorch fallback: if
+the shared library is missing, or a call fails, this module raises.
+"""
+
+import ctypes as C
+import os
+
+import torch
+
+TILE = 64
+MAX_NETS = 8
+MAX_LAYERS = 12
+AUX_ROWS = 18
+
+FEAT_ANGLE, FEAT_BOND, FEAT_DIHEDRAL, FEAT_POSITION = 0, 1, 2, 3
+PP_IDENTITY, PP_ALIGN = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcvf_hip.so")
+
+
+class PPDesc(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("n_coord", C.c_int32), ("n_align", C.c_int32), ("n_rec", C.c_int32),
+                ("d_r", C.c_int32), ("use_angle_value", C.c_int32), ("has_position", C.c_int32), ("pad_", C.c_int32),
+                ("align_idx", C.c_void_p), ("ref_c", C.c_void_p), ("rec", C.c_void_p)]
+
+
+class MLPDesc(C.Structure):
+    _fields_ = [("n_nets", C.c_int32), ("n_layers", C.c_int32), ("dims", C.c_int32 * (MAX_LAYERS + 1)),
+                ("act", C.c_int32 * MAX_LAYERS), ("w_off", (C.c_int32 * MAX_LAYERS) * MAX_NETS),
+                ("b_off", (C.c_int32 * MAX_LAYERS) * MAX_NETS), ("n_params", C.c_int32)]
+
+
+class EFCfg(C.Structure):
+    _fields_ = [("k", C.c_int32), ("lag_idx", C.c_int32), ("sort_eigvals", C.c_int32), ("pad_", C.c_int32),
+                ("alpha", C.c_double), ("beta", C.c_double), ("dt", C.c_double), ("eig_w", C.c_double * MAX_NETS)]
+
+
+_SIGNATURES = {
+    "cvf_version": (C.c_int, []),
+    "cvf_last_error": (C.c_char_p, []),
+    "cvf_ef_nstats": (C.c_int, [C.c_int, C.c_int]),
+    "cvf_align_feature_fwd": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "cvf_metric_apply": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_ef_mlp_fwd": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_ef_stats_scratch_doubles": (C.c_int64, [C.c_int, C.c_int]),
+    "cvf_ef_stats": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_ef_loss": (C.c_int, [C.POINTER(EFCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_ef_backward_slab_floats": (C.c_int64, [C.POINTER(MLPDesc), C.c_int64]),
+    "cvf_ef_backward": (C.c_int, [C.POINTER(EFCfg), C.POINTER(MLPDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_ae_scratch_floats": (C.c_int64, [C.POINTER(MLPDesc), C.c_int64]),
+    "cvf_ae_step": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_mlp_eval_rows": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "cvf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "cvf_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"colvarsfinder: HIP extension not built ({LIB_PATH} missing). Run `python __graft_entry__.py` "
+                "or `make -C colvars-finder_amd/csrc`. There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().cvf_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "HIP path needs contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ntiles(B):
+    return (B + TILE - 1) // TILE
+
+
+def require_gpu(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(
+            "colvarsfinder (MI355X build) computes on the GPU only: pass device=torch.device('cuda'). "
+            "There is no CPU path in this package.")
+    if not torch.cuda.is_available():
+        raise RuntimeError("colvarsfinder: no HIP device visible")
+    lib()
+    return device

@@ -1,0 +1,617 @@
+"""Training tasks with the API of the reference's ``colvarsfinder.core`` on MI355X.
+
+API twin (own code) of reference ``colvarsfinder/core.py``: ``TrainingTask`` (core.py:60-249),
+``EigenFunctionTask`` (core.py:251-566) and ``AutoEncoderTask`` (core.py:569-744) keep their
+constructor arguments, defaults, public methods and attributes, so the reference's example
+scripts run unchanged once ``device=torch.device('cuda')`` is passed.  What differs is *how* a
+step is computed: the model's parameters live in one flat HBM buffer, the trajectory shard is
+resident in HBM and pre-permuted once (batches are static: ``shuffle=False``, core.py:472-481),
+and every step is a short sequence of hand-written gfx950 kernels called through the C ABI of
+``libcvf_hip.so`` (``include/cvf.h``) - no autograd graph, no per-step host synchronisation.
+
+Per-step pipeline of ``EigenFunctionTask`` (generator mode, core.py:418-426,438):
+    K1  align + features           cvf_align_feature_fwd     replaces pp_layer(X)           core.py:403
+    K4a nets forward + dY/dfeat    cvf_ef_mlp_fwd            replaces model(...)            core.py:403
+    K2/3 q = J A J^T g, E          cvf_metric_apply          replaces autograd.grad x k     core.py:424-426
+    K5  batch sums (fp64)          cvf_ef_stats              core.py:406-410,446-452
+    C1  all-reduce of the sums     torch.distributed (RCCL)  (absent in the reference)
+        scalar tail + d loss/d sum cvf_ef_loss               core.py:426-457
+    K4b parameter gradient         cvf_ef_backward           replaces loss.backward()       core.py:517
+    C2  all-reduce of the gradient torch.distributed (RCCL)
+    K6  Adam                       cvf_adam_step             replaces optimizer.step()      core.py:522
+
+There is no CPU path: ``device`` must be a HIP device (``torch.device('cuda')`` is PyTorch's name
+for it) and the HIP extension must be built, otherwise construction raises.
+"""
+
+import copy
+import math
+import os
+from abc import ABC, abstractmethod
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import _dist, _hip
+from .nn import AutoEncoder, EigenFunctions, RegAutoEncoder, RegModel, mlp_layout  # noqa: F401
+from .pp import AlignFeatureLayer, identity_desc
+
+try:  # logging sink of the reference (core.py:50,143); optional here
+    from tensorboardX import SummaryWriter as _SummaryWriter
+except Exception:  # pragma: no cover - tensorboardX is not part of the image
+    _SummaryWriter = None
+
+try:
+    from tqdm import tqdm as _tqdm
+except Exception:  # pragma: no cover
+    def _tqdm(it, **_):
+        return it
+
+
+class _ScalarLog:
+    """Stand-in for ``tensorboardX.SummaryWriter`` when that package is absent: keeps the scalars."""
+
+    def __init__(self, logdir=None):
+        self.logdir, self.scalars = logdir, []
+
+    def add_scalar(self, tag, value, step):
+        self.scalars.append((tag, float(value), int(step)))
+
+
+def _split(n, test_ratio):
+    """Same draw as ``sklearn.model_selection.train_test_split`` at core.py:465,468,672: one permutation
+    from NumPy's global RNG; test = first ceil(ratio n) entries, train = the rest."""
+    n_test = int(math.ceil(test_ratio * n))
+    perm = np.random.permutation(n)
+    return perm[n_test:], perm[:n_test]
+
+
+class _FlatParams:
+    """The model's parameters as views of one fp32 device buffer (+ gradient and Adam moments)."""
+
+    def __init__(self, model, device):
+        model.to(device=device, dtype=torch.float32)
+        lay = mlp_layout(model)
+        self.n = lay["n_params"]
+        self.theta = torch.empty(self.n, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.n, device=device, dtype=torch.float32)
+        pos = 0
+        for p in model.parameters():
+            n = p.numel()
+            self.theta[pos:pos + n].copy_(p.data.reshape(-1))
+            p.data = self.theta[pos:pos + n].view(p.shape)  # the module now aliases the flat buffer
+            pos += n
+        nets = lay["nets"]
+        assert 1 <= len(nets) <= _hip.MAX_NETS, f"between 1 and {_hip.MAX_NETS} nets are supported, got {len(nets)}"
+        L = len(nets[0])
+        assert all(len(c) == L for c in nets) and L <= _hip.MAX_LAYERS, "nets must have the same depth (<= 12 layers)"
+        d = _hip.MLPDesc()
+        d.n_nets, d.n_layers, d.n_params = len(nets), L, self.n
+        for l, (_, _, fin, fout, act) in enumerate(nets[0]):
+            d.dims[l], d.dims[l + 1], d.act[l] = fin, fout, act
+        for i, chain in enumerate(nets):
+            for l, (wo, bo, fin, fout, act) in enumerate(chain):
+                assert (fin, fout, act) == (d.dims[l], d.dims[l + 1], d.act[l]), "nets must share one architecture"
+                d.w_off[i][l], d.b_off[i][l] = wo, bo
+        self.desc = d
+
+
+class _FusedOptimizer:
+    """``optimizer`` attribute of the tasks: Adam / SGD as ONE kernel over the flat buffer
+    (same update rule and defaults as the ``torch.optim`` objects built at core.py:163-166)."""
+
+    def __init__(self, flat, name, lr):
+        self.flat, self.name, self.lr = flat, name.lower(), float(lr)
+        self.betas, self.eps = (0.9, 0.999), 1e-8
+        self.exp_avg = torch.zeros_like(flat.theta)
+        self.exp_avg_sq = torch.zeros_like(flat.theta)
+        self.step_count = torch.zeros(1, device=flat.theta.device, dtype=torch.int32)
+        self.param_groups = [dict(lr=self.lr, betas=self.betas, eps=self.eps)]
+
+    def zero_grad(self, set_to_none=True):
+        pass  # the backward kernels overwrite the whole flat gradient
+
+    def step(self):
+        f, lib = self.flat, _hip.lib()
+        lr = float(self.param_groups[0]["lr"])
+        if self.name == "adam":
+            _hip.check(lib.cvf_adam_step(_hip.ptr(f.theta), _hip.ptr(f.grad), _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq),
+                                         f.n, lr, self.betas[0], self.betas[1], self.eps, _hip.ptr(self.step_count),
+                                         _hip.stream()), "cvf_adam_step")
+        else:
+            _hip.check(lib.cvf_sgd_step(_hip.ptr(f.theta), _hip.ptr(f.grad), f.n, lr, _hip.stream()), "cvf_sgd_step")
+
+
+class TrainingTask(ABC):
+    """Base class of the training tasks (constructor arguments and attributes as core.py:102-143)."""
+
+    def __init__(self, traj_obj, pp_layer, model, model_path, learning_rate, load_model_filename, save_model_every_step,
+                 k, batch_size, num_epochs, test_ratio, optimizer_name, device, plot_class, plot_frequency, verbose,
+                 debug_mode):
+        self.device = _hip.require_gpu(device)
+        self.traj_obj = traj_obj
+        self.preprocessing_layer = pp_layer.to(self.device)
+        self.learning_rate = learning_rate
+        self.batch_size = batch_size
+        self.num_epochs = num_epochs
+        self.test_ratio = test_ratio
+        self.k = k
+        self.model = model
+        self.load_model_filename = load_model_filename
+        self.save_model_every_step = save_model_every_step
+        self.model_path = model_path
+        self.optimizer_name = optimizer_name
+        self.plot_class = plot_class
+        self.plot_frequency = plot_frequency
+        self.verbose = verbose
+        self.debug_mode = debug_mode
+        self.model_name = type(self).__name__
+        if self.verbose:
+            print('\n[Info] Log directory: {}\n'.format(self.model_path), flush=True)
+        self.writer = _SummaryWriter(self.model_path) if _SummaryWriter is not None else _ScalarLog(self.model_path)
+
+    # -- description of r(x) for the kernels
+    def _pp_desc(self, n_coord):
+        pp = self.preprocessing_layer
+        if isinstance(pp, torch.nn.Identity):
+            return identity_desc(n_coord)
+        if isinstance(pp, AlignFeatureLayer):
+            assert n_coord == 3 * pp.n_atoms, f"trajectory frames have {n_coord} coordinates, layer expects {3 * pp.n_atoms}"
+            return pp.pp_desc()
+        raise TypeError("pp_layer must be torch.nn.Identity or a colvarsfinder.pp.AlignFeatureLayer "
+                        f"(PreprocessingANN); the GPU kernels cannot run an arbitrary module ({type(pp).__name__})")
+
+    def init_model_and_optimizer(self):
+        """core.py:145-166: optional restart from ``load_model_filename``; Adam (case-insensitive) else SGD."""
+        if self.load_model_filename:
+            if os.path.isfile(self.load_model_filename):
+                self.model.load_state_dict(torch.load(self.load_model_filename, map_location="cpu"), strict=False)
+                if self.verbose:
+                    print(f'model parameters loaded from: {self.load_model_filename}')
+            elif self.verbose:
+                print(f'model file not found: {self.load_model_filename}')
+        self._flat = _FlatParams(self.model, self.device)
+        self.optimizer = _FusedOptimizer(self._flat, self.optimizer_name, self.learning_rate)
+
+    def save_model(self, epoch, description="latest"):
+        """core.py:168-227: ``model.pt`` + per-CV text files (+ TorchScript CV when the layer is scriptable)."""
+        if _dist.rank() != 0:
+            return
+        if self.verbose:
+            print(f"\n\nEpoch={epoch}:")
+        sd = {k_: v.detach().cpu() for k_, v in self.model.state_dict().items()}
+        if self.debug_mode is True:
+            os.makedirs(f'{self.model_path}/models', exist_ok=True)
+            torch.save(sd, f'{self.model_path}/models/model_{epoch}.pt')
+        out_dir = f'{self.model_path}/{description}'
+        os.makedirs(out_dir, exist_ok=True)
+        torch.save(sd, f'{out_dir}/model.pt')
+        for idx in range(self.k):
+            for name, param in self.model.get_params_of_cv(idx):
+                np.savetxt('%s/%d_' % (out_dir, idx) + name.replace('.', '_') + '.txt', param.detach().cpu().numpy())
+        if self.verbose:
+            print(f'  trained model saved at:\n\t{out_dir}/model.pt')
+        try:
+            cv = self.colvar_model()
+            torch.jit.script(copy.deepcopy(cv).to('cpu')).save(f'{out_dir}/scripted_cv_cpu.pt')
+            torch.jit.script(cv).save(f'{out_dir}/scripted_cv_gpu.pt')
+        except Exception as exc:  # the ctypes-backed alignment layer is not scriptable yet
+            if self.verbose:
+                print(f'  TorchScript export skipped: {type(exc).__name__}')
+
+    @abstractmethod
+    def train(self):
+        pass
+
+    @abstractmethod
+    def colvar_model(self):
+        pass
+
+    @abstractmethod
+    def reg_model(self):
+        pass
+
+
+class _EFWorkspace:
+    """Device buffers of one batch size (all sizes follow include/cvf.h)."""
+
+    def __init__(self, B, k, d_r, n_params, lag, mlp_desc, device):
+        lib = _hip.lib()
+        T = _hip.ntiles(B)
+        Tt = 2 * T if lag > 0 else T
+        f32 = dict(device=device, dtype=torch.float32)
+        f64 = dict(device=device, dtype=torch.float64)
+        self.B, self.T, self.Tt = B, T, Tt
+        self.feat = torch.empty(Tt * d_r * _hip.TILE, **f32)
+        self.aux = torch.empty(T * _hip.AUX_ROWS * _hip.TILE, **f32)
+        self.y = torch.empty(Tt * k * _hip.TILE, **f32)
+        if lag == 0:
+            self.g = torch.empty(T * k * d_r * _hip.TILE, **f32)
+            self.q = torch.empty(T * k * d_r * _hip.TILE, **f32)
+            self.e = torch.empty(T * k * _hip.TILE, **f32)
+        else:
+            self.g = self.q = self.e = None
+        self.scratch = torch.empty(lib.cvf_ef_stats_scratch_doubles(k, lag), **f64)
+        self.stats = torch.empty(lib.cvf_ef_nstats(k, lag), **f64)
+        self.loss_vec = torch.empty(3 + 2 * k, **f64)
+        self.coef = torch.empty(4 * k + k * k, **f64)
+        self.slab = torch.empty(lib.cvf_ef_backward_slab_floats(mlp_desc, Tt), **f32)
+
+
+class EigenFunctionTask(TrainingTask):
+    """Eigenfunctions of the generator (``lag_tau == 0``) or of the transfer operator (``lag_tau > 0``).
+
+    Arguments, defaults and attributes as reference core.py:293-354 (see the module docstring for
+    what replaces what).  ``loss_list`` / ``train_loss_df`` / ``test_loss_df`` hold the same
+    per-step rows ``[loss, eigen_non_penalty, eigen_penalty, eig_1..k]`` as the reference.
+    """
+
+    def __init__(self, traj_obj, pp_layer, model, model_path, alpha, eig_weights, diag_coeff=None, beta=1.0, lag_tau=0,
+                 learning_rate=0.01, load_model_filename=None, save_model_every_step=10, sort_eigvals_in_training=True,
+                 k=1, batch_size=1000, num_epochs=10, test_ratio=0.2, optimizer_name='Adam',
+                 device=torch.device('cuda'), plot_class=None, plot_frequency=0, verbose=True, debug_mode=True):
+        super().__init__(traj_obj, pp_layer, model, model_path, learning_rate, load_model_filename, save_model_every_step,
+                         k, batch_size, num_epochs, test_ratio, optimizer_name, device, plot_class, plot_frequency,
+                         verbose, debug_mode)
+        assert isinstance(model, EigenFunctions), 'model must be an object of the class EigenFunctions'
+        assert k == len(model.eigen_funcs), \
+            f'number of cv ({k}) must equal the number of eigenfunctions ({len(model.eigen_funcs)})'
+        assert len(eig_weights) >= k, f'{k} eigenvalue weights are needed, got {len(eig_weights)}'
+        self._alpha = alpha
+        self._sort_eigvals_in_training = sort_eigvals_in_training
+        self._eig_w = eig_weights
+        self._cvec = None
+        self.traj_dt = traj_obj.dt
+        lag_idx = lag_tau / self.traj_dt
+        assert abs(lag_idx - int(lag_idx)) < 1e-6, \
+            f'lag-time ({lag_tau}) not divisable by the timestep {self.traj_dt} of the trajectory'
+        self.lag_idx = int(lag_idx)
+        if self.verbose:
+            print('\nEigenfunctions:\n', self.model, flush=True)
+        self.init_model_and_optimizer()
+
+        # the trajectory shard and its weights stay resident in HBM (core.py:343-344 keeps CPU copies)
+        traj = np.asarray(traj_obj.trajectory)
+        self._traj = torch.as_tensor(traj).to(device=self.device, dtype=torch.float32).contiguous()
+        self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
+        self.tot_dim = int(traj[0, ...].size)
+        self._beta = beta
+        if self.lag_idx == 0:
+            if diag_coeff is not None:
+                assert diag_coeff.dim() == 1 and diag_coeff.size(dim=0) == self.tot_dim, \
+                    f'diag_coeff should be a 1d tensor of length {self.tot_dim}, current shape: {diag_coeff}'
+                self._diag_coeff = diag_coeff.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            else:
+                self._diag_coeff = torch.ones(self.tot_dim, device=self.device, dtype=torch.float32)
+
+        self._pp = self._pp_desc(self.tot_dim)
+        assert self._pp.d_r == self._flat.desc.dims[0], \
+            f'preprocessing layer emits {self._pp.d_r} features but the networks take {self._flat.desc.dims[0]}'
+        cfg = _hip.EFCfg()
+        cfg.k, cfg.lag_idx, cfg.sort_eigvals = k, self.lag_idx, int(bool(sort_eigvals_in_training))
+        cfg.alpha, cfg.beta, cfg.dt = float(alpha), float(beta), float(self.traj_dt)
+        for i in range(k):
+            cfg.eig_w[i] = float(eig_weights[i])
+        self._cfg = cfg
+        self._ws = {}
+
+    # ---------------------------------------------------------------- model views
+    def get_reordered_eigenfunctions(self, model, cvec):
+        """core.py:356-370: deep copy whose module list is re-ordered by ``cvec``."""
+        new = copy.deepcopy(model)
+        new.eigen_funcs = torch.nn.ModuleList([copy.deepcopy(model.eigen_funcs[int(i)]) for i in cvec])
+        return new
+
+    def colvar_model(self):
+        """core.py:372-382: ``Sequential(preprocessing_layer, nets re-ordered by the last cvec)``."""
+        if self._cvec is None:
+            self._cvec = torch.arange(self.k)
+        return torch.nn.Sequential(self.preprocessing_layer, self.get_reordered_eigenfunctions(self.model, self._cvec))
+
+    def reg_model(self):
+        return None
+
+    # ---------------------------------------------------------------- GPU step
+    def _workspace(self, B):
+        ws = self._ws.get(B)
+        if ws is None:
+            ws = self._ws[B] = _EFWorkspace(B, self.k, self._pp.d_r, self._flat.n, self.lag_idx, self._flat.desc, self.device)
+        return ws
+
+    def _forward(self, X, w, X_lag=None, w_lag=None):
+        """Everything up to the loss for one (local) batch; leaves loss_vec / coef on the device."""
+        lib, s = _hip.lib(), _hip.stream()
+        B = X.shape[0]
+        ws = self._workspace(B)
+        fl, k, d_r = self._flat, self.k, self._pp.d_r
+        lag = self.lag_idx
+        _hip.check(lib.cvf_align_feature_fwd(self._pp, _hip.ptr(X), B, _hip.ptr(ws.feat), None, _hip.ptr(ws.aux), s),
+                   "cvf_align_feature_fwd")
+        if lag > 0:
+            feat_lag = ws.feat[ws.T * d_r * _hip.TILE:]
+            _hip.check(lib.cvf_align_feature_fwd(self._pp, _hip.ptr(X_lag), B, _hip.ptr(feat_lag), None, None, s),
+                       "cvf_align_feature_fwd(lagged)")
+        _hip.check(lib.cvf_ef_mlp_fwd(fl.desc, _hip.ptr(fl.theta), _hip.ptr(ws.feat), ws.Tt, _hip.ptr(ws.y),
+                                      _hip.ptr(ws.g) if lag == 0 else None, s), "cvf_ef_mlp_fwd")
+        if lag == 0:
+            _hip.check(lib.cvf_metric_apply(self._pp, _hip.ptr(X), B, _hip.ptr(ws.aux), _hip.ptr(self._diag_coeff), k,
+                                            _hip.ptr(ws.g), _hip.ptr(ws.q), _hip.ptr(ws.e), s), "cvf_metric_apply")
+            _hip.check(lib.cvf_ef_stats(self._cfg, B, _hip.ptr(w), _hip.ptr(ws.y), _hip.ptr(ws.e), None, None,
+                                        _hip.ptr(ws.scratch), _hip.ptr(ws.stats), s), "cvf_ef_stats")
+        else:
+            y_lag = ws.y[ws.T * k * _hip.TILE:]
+            _hip.check(lib.cvf_ef_stats(self._cfg, B, _hip.ptr(w), _hip.ptr(ws.y), None, _hip.ptr(w_lag), _hip.ptr(y_lag),
+                                        _hip.ptr(ws.scratch), _hip.ptr(ws.stats), s), "cvf_ef_stats")
+        _dist.allreduce_sum_(ws.stats)                                                   # collective #1
+        _hip.check(lib.cvf_ef_loss(self._cfg, _hip.ptr(ws.stats), _hip.ptr(ws.loss_vec), _hip.ptr(ws.coef), s), "cvf_ef_loss")
+        return ws
+
+    def _backward(self, ws, w, w_lag=None):
+        lib, fl = _hip.lib(), self._flat
+        _hip.check(lib.cvf_ef_backward(self._cfg, fl.desc, _hip.ptr(fl.theta), ws.B, _hip.ptr(w), _hip.ptr(w_lag),
+                                       _hip.ptr(ws.feat), _hip.ptr(ws.y), _hip.ptr(ws.q) if self.lag_idx == 0 else None,
+                                       _hip.ptr(ws.coef), _hip.ptr(ws.slab), _hip.ptr(fl.grad), _hip.stream()),
+                   "cvf_ef_backward")
+        _dist.allreduce_sum_(fl.grad)                                                    # collective #2
+
+    def train_step(self, X, w, X_lag=None, w_lag=None):
+        """One optimisation step on device tensors; returns the device vector
+        ``[loss, npl, pen, eig_1..k, cvec_1..k]`` (fp64) without synchronising the host."""
+        ws = self._forward(X, w, X_lag, w_lag)
+        self._backward(ws, w, w_lag)
+        self.optimizer.step()
+        return ws.loss_vec
+
+    def _dev(self, t, dtype=torch.float32):
+        return None if t is None else torch.as_tensor(t).detach().to(device=self.device, dtype=dtype).contiguous()
+
+    def loss_func(self, X, weight, X_lagged, weight_lagged):
+        """core.py:387-457.  Returns ``(loss, eig_vals, non_penalty_loss, penalty, cvec)``; the parameter
+        gradient of ``loss`` is obtained with :meth:`backward` (there is no autograd graph)."""
+        X, weight = self._dev(X), self._dev(weight)
+        X_lagged, weight_lagged = self._dev(X_lagged), self._dev(weight_lagged)
+        ws = self._forward(X, weight, X_lagged, weight_lagged)
+        self._last = (ws, weight, weight_lagged)
+        v = ws.loss_vec.cpu()
+        k = self.k
+        dt = torch.get_default_dtype()
+        cvec = v[3 + k:3 + 2 * k].round().to(torch.long).numpy()
+        return v[0].to(dt), v[3:3 + k].to(dt), v[1].to(dt), v[2].to(dt), cvec
+
+    def backward(self):
+        """Parameter gradient of the last :meth:`loss_func` call -> ``p.grad`` of the model's parameters."""
+        ws, w, w_lag = self._last
+        self._backward(ws, w, w_lag)
+        pos = 0
+        for p in self.model.parameters():
+            p.grad = self._flat.grad[pos:pos + p.numel()].view(p.shape).clone()
+            pos += p.numel()
+
+    # ---------------------------------------------------------------- training loop
+    def train(self):
+        """core.py:459-566 with the trajectory resident in HBM and one host copy of the losses per epoch."""
+        k, lag = self.k, self.lag_idx
+        ll = self._traj.shape[0] - lag
+        _split(ll, self.test_ratio)                                  # core.py:465 (drawn, discarded)
+        idx_train, idx_test = _split(ll, self.test_ratio)            # core.py:468
+        world, rank = _dist.world(), _dist.rank()
+        if world > 1:  # every rank must use rank 0's permutation
+            both = torch.as_tensor(np.concatenate([idx_train, idx_test]), device=self.device)
+            _dist.broadcast_(both)
+            both = both.cpu().numpy()
+            idx_train, idx_test = both[:len(idx_train)], both[len(idx_train):]
+
+        def resident(idx):
+            it = torch.as_tensor(idx, device=self.device, dtype=torch.long)
+            X, w = self._traj[it].contiguous(), self._weights[it].contiguous()
+            if lag > 0:
+                return X, w, self._traj[it + lag].contiguous(), self._weights[it + lag].contiguous()
+            return X, w, None, None
+
+        def batches(n, bs):
+            # DataLoader(batch_size=bs, drop_last=True, shuffle=False); each rank owns one contiguous slice
+            out = []
+            for s in range(0, n - bs + 1, bs) if bs > 0 else []:
+                a, b = _dist.local_slice(bs, rank, world)
+                out.append((s + a, s + b))
+            return out
+
+        bs_train = min(self.batch_size, len(idx_train))
+        bs_test = min(self.batch_size, len(idx_test))
+        Xtr = resident(idx_train)
+        Xte = resident(idx_test)
+        tr_batches, te_batches = batches(len(idx_train), bs_train), batches(len(idx_test), bs_test)
+
+        self.loss_list = []
+        min_loss = float("inf")
+        if rank == 0:
+            print("\nTraining starts.\n%d epochs in total, batch sizes (train/test): %d/%d" % (self.num_epochs, bs_train, bs_test))
+            print("\nTrain set:\n\t%d data, %d iterations per epoch, %d iterations in total." %
+                  (len(idx_train), len(tr_batches), len(tr_batches) * self.num_epochs), flush=True)
+            print("Test set:\n\t%d data, %d iterations per epoch, %d iterations in total." %
+                  (len(idx_test), len(te_batches), len(te_batches) * self.num_epochs), flush=True)
+        loss_names = ['loss', 'eigen_non_penalty', 'eigen_penalty'] + ['eig_%d' % (i + 1) for i in range(k)]
+        nrow = 3 + 2 * k
+        log_tr = torch.zeros(max(len(tr_batches), 1), nrow, device=self.device, dtype=torch.float64)
+        log_te = torch.zeros(max(len(te_batches), 1), nrow, device=self.device, dtype=torch.float64)
+
+        def sl(data, a, b):
+            return tuple(None if t is None else t[a:b] for t in data)
+
+        for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
+            self.model.train()
+            for it, (a, b) in enumerate(tr_batches):
+                X, w, Xl, wl = sl(Xtr, a, b)
+                log_tr[it].copy_(self.train_step(X, w, Xl, wl))
+            for it, (a, b) in enumerate(te_batches):              # core.py:535-551 (same loss, no update)
+                X, w, Xl, wl = sl(Xte, a, b)
+                log_te[it].copy_(self._forward(X, w, Xl, wl).loss_vec)
+            tr = log_tr[:len(tr_batches)].cpu()                    # the only host synchronisation of the epoch
+            te = log_te[:len(te_batches)].cpu()
+            dt = torch.get_default_dtype()
+            if len(tr_batches) > 0:
+                self._cvec = tr[-1, 3 + k:].round().to(torch.long).numpy()      # core.py:515
+            self.loss_list.append([tr[:, :3 + k].to(dt), te[:, :3 + k].to(dt)])   # core.py:553
+
+            if self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1:
+                self.save_model(epoch)
+                last = float(tr[-1, 0]) if len(tr_batches) > 0 else float("inf")
+                if last < min_loss:                                             # core.py:526-528
+                    min_loss = last
+                    self.save_model(epoch, 'best')
+            if self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1:
+                if self.plot_class is not None and rank == 0:
+                    self.plot_class.plot(self.colvar_model(), epoch=epoch)
+            mean_tr = self.loss_list[-1][0].mean(0) if len(tr_batches) else torch.full((3 + k,), float("nan"))
+            mean_te = self.loss_list[-1][1].mean(0) if len(te_batches) else torch.full((3 + k,), float("nan"))
+            for i, name in enumerate(loss_names):                               # core.py:559-561
+                self.writer.add_scalar('%s/train' % name, mean_tr[i], epoch)
+                self.writer.add_scalar('%s/test' % name, mean_te[i], epoch)
+
+        self.train_loss_df = pd.DataFrame(torch.cat([e[0].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
+                                          columns=loss_names)
+        self.test_loss_df = pd.DataFrame(torch.cat([e[1].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
+                                         columns=loss_names)
+
+
+class AutoEncoderTask(TrainingTask):
+    """Autoencoder trained with the weighted reconstruction loss (arguments as core.py:610-625).
+
+    The feature trajectory ``r(x)`` is computed once for all frames (core.py:635) by kernel K1 and
+    stays in HBM; each step is one fused kernel (forward, weighted MSE, parameter gradient) + Adam.
+    """
+
+    def __init__(self, traj_obj, pp_layer, model, model_path, learning_rate=0.01, load_model_filename=None,
+                 save_model_every_step=10, batch_size=1000, num_epochs=10, test_ratio=0.2, optimizer_name='Adam',
+                 device=torch.device('cuda'), plot_class=None, plot_frequency=0, verbose=True, debug_mode=True):
+        super().__init__(traj_obj, pp_layer, model, model_path, learning_rate, load_model_filename, save_model_every_step,
+                         model.encoded_dim, batch_size, num_epochs, test_ratio, optimizer_name, device, plot_class,
+                         plot_frequency, verbose, debug_mode)
+        assert isinstance(model, AutoEncoder), 'model must be an object of the class AutoEncoder'
+        self.init_model_and_optimizer()
+        traj = np.asarray(traj_obj.trajectory)
+        self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
+        X = torch.as_tensor(traj).to(device=self.device, dtype=torch.float32).contiguous()
+        pp = self._pp_desc(int(traj[0, ...].size))
+        n = X.shape[0]
+        self._feature_traj = torch.empty(n, pp.d_r, device=self.device, dtype=torch.float32)       # core.py:635
+        _hip.check(_hip.lib().cvf_align_feature_fwd(pp, _hip.ptr(X), n, None, _hip.ptr(self._feature_traj), None,
+                                                    _hip.stream()), "cvf_align_feature_fwd")
+        assert pp.d_r == self._flat.desc.dims[0] == self._flat.desc.dims[self._flat.desc.n_layers], \
+            'autoencoder input/output width must equal the feature dimension'
+        if self.verbose:
+            print('\nShape of trajectory data array:\n {}'.format(self._feature_traj.shape), flush=True)
+        self._out2 = torch.zeros(2, device=self.device, dtype=torch.float64)
+        self._scratch = {}
+
+    def colvar_model(self):
+        """core.py:640-647."""
+        return torch.nn.Sequential(self.preprocessing_layer, self.model.encoder)
+
+    def reg_model(self):
+        return None
+
+    def _step(self, feat, idx, w, with_grad, inv_wsum=None):
+        """One fused kernel: forward, weighted MSE, parameter gradient.  ``inv_wsum`` = 1 / (global sum of the
+        batch weights); it does not depend on the model, so ``train`` computes it once per (static) batch."""
+        lib, fl = _hip.lib(), self._flat
+        B = w.shape[0]
+        sc = self._scratch.get(B)
+        if sc is None:
+            sc = self._scratch[B] = torch.empty(lib.cvf_ae_scratch_floats(fl.desc, B), device=self.device, dtype=torch.float32)
+        if inv_wsum is None:
+            wsum = w.sum(dtype=torch.float64)
+            _dist.allreduce_sum_(wsum)
+            inv_wsum = 1.0 / float(wsum)
+        _hip.check(lib.cvf_ae_step(fl.desc, _hip.ptr(fl.theta), _hip.ptr(feat), _hip.ptr(idx), B, _hip.ptr(w),
+                                   inv_wsum, _hip.ptr(sc), _hip.ptr(self._out2),
+                                   _hip.ptr(fl.grad) if with_grad else None, _hip.stream()), "cvf_ae_step")
+        out = self._out2.clone()
+        _dist.allreduce_sum_(out)
+        if with_grad:
+            _dist.allreduce_sum_(fl.grad)
+        return out[0] / out[1]
+
+    def weighted_MSE_loss(self, X, weight):
+        """core.py:652-666 on a feature batch ``X [B, d_r]``; ``backward()`` afterwards fills ``p.grad``."""
+        X = torch.as_tensor(X).detach().to(device=self.device, dtype=torch.float32).contiguous()
+        weight = torch.as_tensor(weight).detach().to(device=self.device, dtype=torch.float32).contiguous()
+        loss = self._step(X, None, weight, with_grad=True)
+        return loss.to(torch.get_default_dtype())
+
+    def backward(self):
+        pos = 0
+        for p in self.model.parameters():
+            p.grad = self._flat.grad[pos:pos + p.numel()].view(p.shape).clone()
+            pos += p.numel()
+
+    def train(self):
+        """core.py:668-744."""
+        n = self._feature_traj.shape[0]
+        idx_train, idx_test = _split(n, self.test_ratio)             # core.py:672 (one draw)
+        world, rank = _dist.world(), _dist.rank()
+        if world > 1:
+            both = torch.as_tensor(np.concatenate([idx_train, idx_test]), device=self.device)
+            _dist.broadcast_(both)
+            both = both.cpu().numpy()
+            idx_train, idx_test = both[:len(idx_train)], both[len(idx_train):]
+        bs_train, bs_test = min(self.batch_size, len(idx_train)), min(self.batch_size, len(idx_test))
+        itr = torch.as_tensor(idx_train, device=self.device, dtype=torch.long)
+        ite = torch.as_tensor(idx_test, device=self.device, dtype=torch.long)
+        wtr, wte = self._weights[itr].contiguous(), self._weights[ite].contiguous()
+
+        def batches(n_, bs):
+            out = []
+            for s in range(0, n_ - bs + 1, bs) if bs > 0 else []:
+                a, b = _dist.local_slice(bs, rank, world)
+                out.append((s + a, s + b))
+            return out
+
+        tr_batches, te_batches = batches(len(idx_train), bs_train), batches(len(idx_test), bs_test)
+
+        def inv_wsums(wv, bl):
+            # batches are static (shuffle=False): their weight sums are known before the first step
+            if not bl:
+                return []
+            sums = torch.stack([wv[a:b].sum(dtype=torch.float64) for a, b in bl])
+            _dist.allreduce_sum_(sums)
+            return [1.0 / float(v) for v in sums.cpu()]
+
+        iw_tr, iw_te = inv_wsums(wtr, tr_batches), inv_wsums(wte, te_batches)
+        self.loss_list = []
+        min_loss = float("inf")
+        if rank == 0:
+            print("\nTraining starts.\n%d epochs in total, batch sizes (train/test): %d/%d" % (self.num_epochs, bs_train, bs_test))
+            print("\nTrain set:\n\t%d data, %d iterations per epoch, %d iterations in total." %
+                  (len(idx_train), len(tr_batches), len(tr_batches) * self.num_epochs), flush=True)
+            print("Test set:\n\t%d data, %d iterations per epoch, %d iterations in total." %
+                  (len(idx_test), len(te_batches), len(te_batches) * self.num_epochs), flush=True)
+        log_tr = torch.zeros(max(len(tr_batches), 1), device=self.device, dtype=torch.float64)
+        log_te = torch.zeros(max(len(te_batches), 1), device=self.device, dtype=torch.float64)
+        for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
+            self.model.train()
+            for it, (a, b) in enumerate(tr_batches):
+                log_tr[it] = self._step(self._feature_traj, itr[a:b], wtr[a:b], True, iw_tr[it])
+                self.optimizer.step()
+            self.model.eval()
+            for it, (a, b) in enumerate(te_batches):
+                log_te[it] = self._step(self._feature_traj, ite[a:b], wte[a:b], False, iw_te[it])
+            dt = torch.get_default_dtype()
+            tr, te = log_tr[:len(tr_batches)].cpu().to(dt), log_te[:len(te_batches)].cpu().to(dt)
+            self.loss_list.append([tr, te])                                        # core.py:736
+            if self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1:
+                self.save_model(epoch)
+                last = float(tr[-1]) if len(tr) else float("inf")
+                if last < min_loss:
+                    min_loss = last
+                    self.save_model(epoch, 'best')
+            if self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1:
+                if self.plot_class is not None and rank == 0:
+                    self.plot_class.plot(self.colvar_model(), epoch=epoch)
+            self.writer.add_scalar('Loss/train', tr.mean() if len(tr) else float("nan"), epoch)   # core.py:738-739
+            self.writer.add_scalar('Loss/test', te.mean() if len(te) else float("nan"), epoch)
+        self.train_loss_df = pd.DataFrame(torch.cat([e[0].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
+                                          columns=['loss'])
+        self.test_loss_df = pd.DataFrame(torch.cat([e[1].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
+                                         columns=['loss'])

@@ -1,0 +1,177 @@
+"""Preprocessing layer ``r(x)``: Kabsch alignment to a reference structure + feature map.
+
+The reference takes this layer from the third-party package molann
+(``examples/dipeptide/main.ipynb:31-32,333-348``) and treats it as an opaque
+``pp_layer: torch.nn.Module`` (``core.py:65,122,403,414,635``).  This module provides the same
+constructor surface (``Feature``, ``FeatureLayer``, ``AlignmentLayer``, ``PreprocessingANN``;
+atom groups are duck-typed: ``.ix`` and ``.positions``) on top of :class:`AlignFeatureLayer`,
+whose ``forward`` is the hand-written gfx950 kernel K1 behind ``cvf_align_feature_fwd``.
+
+Conventions: unweighted centroid of the align atoms,
+``x_aligned = (x - c) @ R`` with ``R = U diag(1,1,sign det(U V^T)) V^T`` from the SVD of
+``(x_align - c)^T @ ref_c``; features are concatenated in list order: ``position`` -> 3 n
+coordinates (atom-major), ``bond`` -> distance, ``angle`` -> cos (or value), ``dihedral`` ->
+(cos, sin) (or value).
+"""
+
+import numpy as np
+import torch
+
+from . import _hip
+
+_TYPE_ID = {"angle": _hip.FEAT_ANGLE, "bond": _hip.FEAT_BOND, "dihedral": _hip.FEAT_DIHEDRAL,
+            "position": _hip.FEAT_POSITION}
+_TYPE_NATOMS = {"angle": 3, "bond": 2, "dihedral": 4}
+
+
+def _ix(atom_group):
+    return np.asarray(atom_group.ix if hasattr(atom_group, "ix") else atom_group, dtype=np.int64)
+
+
+class Feature:
+    """``Feature(name, feature_type, atom_group)`` as in molann (main.ipynb:335)."""
+
+    def __init__(self, name, feature_type, atom_group):
+        if feature_type not in _TYPE_ID:
+            raise ValueError(f"unknown feature type '{feature_type}' (expected one of {sorted(_TYPE_ID)})")
+        idx = _ix(atom_group)
+        if feature_type != "position" and len(idx) != _TYPE_NATOMS[feature_type]:
+            raise ValueError(f"feature '{name}' of type {feature_type} needs {_TYPE_NATOMS[feature_type]} atoms, got {len(idx)}")
+        self.name, self.type_name, self.type_id, self.atom_indices = name, feature_type, _TYPE_ID[feature_type], idx
+
+    def get_name(self):
+        return self.name
+
+    def get_type(self):
+        return self.type_name
+
+    def get_atom_indices(self):
+        return self.atom_indices
+
+
+class AlignFeatureLayer(torch.nn.Module):
+    """Alignment + features on local (0-based, into the input atoms) indices.
+
+    Args:
+        n_atoms: number of input atoms N; ``forward`` takes ``[B, N, 3]``.
+        align_idx: local indices of the atoms used for the alignment.
+        ref_pos: ``[n_align, 3]`` reference positions of those atoms (stored centred).
+        features: list of ``(type_name, local_atom_indices)``.
+        use_angle_value: emit angles in radians instead of cos / (cos, sin).
+    """
+
+    def __init__(self, n_atoms, align_idx, ref_pos, features, use_angle_value=False):
+        super().__init__()
+        align_idx = np.asarray(align_idx, dtype=np.int64)
+        ref = np.asarray(ref_pos, dtype=np.float64)
+        assert ref.shape == (len(align_idx), 3), f"ref_pos must be [{len(align_idx)},3], got {ref.shape}"
+        assert len(align_idx) >= 3, "at least 3 atoms are needed for the alignment"
+        assert align_idx.min() >= 0 and align_idx.max() < n_atoms, "align index out of range"
+        rec, out = [], 0
+        for tname, atoms in features:
+            atoms = [int(a) for a in atoms]
+            assert all(0 <= a < n_atoms for a in atoms), f"feature atom index out of range: {atoms}"
+            if tname == "position":
+                for a in atoms:
+                    rec.append([_hip.FEAT_POSITION, a, 0, 0, 0, out])
+                    out += 3
+            else:
+                assert len(atoms) == _TYPE_NATOMS[tname]
+                rec.append([_TYPE_ID[tname]] + atoms + [0] * (4 - len(atoms)) + [out])
+                out += 2 if (tname == "dihedral" and not use_angle_value) else 1
+        self.n_atoms, self.d_r, self.use_angle_value = int(n_atoms), out, bool(use_angle_value)
+        self.features = [(t, tuple(int(a) for a in atoms)) for t, atoms in features]
+        self.register_buffer("align_idx", torch.tensor(align_idx, dtype=torch.int32))
+        self.register_buffer("ref_c", torch.tensor(ref - ref.mean(axis=0, keepdims=True), dtype=torch.float32))
+        self.register_buffer("rec", torch.tensor(rec, dtype=torch.int32).reshape(-1, 6))
+
+    def pp_desc(self):
+        assert self.rec.is_cuda, "preprocessing layer is not on the GPU (call .to(device))"
+        d = _hip.PPDesc()
+        d.mode, d.n_coord, d.n_align, d.n_rec = _hip.PP_ALIGN, 3 * self.n_atoms, self.align_idx.numel(), self.rec.shape[0]
+        d.d_r, d.use_angle_value = self.d_r, int(self.use_angle_value)
+        d.has_position = int(bool((self.rec[:, 0] == _hip.FEAT_POSITION).any().item()))
+        d.align_idx, d.ref_c, d.rec = self.align_idx.data_ptr(), self.ref_c.data_ptr(), self.rec.data_ptr()
+        return d
+
+    def forward(self, x):
+        """``[B, N, 3]`` fp32 device tensor -> ``[B, d_r]`` (no autograd: the training tasks use the
+        analytic derivative kernels instead of differentiating through this call)."""
+        _hip.require_gpu(x.device)
+        assert x.dim() == 3 and x.shape[1] == self.n_atoms and x.shape[2] == 3, \
+            f"expected [B,{self.n_atoms},3], got {tuple(x.shape)}"
+        if x.requires_grad:
+            raise RuntimeError("AlignFeatureLayer.forward is not differentiable through autograd; "
+                               "EigenFunctionTask applies its analytic Jacobian on the GPU instead")
+        x = x.detach().to(torch.float32).contiguous()
+        B = x.shape[0]
+        out = torch.empty(B, self.d_r, device=x.device, dtype=torch.float32)
+        if B == 0:
+            return out
+        desc = self.pp_desc()
+        _hip.check(_hip.lib().cvf_align_feature_fwd(desc, _hip.ptr(x), B, None, _hip.ptr(out), None, _hip.stream()),
+                   "cvf_align_feature_fwd")
+        return out
+
+
+class FeatureLayer:
+    """``FeatureLayer(feature_list, input_atom_group, use_angle_value=False)`` (main.ipynb:337)."""
+
+    def __init__(self, feature_list, input_atom_group, use_angle_value=False):
+        self.feature_list = list(feature_list)
+        self.input_ix = _ix(input_atom_group)
+        self.use_angle_value = use_angle_value
+        lut = {int(g): i for i, g in enumerate(self.input_ix)}
+        self.local = []
+        for f in self.feature_list:
+            try:
+                self.local.append((f.type_name, tuple(lut[int(g)] for g in f.atom_indices)))
+            except KeyError as e:
+                raise ValueError(f"feature '{f.name}' uses atom {e} that is not in the input atom group") from None
+
+    def get_feature_info(self):
+        import pandas as pd
+        # molann prints 1-based atom ids in this table (main.ipynb:306-307)
+        return pd.DataFrame({"name": [f.name for f in self.feature_list], "type": [f.type_name for f in self.feature_list],
+                             "type_id": [f.type_id for f in self.feature_list],
+                             "atom indices": [list(f.atom_indices + 1) for f in self.feature_list]})
+
+    def output_dimension(self):
+        return sum(3 * len(a) if t == "position" else (2 if t == "dihedral" and not self.use_angle_value else 1)
+                   for t, a in self.local)
+
+
+class AlignmentLayer:
+    """``AlignmentLayer(align_atom_group, input_atom_group)`` (main.ipynb:345)."""
+
+    def __init__(self, align_atom_group, input_atom_group):
+        self.align_ix = _ix(align_atom_group)
+        self.input_ix = _ix(input_atom_group)
+        lut = {int(g): i for i, g in enumerate(self.input_ix)}
+        try:
+            self.local_idx = np.asarray([lut[int(g)] for g in self.align_ix], dtype=np.int64)
+        except KeyError as e:
+            raise ValueError(f"align atom {e} is not in the input atom group") from None
+        pos = np.asarray(align_atom_group.positions, dtype=np.float64)
+        self.ref_c = pos - pos.mean(axis=0, keepdims=True)
+
+    def show_info(self):
+        print(f"\n{len(self.input_ix)} atoms used for input, (0-based) global indices: \n {list(self.input_ix)}")
+        print(f"\n{len(self.align_ix)} atoms used for alignment, with (0-based) global indices: \n {list(self.align_ix)}")
+        print("local indices\n", list(self.local_idx))
+        print("\npositions of reference state used in aligment:\n", self.ref_c.astype(np.float32))
+
+
+class PreprocessingANN(AlignFeatureLayer):
+    """``PreprocessingANN(align_layer, feature_layer)`` (main.ipynb:348) -> one fused GPU layer."""
+
+    def __init__(self, align_layer, feature_layer):
+        assert np.array_equal(align_layer.input_ix, feature_layer.input_ix), "align and feature layers use different input atoms"
+        super().__init__(len(align_layer.input_ix), align_layer.local_idx, align_layer.ref_c, feature_layer.local,
+                         feature_layer.use_angle_value)
+
+
+def identity_desc(n_coord):
+    d = _hip.PPDesc()
+    d.mode, d.n_coord, d.d_r = _hip.PP_IDENTITY, int(n_coord), int(n_coord)
+    return d

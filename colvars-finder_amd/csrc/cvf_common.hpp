@@ -1,0 +1,115 @@
+// Shared device/host helpers for the gfx950 kernels of libcvf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cvf.h"
+
+#define CVF_WAVE 64
+
+void cvf_set_error(const char* fmt, ...);
+int cvf_check_launch(const char* what);
+
+#define CVF_REQUIRE(cond, ...)      \
+  do {                              \
+    if (!(cond)) {                  \
+      cvf_set_error(__VA_ARGS__);   \
+      return -1;                    \
+    }                               \
+  } while (0)
+
+static inline int64_t cvf_ntiles(int64_t B) { return (B + CVF_TILE - 1) / CVF_TILE; }
+
+// ------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// tanh with full fp32 accuracy (the reference runs torch.tanh in fp32; 1e-5 parity on the
+// loss leaves no room for the fast approximations).
+__device__ __forceinline__ float cvf_tanh(float x) { return tanhf(x); }
+
+// ------------------------------------------------------------------------------------
+// Stage one tile (64 frames) of a row-major [B][nc] fp32 array into LDS as
+// lds[frame * stride + j], stride odd so that per-lane reads (lane = frame) are
+// conflict-free.  Global reads are coalesced (the tile is one contiguous 64*nc*4 B run).
+// Frames past B replicate frame B-1 (their weight is forced to 0 by the callers).
+// ------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int x_tile_stride(int nc) { return nc | 1; }
+
+__device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int64_t B, int nc, int64_t tile, float* lds,
+                                            int lane) {
+  const int stride = x_tile_stride(nc);
+  const int64_t f0 = tile * CVF_TILE;
+  const int total = CVF_TILE * nc;
+  if (f0 + CVF_TILE <= B) {
+    const float4* src = reinterpret_cast<const float4*>(x + f0 * nc);  // 64*nc*4 B tiles are 16-B aligned
+    const int nvec = total >> 2;                                       // total is a multiple of 64
+    // (frame, j) of element 4*v advance incrementally: +256 elements per iteration
+    int e = lane * 4;
+    int fr = e / nc;
+    int j = e - fr * nc;
+    const int dfr = 256 / nc, dj = 256 - dfr * nc;
+    for (int v = lane; v < nvec; v += CVF_WAVE) {
+      float4 val = src[v];
+      int f = fr, jj = j;
+      lds[f * stride + jj] = val.x;
+      if (++jj == nc) { jj = 0; ++f; }
+      lds[f * stride + jj] = val.y;
+      if (++jj == nc) { jj = 0; ++f; }
+      lds[f * stride + jj] = val.z;
+      if (++jj == nc) { jj = 0; ++f; }
+      lds[f * stride + jj] = val.w;
+      fr += dfr;
+      j += dj;
+      if (j >= nc) { j -= nc; ++fr; }
+    }
+  } else {
+    for (int e = lane; e < total; e += CVF_WAVE) {
+      int fr = e / nc;
+      int j = e - fr * nc;
+      int64_t src = f0 + fr;
+      if (src > B - 1) src = B - 1;
+      lds[fr * stride + j] = x[src * nc + j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// 3x3 helpers (per lane, registers)
+// ------------------------------------------------------------------------------------
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// row-major 3x3 in 9 floats:  (v R)_j = sum_i v_i R[3i+j]   (row vector times matrix)
+__device__ __forceinline__ V3 row_times(V3 v, const float* R) {
+  return V3{v.x * R[0] + v.y * R[3] + v.z * R[6], v.x * R[1] + v.y * R[4] + v.z * R[7],
+            v.x * R[2] + v.y * R[5] + v.z * R[8]};
+}
+// (R g)_i = sum_j R[3i+j] g_j
+__device__ __forceinline__ V3 mat_times(const float* R, V3 g) {
+  return V3{R[0] * g.x + R[1] * g.y + R[2] * g.z, R[3] * g.x + R[4] * g.y + R[5] * g.z,
+            R[6] * g.x + R[7] * g.y + R[8] * g.z};
+}
+// symmetric 3x3 from 6 floats (00 01 02 11 12 22) times vector
+__device__ __forceinline__ V3 sym_times(const float* K, V3 t) {
+  return V3{K[0] * t.x + K[1] * t.y + K[2] * t.z, K[1] * t.x + K[3] * t.y + K[4] * t.z,
+            K[2] * t.x + K[4] * t.y + K[5] * t.z};
+}

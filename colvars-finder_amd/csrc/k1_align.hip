@@ -1,0 +1,339 @@
+// K1: Kabsch alignment + feature map, forward; K2+K3: q = J A J^T g, E = g^T J A J^T g.
+// One lane = one frame, one wave = one 64-frame tile.  The tile's coordinates are staged
+// once into LDS with coalesced 16-byte global loads (HBM traffic = 12 B/atom/frame in,
+// 4 B/feature/frame out); the 3x3 covariance, its eigen-decomposition and the small
+// solves run per lane in fp64, so all 64 lanes stay busy for small molecules.
+#include "cvf_kabsch.hpp"
+
+namespace {
+
+struct Rec {
+  int type, a0, a1, a2, a3, out;
+};
+__device__ __forceinline__ Rec load_rec(const int32_t* __restrict__ rec, int r) {
+  const int32_t* p = rec + 6 * r;
+  return Rec{p[0], p[1], p[2], p[3], p[4], p[5]};
+}
+__device__ __forceinline__ V3 atom(const float* my, int a) { return V3{my[3 * a], my[3 * a + 1], my[3 * a + 2]}; }
+
+// per-lane alignment: centroid (fp64), covariance (fp64), rotation, Kinv
+__device__ __forceinline__ void align_lane(const cvf_pp_desc& pp, const float* my, double (&c)[3], KabschOut& ko) {
+  double cx = 0, cy = 0, cz = 0;
+  for (int b = 0; b < pp.n_align; ++b) {
+    const int a = pp.align_idx[b];
+    cx += (double)my[3 * a];
+    cy += (double)my[3 * a + 1];
+    cz += (double)my[3 * a + 2];
+  }
+  const double inv = 1.0 / (double)pp.n_align;
+  c[0] = cx * inv;
+  c[1] = cy * inv;
+  c[2] = cz * inv;
+  double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int b = 0; b < pp.n_align; ++b) {
+    const int a = pp.align_idx[b];
+    const double xc0 = (double)my[3 * a] - c[0], xc1 = (double)my[3 * a + 1] - c[1], xc2 = (double)my[3 * a + 2] - c[2];
+    const double r0 = (double)pp.ref_c[3 * b], r1 = (double)pp.ref_c[3 * b + 1], r2 = (double)pp.ref_c[3 * b + 2];
+    H[0][0] += xc0 * r0; H[0][1] += xc0 * r1; H[0][2] += xc0 * r2;
+    H[1][0] += xc1 * r0; H[1][1] += xc1 * r1; H[1][2] += xc1 * r2;
+    H[2][0] += xc2 * r0; H[2][1] += xc2 * r1; H[2][2] += xc2 * r2;
+  }
+  kabsch_from_H(H, ko);
+}
+
+__device__ __forceinline__ V3 centred(const float* my, int a, const double (&c)[3]) {
+  return V3{(float)((double)my[3 * a] - c[0]), (float)((double)my[3 * a + 1] - c[1]),
+            (float)((double)my[3 * a + 2] - c[2])};
+}
+
+__global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
+                                                       float* __restrict__ feat_tiled, float* __restrict__ feat_rows,
+                                                       float* __restrict__ aux_tiled) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int64_t tile = blockIdx.x;
+  const int nc = pp.n_coord;
+  load_x_tile(x, B, nc, tile, lds, lane);
+  __syncthreads();
+  const float* my = lds + lane * x_tile_stride(nc);
+  double c[3];
+  KabschOut ko;
+  align_lane(pp, my, c, ko);
+  if (aux_tiled) {
+    float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ax[i * CVF_TILE] = ko.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ax[(9 + i) * CVF_TILE] = (float)c[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ax[(12 + i) * CVF_TILE] = ko.Kinv[i];
+  }
+  const int64_t frame = tile * CVF_TILE + lane;
+  float* ft = feat_tiled ? feat_tiled + tile * pp.d_r * CVF_TILE + lane : nullptr;
+  float* fr = (feat_rows && frame < B) ? feat_rows + frame * pp.d_r : nullptr;
+  auto emit = [&](int o, float v) {
+    if (ft) ft[o * CVF_TILE] = v;
+    if (fr) fr[o] = v;
+  };
+  for (int r = 0; r < pp.n_rec; ++r) {
+    const Rec rc = load_rec(pp.rec, r);
+    if (rc.type == CVF_FEAT_POSITION) {
+      const V3 al = row_times(centred(my, rc.a0, c), ko.R);
+      emit(rc.out, al.x);
+      emit(rc.out + 1, al.y);
+      emit(rc.out + 2, al.z);
+    } else if (rc.type == CVF_FEAT_BOND) {
+      emit(rc.out, bond_eval(atom(my, rc.a0), atom(my, rc.a1)).val);
+    } else if (rc.type == CVF_FEAT_ANGLE) {
+      const float cs = angle_eval(atom(my, rc.a0), atom(my, rc.a1), atom(my, rc.a2)).cs;
+      emit(rc.out, pp.use_angle_value ? acosf(cs) : cs);
+    } else {
+      const DihedralG dg = dihedral_eval(atom(my, rc.a0), atom(my, rc.a1), atom(my, rc.a2), atom(my, rc.a3));
+      if (pp.use_angle_value) {
+        emit(rc.out, atan2f(dg.sn, dg.cs));
+      } else {
+        emit(rc.out, dg.cs);
+        emit(rc.out + 1, dg.sn);
+      }
+    }
+  }
+}
+
+// identity preprocessing: features = coordinates; only the tiling changes
+__global__ __launch_bounds__(64) void k1_identity_kernel(int d, const float* __restrict__ x, int64_t B,
+                                                          float* __restrict__ feat_tiled, float* __restrict__ feat_rows) {
+  const int lane = threadIdx.x;
+  const int64_t tile = blockIdx.x;
+  int64_t frame = tile * CVF_TILE + lane;
+  const bool valid = frame < B;
+  if (!valid) frame = B - 1;
+  for (int j = 0; j < d; ++j) {
+    const float v = x[frame * d + j];
+    if (feat_tiled) feat_tiled[(tile * d + j) * CVF_TILE + lane] = v;
+    if (feat_rows && valid) feat_rows[frame * d + j] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// metric: per (tile, net)   G = J^T g ; E = sum_j a_j G_j^2 ; q = J (a .* G)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
+                                                           const float* __restrict__ aux_tiled,
+                                                           const float* __restrict__ a, int k,
+                                                           const float* __restrict__ g_tiled,
+                                                           float* __restrict__ q_tiled, float* __restrict__ e_tiled) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int64_t tile = blockIdx.x;
+  const int net = blockIdx.y;
+  const int nc = pp.n_coord;
+  const int stride = x_tile_stride(nc);
+  load_x_tile(x, B, nc, tile, lds, lane);
+  float* Gl = lds + CVF_TILE * stride + lane;  // G(j) = Gl[j*64]
+  for (int j = 0; j < nc; ++j) Gl[j * CVF_TILE] = 0.0f;
+  __syncthreads();
+  const float* my = lds + lane * stride;
+  const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
+  float R[9], Kinv[6];
+  double c[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = ax[i * CVF_TILE];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c[i] = (double)ax[(9 + i) * CVF_TILE];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Kinv[i] = ax[(12 + i) * CVF_TILE];
+  const int64_t base = (tile * k + net) * (int64_t)pp.d_r * CVF_TILE + lane;
+  const float* gt = g_tiled + base;
+  float* qt = q_tiled + base;
+  auto addG = [&](int atm, V3 v) {
+    Gl[(3 * atm) * CVF_TILE] += v.x;
+    Gl[(3 * atm + 1) * CVF_TILE] += v.y;
+    Gl[(3 * atm + 2) * CVF_TILE] += v.z;
+  };
+  auto getU = [&](int atm) {
+    return V3{Gl[(3 * atm) * CVF_TILE], Gl[(3 * atm + 1) * CVF_TILE], Gl[(3 * atm + 2) * CVF_TILE]};
+  };
+  // ---- VJP: G = J^T g
+  V3 sump = v3(0, 0, 0);
+  float M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = 0; r < pp.n_rec; ++r) {
+    const Rec rc = load_rec(pp.rec, r);
+    if (rc.type == CVF_FEAT_POSITION) {
+      const V3 g = v3(gt[rc.out * CVF_TILE], gt[(rc.out + 1) * CVF_TILE], gt[(rc.out + 2) * CVF_TILE]);
+      const V3 p = mat_times(R, g);
+      addG(rc.a0, p);
+      sump = sump + p;
+      const V3 xc = centred(my, rc.a0, c);
+      M[0] += xc.x * g.x; M[1] += xc.x * g.y; M[2] += xc.x * g.z;
+      M[3] += xc.y * g.x; M[4] += xc.y * g.y; M[5] += xc.y * g.z;
+      M[6] += xc.z * g.x; M[7] += xc.z * g.y; M[8] += xc.z * g.z;
+    } else if (rc.type == CVF_FEAT_BOND) {
+      const BondG e = bond_eval(atom(my, rc.a0), atom(my, rc.a1));
+      const float gs = gt[rc.out * CVF_TILE];
+      addG(rc.a0, gs * e.ga);
+      addG(rc.a1, gs * e.gb);
+    } else if (rc.type == CVF_FEAT_ANGLE) {
+      const AngleG e = angle_eval(atom(my, rc.a0), atom(my, rc.a1), atom(my, rc.a2));
+      float gs = gt[rc.out * CVF_TILE];
+      if (pp.use_angle_value) gs = -gs / sqrtf(fmaxf(1.0f - e.cs * e.cs, 1e-30f));
+      addG(rc.a0, gs * e.ga);
+      addG(rc.a1, gs * e.gb);
+      addG(rc.a2, gs * e.gc);
+    } else {
+      const DihedralG e = dihedral_eval(atom(my, rc.a0), atom(my, rc.a1), atom(my, rc.a2), atom(my, rc.a3));
+      const float gs = pp.use_angle_value ? gt[rc.out * CVF_TILE]
+                                          : (gt[(rc.out + 1) * CVF_TILE] * e.cs - gt[rc.out * CVF_TILE] * e.sn);
+      addG(rc.a0, gs * e.g1);
+      addG(rc.a1, gs * e.g2);
+      addG(rc.a2, gs * e.g3);
+      addG(rc.a3, gs * e.g4);
+    }
+  }
+  const float inv_nal = 1.0f / (float)pp.n_align;
+  if (pp.has_position) {
+    // s = Kinv ax(R^T M);  Z = R [s]x;  G_b += Z ref_b - sum_p / n_align   (b over align atoms)
+    float T[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * M[j] + R[3 + i] * M[3 + j] + R[6 + i] * M[6 + j];
+    const V3 s = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
+    // [s]x rows: (0,-sz,sy), (sz,0,-sx), (-sy,sx,0)
+    float Z[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Z[3 * i + 0] = R[3 * i + 1] * s.z - R[3 * i + 2] * s.y;
+      Z[3 * i + 1] = -R[3 * i + 0] * s.z + R[3 * i + 2] * s.x;
+      Z[3 * i + 2] = R[3 * i + 0] * s.y - R[3 * i + 1] * s.x;
+    }
+    const V3 shift = inv_nal * sump;
+    for (int b = 0; b < pp.n_align; ++b) {
+      const V3 rf = v3(pp.ref_c[3 * b], pp.ref_c[3 * b + 1], pp.ref_c[3 * b + 2]);
+      addG(pp.align_idx[b], mat_times(Z, rf) - shift);
+    }
+  }
+  // ---- E = sum a G^2 ; u = a .* G (in place)
+  float E = 0.0f;
+  for (int j = 0; j < nc; ++j) {
+    const float Gj = Gl[j * CVF_TILE];
+    const float uj = a[j] * Gj;
+    E += uj * Gj;
+    Gl[j * CVF_TILE] = uj;
+  }
+  e_tiled[(tile * k + net) * CVF_TILE + lane] = E;
+  // ---- JVP: q = J u
+  V3 ubar = v3(0, 0, 0);
+  float dR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (pp.has_position) {
+    for (int b = 0; b < pp.n_align; ++b) ubar = ubar + getU(pp.align_idx[b]);
+    ubar = inv_nal * ubar;
+    float dH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < pp.n_align; ++b) {
+      const V3 u = getU(pp.align_idx[b]) - ubar;
+      const V3 rf = v3(pp.ref_c[3 * b], pp.ref_c[3 * b + 1], pp.ref_c[3 * b + 2]);
+      dH[0] += u.x * rf.x; dH[1] += u.x * rf.y; dH[2] += u.x * rf.z;
+      dH[3] += u.y * rf.x; dH[4] += u.y * rf.y; dH[5] += u.y * rf.z;
+      dH[6] += u.z * rf.x; dH[7] += u.z * rf.y; dH[8] += u.z * rf.z;
+    }
+    float T[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * dH[j] + R[3 + i] * dH[3 + j] + R[6 + i] * dH[6 + j];
+    const V3 w = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      dR[3 * i + 0] = R[3 * i + 1] * w.z - R[3 * i + 2] * w.y;
+      dR[3 * i + 1] = -R[3 * i + 0] * w.z + R[3 * i + 2] * w.x;
+      dR[3 * i + 2] = R[3 * i + 0] * w.y - R[3 * i + 1] * w.x;
+    }
+  }
+  for (int r = 0; r < pp.n_rec; ++r) {
+    const Rec rc = load_rec(pp.rec, r);
+    if (rc.type == CVF_FEAT_POSITION) {
+      const V3 qa = row_times(getU(rc.a0) - ubar, R) + row_times(centred(my, rc.a0, c), dR);
+      qt[rc.out * CVF_TILE] = qa.x;
+      qt[(rc.out + 1) * CVF_TILE] = qa.y;
+      qt[(rc.out + 2) * CVF_TILE] = qa.z;
+    } else if (rc.type == CVF_FEAT_BOND) {
+      const BondG e = bond_eval(atom(my, rc.a0), atom(my, rc.a1));
+      qt[rc.out * CVF_TILE] = dot(e.ga, getU(rc.a0)) + dot(e.gb, getU(rc.a1));
+    } else if (rc.type == CVF_FEAT_ANGLE) {
+      const AngleG e = angle_eval(atom(my, rc.a0), atom(my, rc.a1), atom(my, rc.a2));
+      float dv = dot(e.ga, getU(rc.a0)) + dot(e.gb, getU(rc.a1)) + dot(e.gc, getU(rc.a2));
+      if (pp.use_angle_value) dv = -dv / sqrtf(fmaxf(1.0f - e.cs * e.cs, 1e-30f));
+      qt[rc.out * CVF_TILE] = dv;
+    } else {
+      const DihedralG e = dihedral_eval(atom(my, rc.a0), atom(my, rc.a1), atom(my, rc.a2), atom(my, rc.a3));
+      const float dphi = dot(e.g1, getU(rc.a0)) + dot(e.g2, getU(rc.a1)) + dot(e.g3, getU(rc.a2)) + dot(e.g4, getU(rc.a3));
+      if (pp.use_angle_value) {
+        qt[rc.out * CVF_TILE] = dphi;
+      } else {
+        qt[rc.out * CVF_TILE] = -e.sn * dphi;
+        qt[(rc.out + 1) * CVF_TILE] = e.cs * dphi;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void metric_identity_kernel(int d, const float* __restrict__ a, int k,
+                                                              const float* __restrict__ g_tiled,
+                                                              float* __restrict__ q_tiled, float* __restrict__ e_tiled) {
+  const int lane = threadIdx.x;
+  const int64_t tile = blockIdx.x;
+  const int net = blockIdx.y;
+  const int64_t base = (tile * k + net) * (int64_t)d * CVF_TILE + lane;
+  float E = 0.0f;
+  for (int j = 0; j < d; ++j) {
+    const float g = g_tiled[base + j * CVF_TILE];
+    const float u = a[j] * g;
+    E += u * g;
+    q_tiled[base + j * CVF_TILE] = u;
+  }
+  e_tiled[(tile * k + net) * CVF_TILE + lane] = E;
+}
+
+}  // namespace
+
+extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled,
+                                     float* feat_rows, float* aux_tiled, void* stream) {
+  CVF_REQUIRE(pp && x && B > 0, "cvf_align_feature_fwd: null argument or empty batch (B=%lld)", (long long)B);
+  CVF_REQUIRE(feat_tiled || feat_rows, "cvf_align_feature_fwd: no output buffer");
+  const int64_t T = cvf_ntiles(B);
+  hipStream_t s = (hipStream_t)stream;
+  if (pp->mode == CVF_PP_IDENTITY) {
+    CVF_REQUIRE(pp->d_r == pp->n_coord, "identity preprocessing needs d_r == n_coord");
+    hipLaunchKernelGGL(k1_identity_kernel, dim3((unsigned)T), dim3(64), 0, s, pp->n_coord, x, B, feat_tiled, feat_rows);
+    return cvf_check_launch("k1_identity_kernel");
+  }
+  CVF_REQUIRE(pp->mode == CVF_PP_ALIGN, "unknown pp mode %d", pp->mode);
+  CVF_REQUIRE(pp->n_coord % 3 == 0 && pp->n_align >= 3 && pp->align_idx && pp->ref_c && pp->rec,
+              "cvf_align_feature_fwd: malformed descriptor (n_coord=%d n_align=%d)", pp->n_coord, pp->n_align);
+  const size_t lds = (size_t)CVF_TILE * x_tile_stride(pp->n_coord) * sizeof(float);
+  CVF_REQUIRE(lds <= 160 * 1024, "frames of %d coordinates do not fit the lane-per-frame kernel's LDS tile", pp->n_coord);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k1_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k1_align_kernel, dim3((unsigned)T), dim3(64), lds, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled);
+  return cvf_check_launch("k1_align_kernel");
+}
+
+extern "C" int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled,
+                                const float* a, int k, const float* g_tiled, float* q_tiled, float* e_tiled,
+                                void* stream) {
+  CVF_REQUIRE(pp && a && g_tiled && q_tiled && e_tiled && B > 0 && k >= 1 && k <= CVF_MAX_NETS,
+              "cvf_metric_apply: bad argument (B=%lld k=%d)", (long long)B, k);
+  const int64_t T = cvf_ntiles(B);
+  hipStream_t s = (hipStream_t)stream;
+  if (pp->mode == CVF_PP_IDENTITY) {
+    hipLaunchKernelGGL(metric_identity_kernel, dim3((unsigned)T, k), dim3(64), 0, s, pp->n_coord, a, k, g_tiled, q_tiled,
+                       e_tiled);
+    return cvf_check_launch("metric_identity_kernel");
+  }
+  CVF_REQUIRE(x && aux_tiled, "cvf_metric_apply: align mode needs x and aux");
+  const size_t lds = (size_t)CVF_TILE * (x_tile_stride(pp->n_coord) + pp->n_coord) * sizeof(float);
+  CVF_REQUIRE(lds <= 160 * 1024, "frames of %d coordinates do not fit the lane-per-frame metric kernel's LDS", pp->n_coord);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)metric_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(metric_align_kernel, dim3((unsigned)T, k), dim3(64), lds, s, *pp, x, B, aux_tiled, a, k, g_tiled,
+                     q_tiled, e_tiled);
+  return cvf_check_launch("metric_align_kernel");
+}

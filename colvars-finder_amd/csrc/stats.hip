@@ -1,0 +1,292 @@
+// K5: batch statistics of EigenFunctionTask.loss_func (core.py:406-416,426,428,446-452) in
+// fp64 with a fixed-order two-stage reduction (bitwise reproducible: every rank of a
+// data-parallel job must derive the same ordering cvec from the reduced vector), the scalar
+// tail of the loss (core.py:426-457) with its partial derivatives, and K6: Adam.
+#include "cvf_common.hpp"
+#include <stdarg.h>
+#include <stdio.h>
+
+// ---------------------------------------------------------------------------------------
+// error plumbing shared by all translation units
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void cvf_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int cvf_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    cvf_set_error("%s: %s", what, hipGetErrorString(e));
+    return -2;
+  }
+  return 0;
+}
+extern "C" const char* cvf_last_error(void) { return g_err; }
+extern "C" int cvf_version(void) { return 100; }
+
+extern "C" int cvf_ef_nstats(int k, int lag_idx) {
+  const int base = 1 + k + CVF_NPAIR(k);
+  return lag_idx == 0 ? base + k : base + 1 + 2 * k + k;
+}
+
+namespace {
+
+constexpr int kStatBlocks = 256;
+constexpr int kMaxStats = 1 + CVF_MAX_NETS + CVF_NPAIR(CVF_MAX_NETS) + 1 + 3 * CVF_MAX_NETS;
+
+// one wave per block; block g handles tiles g, g+G, ...; lane = frame
+__global__ __launch_bounds__(64) void ef_stats_partial_kernel(int k, int lag_idx, int64_t B, const float* __restrict__ w,
+                                                               const float* __restrict__ y, const float* __restrict__ e,
+                                                               const float* __restrict__ w_lag,
+                                                               const float* __restrict__ y_lag,
+                                                               double* __restrict__ partial) {
+  const int lane = threadIdx.x;
+  const int64_t T = (B + CVF_TILE - 1) / CVF_TILE;
+  const int npair = CVF_NPAIR(k);
+  double acc[kMaxStats];
+#pragma unroll
+  for (int i = 0; i < kMaxStats; ++i) acc[i] = 0.0;
+  for (int64_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
+    const int64_t frame = tile * CVF_TILE + lane;
+    const bool valid = frame < B;
+    const double wb = valid ? (double)w[frame] : 0.0;
+    double yv[CVF_MAX_NETS];
+#pragma unroll
+    for (int i = 0; i < CVF_MAX_NETS; ++i) yv[i] = i < k ? (double)y[(tile * k + i) * CVF_TILE + lane] : 0.0;
+    acc[0] += wb;
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < CVF_MAX_NETS; ++i) {
+      if (i < k) {
+        acc[1 + i] += wb * yv[i];
+#pragma unroll
+        for (int j = i; j < CVF_MAX_NETS; ++j)
+          if (j < k) acc[1 + k + p++] += wb * yv[i] * yv[j];
+      }
+    }
+    const int o = 1 + k + npair;
+    if (lag_idx == 0) {
+#pragma unroll
+      for (int i = 0; i < CVF_MAX_NETS; ++i)
+        if (i < k) acc[o + i] += wb * (double)e[(tile * k + i) * CVF_TILE + lane];
+    } else {
+      const double wl = valid ? (double)w_lag[frame] : 0.0;
+      acc[o] += wl;
+#pragma unroll
+      for (int i = 0; i < CVF_MAX_NETS; ++i)
+        if (i < k) {
+          const double yl = (double)y_lag[(tile * k + i) * CVF_TILE + lane];
+          acc[o + 1 + i] += wl * yl;
+          acc[o + 1 + k + i] += wl * yl * yl;
+          const double df = yl - yv[i];
+          acc[o + 1 + 2 * k + i] += wb * df * df;
+        }
+    }
+  }
+  const int ns = lag_idx == 0 ? 1 + k + npair + k : 1 + k + npair + 1 + 3 * k;
+#pragma unroll
+  for (int i = 0; i < kMaxStats; ++i)
+    if (i < ns) {
+      const double s = wave_sum(acc[i]);
+      if (lane == 0) partial[(int64_t)blockIdx.x * ns + i] = s;
+    }
+}
+
+__global__ void ef_stats_final_kernel(int ns, int nblocks, const double* __restrict__ partial, double* __restrict__ stats) {
+  const int i = threadIdx.x;
+  if (i >= ns) return;
+  double s = 0.0;
+  for (int g = 0; g < nblocks; ++g) s += partial[(int64_t)g * ns + i];
+  stats[i] = s;
+}
+
+// the scalar tail of loss_func, one thread, fp64
+__global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats, double* __restrict__ loss_vec,
+                               double* __restrict__ coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int k = cfg.k;
+  const int npair = CVF_NPAIR(k);
+  const double W = stats[0];
+  const double* S1 = stats + 1;
+  const double* S2 = stats + 1 + k;
+  double m[CVF_MAX_NETS], v[CVF_MAX_NETS], s2[CVF_MAX_NETS][CVF_MAX_NETS];
+  {
+    int p = 0;
+    for (int i = 0; i < k; ++i)
+      for (int j = i; j < k; ++j) {
+        s2[i][j] = s2[j][i] = S2[p++];
+      }
+  }
+  for (int i = 0; i < k; ++i) {
+    m[i] = S1[i] / W;                       // core.py:409
+    v[i] = s2[i][i] / W - m[i] * m[i];      // core.py:410
+  }
+  double eig[CVF_MAX_NETS], num[CVF_MAX_NETS], den[CVF_MAX_NETS];
+  double pref;
+  double vl[CVF_MAX_NETS], ml[CVF_MAX_NETS], Wl = 1.0;
+  const int o = 1 + k + npair;
+  if (cfg.lag_idx == 0) {
+    pref = 1.0 / (W * cfg.beta);            // core.py:426,438
+    for (int i = 0; i < k; ++i) {
+      num[i] = stats[o + i];
+      den[i] = v[i];
+      eig[i] = pref * num[i] / den[i];
+    }
+  } else {
+    Wl = stats[o];
+    for (int i = 0; i < k; ++i) {
+      ml[i] = stats[o + 1 + i] / Wl;                          // core.py:415
+      vl[i] = stats[o + 1 + k + i] / Wl - ml[i] * ml[i];      // core.py:416
+      num[i] = stats[o + 1 + 2 * k + i];
+      den[i] = v[i] + vl[i];
+    }
+    pref = 1.0 / (cfg.dt * cfg.lag_idx) / W;                  // core.py:428,440
+    for (int i = 0; i < k; ++i) eig[i] = pref * num[i] / den[i];
+  }
+  // cvec = argsort(eig) (core.py:432), stable insertion sort
+  int cvec[CVF_MAX_NETS];
+  for (int i = 0; i < k; ++i) cvec[i] = i;
+  if (cfg.sort_eigvals) {
+    for (int i = 1; i < k; ++i) {
+      const int c = cvec[i];
+      int j = i - 1;
+      while (j >= 0 && eig[cvec[j]] > eig[c]) {
+        cvec[j + 1] = cvec[j];
+        --j;
+      }
+      cvec[j + 1] = c;
+    }
+  }
+  // variational objective; generator: numerator AND denominator at cvec[idx] (core.py:438);
+  // transfer: numerator at idx, denominator at cvec[idx] (core.py:440, reproduced as is)
+  double npl = 0.0;
+  double gnum[CVF_MAX_NETS], gden[CVF_MAX_NETS];
+  for (int i = 0; i < k; ++i) gnum[i] = gden[i] = 0.0;
+  for (int idx = 0; idx < k; ++idx) {
+    const int c = cvec[idx];
+    const int nsrc = cfg.lag_idx == 0 ? c : idx;
+    npl += cfg.eig_w[idx] * num[nsrc] / den[c];
+    gnum[nsrc] += pref * cfg.eig_w[idx] / den[c];
+    gden[c] += -pref * cfg.eig_w[idx] * num[nsrc] / (den[c] * den[c]);
+  }
+  npl *= pref;
+  double pen = 0.0;
+  double cov[CVF_MAX_NETS][CVF_MAX_NETS];
+  for (int i = 0; i < k; ++i) pen += (v[i] - 1.0) * (v[i] - 1.0);           // core.py:446
+  for (int i = 0; i < k; ++i)
+    for (int j = i + 1; j < k; ++j) {
+      cov[i][j] = cov[j][i] = s2[i][j] / W - m[i] * m[j];                   // core.py:452
+      pen += cov[i][j] * cov[i][j];
+    }
+  const double loss = npl + cfg.alpha * pen;                                // core.py:455
+  loss_vec[0] = loss;
+  loss_vec[1] = npl;
+  loss_vec[2] = pen;
+  for (int idx = 0; idx < k; ++idx) {
+    loss_vec[3 + idx] = eig[cvec[idx]];                                     // core.py:434
+    loss_vec[3 + k + idx] = (double)cvec[idx];
+  }
+  // ---- partial derivatives (eigenvalues and cvec are constants: core.py:426,428 detach them)
+  double* gS1 = coef;
+  double* gS2 = coef + k;
+  double* gEt = coef + k + k * k;
+  double* gS1l = coef + 2 * k + k * k;
+  double* gS2l = coef + 3 * k + k * k;
+  for (int i = 0; i < k; ++i) {
+    const double Lv = gden[i] + 2.0 * cfg.alpha * (v[i] - 1.0);   // d loss / d var_i
+    double g1 = Lv * (-2.0 * m[i] / W);
+    for (int j = 0; j < k; ++j)
+      if (j != i) g1 += 2.0 * cfg.alpha * cov[i][j] * (-m[j] / W);
+    gS1[i] = g1;
+    for (int j = 0; j < k; ++j) gS2[i * k + j] = (i == j) ? Lv / W : 2.0 * cfg.alpha * cov[i][j] / W;
+    gEt[i] = gnum[i];
+    if (cfg.lag_idx > 0) {
+      const double Lvl = gden[i];                                 // d loss / d var'_i
+      gS1l[i] = Lvl * (-2.0 * ml[i] / Wl);
+      gS2l[i] = Lvl / Wl;
+    } else {
+      gS1l[i] = 0.0;
+      gS2l[i] = 0.0;
+    }
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                            const int32_t* __restrict__ step_in) {
+  // torch.optim.Adam (single-tensor path): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+  // theta -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+  const int t = *step_in + 1;
+  const double bc1 = 1.0 - pow((double)b1, (double)t);
+  const double bc2 = 1.0 - pow((double)b2, (double)t);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = grad[i];
+    const float mi = m[i] + (g - m[i]) * (1.0f - b1);   // lerp form used by torch
+    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    theta[i] -= step_size * (mi / denom);
+  }
+}
+__global__ void bump_step_kernel(int32_t* step) { *step += 1; }
+
+__global__ void sgd_kernel(float* __restrict__ theta, const float* __restrict__ grad, int64_t n, float lr) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    theta[i] -= lr * grad[i];
+}
+
+}  // namespace
+
+extern "C" int64_t cvf_ef_stats_scratch_doubles(int k, int lag_idx) {
+  return (int64_t)kStatBlocks * cvf_ef_nstats(k, lag_idx);
+}
+
+extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
+                            const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, void* stream) {
+  CVF_REQUIRE(cfg && w && y_tiled && scratch && stats && B > 0, "cvf_ef_stats: bad argument");
+  CVF_REQUIRE(cfg->k >= 1 && cfg->k <= CVF_MAX_NETS, "cvf_ef_stats: k=%d out of range", cfg->k);
+  if (cfg->lag_idx == 0) CVF_REQUIRE(e_tiled, "cvf_ef_stats: generator mode needs e_tiled");
+  else CVF_REQUIRE(w_lag && y_lag_tiled, "cvf_ef_stats: transfer mode needs lagged inputs");
+  const int ns = cvf_ef_nstats(cfg->k, cfg->lag_idx);
+  const int64_t T = cvf_ntiles(B);
+  const int G = (int)(T < kStatBlocks ? T : kStatBlocks);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ef_stats_partial_kernel, dim3(G), dim3(64), 0, s, cfg->k, cfg->lag_idx, B, w, y_tiled, e_tiled,
+                     w_lag, y_lag_tiled, scratch);
+  int rc = cvf_check_launch("ef_stats_partial_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ef_stats_final_kernel, dim3(1), dim3(64), 0, s, ns, G, scratch, stats);
+  return cvf_check_launch("ef_stats_final_kernel");
+}
+
+extern "C" int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* loss_vec, double* coef, void* stream) {
+  CVF_REQUIRE(cfg && stats && loss_vec && coef, "cvf_ef_loss: bad argument");
+  CVF_REQUIRE(cfg->k >= 1 && cfg->k <= CVF_MAX_NETS, "cvf_ef_loss: k=%d out of range", cfg->k);
+  hipLaunchKernelGGL(ef_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *cfg, stats, loss_vec, coef);
+  return cvf_check_launch("ef_loss_kernel");
+}
+
+extern "C" int cvf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
+                             double beta2, double eps, int32_t* step_count, void* stream) {
+  CVF_REQUIRE(theta && grad && m && v && step_count && n > 0, "cvf_adam_step: bad argument");
+  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, grad, m, v, n, (float)lr,
+                     (float)beta1, (float)beta2, (float)eps, step_count);
+  int rc = cvf_check_launch("adam_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_count);
+  return cvf_check_launch("bump_step_kernel");
+}
+
+extern "C" int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, void* stream) {
+  CVF_REQUIRE(theta && grad && n > 0, "cvf_sgd_step: bad argument");
+  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, grad, n, (float)lr);
+  return cvf_check_launch("sgd_kernel");
+}

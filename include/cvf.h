@@ -1,0 +1,163 @@
+/* cvf.h - C ABI of libcvf_hip.so, the MI355X (gfx950) hot path of colvarsfinder.
+ *
+ * The reference (zwpku/colvars-finder v0.1.14) exposes NO FFI for this path: it is
+ * plain PyTorch behind Python objects.  This header is therefore
+ * the boundary the reference's Python layer would bind with ctypes; every entry point
+ * names the reference code it replaces (file:line under the reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - every function is stream-ordered on `stream` (a hipStream_t passed as void*),
+ *     never synchronises the host, never allocates, never frees: the caller owns all
+ *     buffers (sizes are returned by the cvf_*_size helpers);
+ *   - return value: 0 on success, negative on error (cvf_last_error() has the text);
+ *   - "tiled" tensors are laid out [tile][row][64]: frame b lives in tile b/64, lane
+ *     b%64; rows are features / nets / auxiliary slots.  Tail tiles are padded with
+ *     copies of the last frame whose weight is forced to 0.
+ *   - theta / grad / adam moments are flat fp32 buffers in torch's parameters() order
+ *     (per Linear: weight [out,in] row-major, then bias [out]); cvf_mlp_desc holds the
+ *     offsets.
+ */
+#ifndef CVF_H
+#define CVF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVF_TILE 64
+#define CVF_MAX_NETS 8
+#define CVF_MAX_LAYERS 12
+#define CVF_AUX_ROWS 18 /* R (9, row-major), centroid (3), Kinv (6: 00 01 02 11 12 22) */
+
+/* feature record types: molann's ids (examples/dipeptide/main.ipynb:306-307 prints
+ * "position ... type_id 3") */
+enum { CVF_FEAT_ANGLE = 0, CVF_FEAT_BOND = 1, CVF_FEAT_DIHEDRAL = 2, CVF_FEAT_POSITION = 3 };
+enum { CVF_PP_IDENTITY = 0, CVF_PP_ALIGN = 1 };
+
+/* The preprocessing layer r(x): torch.nn.Identity (examples/2d/2d.ipynb:485) or the
+ * Kabsch alignment + feature map the reference gets from molann
+ * (examples/dipeptide/main.ipynb:333-348; consumed at core.py:403,414,635). */
+typedef struct cvf_pp_desc {
+  int32_t mode;            /* CVF_PP_* */
+  int32_t n_coord;         /* floats per frame: 3*N (align) or d (identity) */
+  int32_t n_align;         /* number of align atoms */
+  int32_t n_rec;           /* number of feature records */
+  int32_t d_r;             /* output dimension */
+  int32_t use_angle_value; /* 0: angle->cos, dihedral->(cos,sin); 1: radians */
+  int32_t has_position;    /* any CVF_FEAT_POSITION record */
+  int32_t pad_;
+  const int32_t* align_idx; /* [n_align] atom indices into the frame */
+  const float* ref_c;       /* [n_align*3] reference positions minus their centroid */
+  const int32_t* rec;       /* [n_rec*6]: type, a0, a1, a2, a3, out_offset (one record per
+                               position ATOM: a0 = atom, 3 outputs) */
+} cvf_pp_desc;
+
+/* k identical feed-forward nets (colvarsfinder.nn.EigenFunctions, nn.py:242-293) or one
+ * chain (AutoEncoder = encoder followed by decoder, nn.py:61-114). */
+typedef struct cvf_mlp_desc {
+  int32_t n_nets;
+  int32_t n_layers;                      /* Linear layers per net */
+  int32_t dims[CVF_MAX_LAYERS + 1];      /* widths d0..dL */
+  int32_t act[CVF_MAX_LAYERS];           /* 1: tanh after this Linear (nn.py:55-57) */
+  int32_t w_off[CVF_MAX_NETS][CVF_MAX_LAYERS];
+  int32_t b_off[CVF_MAX_NETS][CVF_MAX_LAYERS];
+  int32_t n_params;
+} cvf_mlp_desc;
+
+/* Scalars of EigenFunctionTask (core.py:293-354). */
+typedef struct cvf_ef_cfg {
+  int32_t k;
+  int32_t lag_idx;       /* 0: generator (core.py:418-426,438); >0: transfer operator (428,440) */
+  int32_t sort_eigvals;  /* core.py:430-434 */
+  int32_t pad_;
+  double alpha;          /* core.py:455 */
+  double beta;           /* core.py:426,438 */
+  double dt;             /* core.py:428,440 */
+  double eig_w[CVF_MAX_NETS];
+} cvf_ef_cfg;
+
+/* layout of the fp64 statistics vector (collective #1) */
+#define CVF_NPAIR(k) ((k) * ((k) + 1) / 2)
+/* generator: [W, S1(k), S2(k(k+1)/2, i<=j row-major), E(k)]
+ * transfer : [W, S1(k), S2(...), W', S1'(k), S2'_ii(k), T(k)] */
+int cvf_ef_nstats(int k, int lag_idx);
+/* loss vector written by cvf_ef_loss: [loss, npl, pen, eig_sorted(k), cvec(k) as doubles] */
+#define CVF_LOSS_LEN(k) (3 + 2 * (k))
+/* coefficient vector written by cvf_ef_loss and read by cvf_ef_backward:
+ * [gS1(k), gS2(k*k symmetric full), gE_or_gT(k), gS1'(k), gS2'_ii(k)] */
+#define CVF_COEF_LEN(k) (4 * (k) + (k) * (k))
+
+int cvf_version(void);
+const char* cvf_last_error(void);
+
+/* --- K1: alignment + features, forward.  Replaces pp_layer(X) at core.py:403,414,635.
+ * x [B, n_coord] row-major fp32.  feat_tiled [T][d_r][64] and/or feat_rows [B][d_r]
+ * (either may be NULL); aux_tiled [T][18][64] (may be NULL; identity mode ignores it). */
+int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
+                          float* aux_tiled, void* stream);
+
+/* --- K2+K3: per frame and net, q = J A J^T g and E = g^T J A J^T g with J the Jacobian
+ * of r at the frame and A = diag(a).  Replaces the k autograd.grad calls through
+ * pp_layer at core.py:424 and the a-weighted square sums at core.py:426,438; the
+ * [B,3N,k] gradient tensor is never materialised.
+ * g_tiled, q_tiled [T][k][d_r][64]; e_tiled [T][k][64]; a [n_coord]. */
+int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled, const float* a,
+                     int k, const float* g_tiled, float* q_tiled, float* e_tiled, void* stream);
+
+/* --- K4a: k nets forward (+ gradient of each output w.r.t. the features).
+ * Replaces self.model(...) at core.py:403,414 (nn.py:293).
+ * y_tiled [T][k][64]; g_tiled [T][k][d0][64] or NULL. */
+int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* feat_tiled, int64_t n_tiles,
+                   float* y_tiled, float* g_tiled, void* stream);
+
+/* --- K5: batch statistics (core.py:406-416,426,428,446-452), fp64, fixed-order two
+ * stage reduction.  w [B]; y_tiled [T][k][64]; generator: e_tiled [T][k][64];
+ * transfer: y_lag_tiled, w_lag.  scratch: cvf_ef_stats_scratch_doubles() doubles. */
+int64_t cvf_ef_stats_scratch_doubles(int k, int lag_idx);
+int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
+                 const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, void* stream);
+
+/* --- loss, eigenvalues, ordering and the partial derivatives d loss / d stat
+ * (core.py:426-457 after the sums).  One wave; runs after the cross-rank all-reduce of
+ * `stats` when there is one. */
+int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* loss_vec, double* coef, void* stream);
+
+/* --- K4b: parameter gradient of the loss given the coefficients (what loss.backward()
+ * does at core.py:517): reverse mode over the nets and, in generator mode, over their
+ * directional derivative along q.  Partial sums per block go to `slab`
+ * (cvf_ef_backward_slab_floats floats), then are summed in fixed order into grad [P].
+ * transfer mode: feat/y hold 2T tiles (frames then their lagged partners). */
+int64_t cvf_ef_backward_slab_floats(const cvf_mlp_desc* mlp, int64_t n_tiles);
+int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, int64_t B, const float* w,
+                    const float* w_lag, const float* feat_tiled, const float* y_tiled, const float* q_tiled,
+                    const double* coef, float* slab, float* grad, void* stream);
+
+/* --- AutoEncoder: weighted reconstruction loss and its parameter gradient in one pass
+ * (core.py:664-666,708).  feat_rows [n][d0] row-major (the precomputed feature
+ * trajectory of core.py:635); idx NULL or [B] frame indices into it; w [B]; inv_wsum =
+ * 1/sum(w) (host-known: batches are static).  out2 [2] doubles: {sum w*err, sum w}.
+ * grad may be NULL (test pass, core.py:725-735). */
+int64_t cvf_ae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B);
+int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx, int64_t B,
+                const float* w, double inv_wsum, float* scratch, double* out2, float* grad, void* stream);
+
+/* --- nets forward on row-major features (inference: colvar_model(), core.py:372-382,
+ * 640-647).  out [B][n_out] where n_out = n_nets * d_L; upto_layer < n_layers stops a
+ * single chain early (AutoEncoder encoder). */
+int cvf_mlp_eval_rows(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, int64_t B, int upto_layer,
+                      float* out, void* stream);
+
+/* --- K6: Adam (torch.optim.Adam defaults as constructed at core.py:164: betas
+ * (0.9,0.999), eps 1e-8, no weight decay, no amsgrad), one launch over the flat buffer.
+ * step_count is a device int32 incremented by the kernel (graph-replay safe). */
+int cvf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
+                  double beta2, double eps, int32_t* step_count, void* stream);
+int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,244 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the golden
+fixtures the reference produced.
+
+Tolerances.  Everything on this path is floating point.  north_star asks for per-step loss and
+learned-CV outputs within 1e-5 relative of the reference's CPU path; the reference's own fp32 run
+differs from its fp64 run by 6.6e-6..6.4e-5 relative, so
+  * against the fp64 fixtures / fp64 oracle (the exact answer) the bar is RTOL64 = 2e-5
+    (fp32 arithmetic of the kernels themselves),
+  * against the fp32 fixtures the bar is RTOL32 = 2e-4 (the reference's own fp32 noise on top).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from tests import goldens
+from tests.synth import Traj, diag_coeff_for, make_molecule_traj, random_rotations
+
+pytestmark = pytest.mark.gpu
+
+RTOL64, RTOL32 = 2e-5, 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _restore_dtype():
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+def make_layer(spec, n_atoms, dev):
+    from colvarsfinder import pp
+    if spec is None:
+        return torch.nn.Identity()
+    return pp.AlignFeatureLayer(n_atoms, spec["align_idx"], spec["ref_pos"], spec["features"], spec["use_angle_value"]).to(dev)
+
+
+def oracle_layer(spec):
+    from oracle.pp import AlignFeature
+    if spec is None:
+        return torch.nn.Identity()
+    return AlignFeature(spec["align_idx"], spec["ref_pos"], spec["features"], spec["use_angle_value"])
+
+
+MIXED = [("position", (0, 2, 3, 5)), ("bond", (0, 1)), ("bond", (2, 7)), ("angle", (1, 2, 3)),
+         ("dihedral", (0, 1, 2, 3)), ("dihedral", (4, 5, 6, 7)), ("angle", (6, 8, 9))]
+
+
+# ------------------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("n_atoms,B,feats,angle_value", [
+    (10, 300, None, False), (22, 256, None, False), (22, 1, None, False), (22, 65, None, False),
+    (10, 300, MIXED, False), (10, 131, MIXED, True), (40, 200, None, False)])
+def test_k1_align_feature_vs_oracle(dev, n_atoms, B, feats, angle_value):
+    traj, _, ref = make_molecule_traj(n_atoms, B, seed=31 + n_atoms)
+    align = list(range(n_atoms)) if feats is None else [0, 1, 2, 4, 5, 8]
+    spec = dict(align_idx=align, ref_pos=ref[align], features=feats or [("position", tuple(range(n_atoms)))],
+                use_angle_value=angle_value)
+    got = make_layer(spec, n_atoms, dev)(torch.tensor(traj, device=dev)).cpu().numpy()
+    torch.set_default_dtype(torch.float64)
+    want = oracle_layer(spec)(torch.tensor(traj, dtype=torch.float64)).numpy()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6 * np.abs(want).max())
+
+
+def test_k1_rigid_motion_invariance_full_size(dev):
+    """size-independent property at BASELINE config-2 size (22 atoms x 100k frames)."""
+    n_atoms, B = 22, 100_000
+    traj, _, ref = make_molecule_traj(n_atoms, B, seed=77)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_atoms)))], use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    rs = np.random.RandomState(5)
+    Q = random_rotations(rs, B).astype(np.float32)
+    moved = np.einsum("bij,baj->bai", Q, traj) + rs.normal(size=(B, 1, 3)).astype(np.float32)
+    f0 = layer(torch.tensor(traj, device=dev))
+    f1 = layer(torch.tensor(moved, device=dev))
+    assert torch.isfinite(f0).all()
+    assert float((f0 - f1).abs().max()) < 5e-5 * float(f0.abs().max())
+    # aligned coordinates are centred: per frame the position features sum to ~0 per axis
+    assert float(f0.reshape(B, n_atoms, 3).sum(1).abs().max()) < 1e-4 * float(f0.abs().max()) * n_atoms
+
+
+def test_k1_identity_and_reference_frame(dev):
+    n_atoms = 12
+    _, _, ref = make_molecule_traj(n_atoms, 4, seed=3)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_atoms)))], use_angle_value=False)
+    x = (ref[None] + np.array([1.0, -2.0, 0.5])).astype(np.float32)
+    got = make_layer(spec, n_atoms, dev)(torch.tensor(x, device=dev)).cpu().numpy().reshape(n_atoms, 3)
+    np.testing.assert_allclose(got, ref - ref.mean(0), atol=2e-6)   # frame == reference -> R = I
+    # reflection: still a proper rotation (orthogonal residual cannot vanish, output stays finite and centred)
+    mir = (x * np.array([1.0, 1.0, -1.0])).astype(np.float32)
+    out = make_layer(spec, n_atoms, dev)(torch.tensor(mir, device=dev)).cpu().numpy().reshape(n_atoms, 3)
+    torch.set_default_dtype(torch.float64)
+    want = oracle_layer(spec)(torch.tensor(mir, dtype=torch.float64)).numpy().reshape(n_atoms, 3)
+    np.testing.assert_allclose(out, want, atol=5e-6)
+
+
+# ------------------------------------------------------------------------------------------------ loss_func KATs
+def build_task(g, dev, tag_dtype=torch.float32):
+    from colvarsfinder import core, nn
+    k = int(g["k"])
+    dims = [int(d) for d in g["layer_dims"]]
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(goldens.state_dict(g, dtype=torch.float32))
+    traj = np.array(g["traj"])
+    spec = goldens.pp_spec(g)
+    layer = make_layer(spec, traj.shape[1] if traj.ndim == 3 else 0, dev)
+    lag = int(g["lag_idx"])
+    a = torch.tensor(np.array(g["diag_coeff"]), dtype=torch.float32) if lag == 0 else None
+    kw = dict(diag_coeff=a, beta=float(g["beta"]), lag_tau=lag * float(g["dt"]), k=k, device=dev, verbose=False,
+              save_model_every_step=0)
+    if "sort" in g.files:
+        kw["sort_eigvals_in_training"] = bool(g["sort"])
+    if "lr" in g.files:
+        kw.update(learning_rate=float(g["lr"]), batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]))
+    task = core.EigenFunctionTask(Traj(traj, np.array(g["w"]), float(g["dt"])), layer, model, "/tmp/cvf_test", float(g["alpha"]),
+                                  [float(x) for x in g["eig_w"]], **kw)
+    return task, model
+
+
+@pytest.mark.parametrize("tag,rtol", [("f64", RTOL64), ("f32", RTOL32)])
+@pytest.mark.parametrize("name", goldens.KAT_CASES)
+def test_loss_func_kat(dev, name, tag, rtol):
+    g = goldens.load(name, tag)
+    task, model = build_task(g, dev)
+    lag = int(g["lag_idx"])
+    traj, w = np.array(g["traj"]), np.array(g["w"])
+    B = traj.shape[0] - lag
+    X, wt = torch.tensor(traj[:B]), torch.tensor(w[:B])
+    Xl = torch.tensor(traj[lag:lag + B]) if lag else None
+    wl = torch.tensor(w[lag:lag + B]) if lag else None
+    loss, eig, npl, pen, cvec = task.loss_func(X, wt, Xl, wl)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=rtol)
+    np.testing.assert_allclose(float(npl), float(g["npl"]), rtol=rtol)
+    np.testing.assert_allclose(float(pen), float(g["pen"]), rtol=rtol, atol=rtol * abs(float(g["loss"])) / float(g["alpha"]))
+    np.testing.assert_allclose(eig.numpy(), g["eig"], rtol=rtol)
+    assert list(cvec) == list(g["cvec"])
+    task.backward()
+    # absolute tolerance on the scale of the whole gradient: some entries are analytically zero (the loss
+    # does not change when a constant is added to an eigenfunction, so d loss / d last-bias == 0) and hold
+    # nothing but roundoff, in the reference (1e-13 in fp64, 1e-6..4e-4 in fp32) as well as here
+    gmax = max(float(np.abs(g["grad/" + n]).max()) for n, _ in model.named_parameters())
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad/" + n], rtol=20 * rtol, atol=20 * rtol * gmax, err_msg=n)
+
+
+def test_stats_are_bitwise_reproducible(dev):
+    g = goldens.load("kat_gen_mol22_k3", "f32")
+    task, _ = build_task(g, dev)
+    X, wt = torch.tensor(np.array(g["traj"])), torch.tensor(np.array(g["w"]))
+    task.loss_func(X, wt, None, None)
+    s0 = task._ws[X.shape[0]].stats.clone()
+    for _ in range(3):
+        task.loss_func(X, wt, None, None)
+        assert torch.equal(task._ws[X.shape[0]].stats, s0)
+
+
+# ------------------------------------------------------------------------------------------------ train traces
+@pytest.mark.parametrize("tag,rtol", [("f64", 5 * RTOL64), ("f32", RTOL32)])
+@pytest.mark.parametrize("name", goldens.EF_TRAIN_CASES)
+def test_ef_train_trace(dev, name, tag, rtol):
+    g = goldens.load(name, tag)
+    task, model = build_task(g, dev)
+    np.random.seed(int(g["seed"]))
+    task.train()
+    tr = np.stack([e[0].numpy() for e in task.loss_list])
+    te = np.stack([e[1].numpy() for e in task.loss_list])
+    np.testing.assert_allclose(tr, g["train_loss"], rtol=rtol, atol=rtol)
+    np.testing.assert_allclose(te, g["test_loss"], rtol=rtol, atol=rtol)
+    assert list(task._cvec) == list(g["cvec"])
+    np.testing.assert_allclose(task.train_loss_df.to_numpy(), g["train_loss_df"], rtol=rtol, atol=rtol)
+    assert list(task.train_loss_df.columns) == [str(s) for s in g["loss_names"]]
+    # The last bias of every eigenfunction is excluded: its exact gradient is 0 (shift invariance of the loss),
+    # Adam turns the roundoff in it into +-lr steps, and the reference's own fp32 and fp64 runs end 0.016 apart
+    # in that entry.  For the same reason the learned CVs are compared up to an additive constant per CV.
+    last_bias = f".{len(g['layer_dims']) - 1}.bias"
+    for n, p in model.state_dict().items():
+        if n.endswith(last_bias):
+            continue
+        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=50 * rtol, atol=50 * rtol, err_msg=n)
+    probe = torch.tensor(np.array(g["traj"])[:64], device=dev, dtype=torch.float32)
+    cv = task.colvar_model()(probe).detach().cpu().numpy()
+    ref_cv = np.array(g["colvar_probe"])
+    np.testing.assert_allclose(cv - cv.mean(0), ref_cv - ref_cv.mean(0), rtol=50 * rtol, atol=50 * rtol)
+
+
+# ------------------------------------------------------------------------------------------------ autoencoder
+@pytest.mark.parametrize("tag,rtol", [("f64", 5 * RTOL64), ("f32", RTOL32)])
+@pytest.mark.parametrize("name", goldens.AE_TRAIN_CASES)
+def test_ae_train_trace(dev, name, tag, rtol):
+    from colvarsfinder import core, nn
+    g = goldens.load(name, tag)
+    e_dims, d_dims = [int(d) for d in g["e_dims"]], [int(d) for d in g["d_dims"]]
+    model = nn.AutoEncoder(e_dims, d_dims)
+    model.load_state_dict(goldens.state_dict(g, dtype=torch.float32))
+    traj = np.array(g["traj"])
+    layer = make_layer(goldens.pp_spec(g), traj.shape[1] if traj.ndim == 3 else 0, dev)
+    task = core.AutoEncoderTask(Traj(traj, np.array(g["w"]), 0.5), layer, model, "/tmp/cvf_test", learning_rate=float(g["lr"]),
+                                batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]), device=dev, verbose=False,
+                                save_model_every_step=0)
+    np.testing.assert_allclose(task._feature_traj.cpu().numpy(), g["features"], rtol=1e-5, atol=5e-6 * np.abs(g["features"]).max())
+    n0 = min(256, traj.shape[0])
+    l0 = task.weighted_MSE_loss(task._feature_traj[:n0], task._weights[:n0])
+    task.backward()
+    np.testing.assert_allclose(float(l0), float(g["loss0"]), rtol=rtol)
+    for n, p in model.named_parameters():
+        ref = g["grad/" + n]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=20 * rtol, atol=20 * rtol * max(1e-3, np.abs(ref).max()), err_msg=n)
+    np.random.seed(int(g["seed"]))
+    task.train()
+    np.testing.assert_allclose(np.stack([e[0].numpy() for e in task.loss_list]), g["train_loss"], rtol=rtol)
+    np.testing.assert_allclose(np.stack([e[1].numpy() for e in task.loss_list]), g["test_loss"], rtol=rtol)
+    for n, p in model.state_dict().items():
+        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=50 * rtol, atol=50 * rtol, err_msg=n)
+    probe = torch.tensor(traj[:64], device=dev, dtype=torch.float32)
+    cv = task.colvar_model()(probe).detach().cpu().numpy()
+    np.testing.assert_allclose(cv, g["colvar_probe"], rtol=50 * rtol, atol=50 * rtol)
+
+
+# ------------------------------------------------------------------------------------------------ Adam
+def test_fused_adam_matches_torch(dev):
+    from colvarsfinder import _hip
+    lib = _hip.lib()
+    n = 6603
+    gen = torch.Generator().manual_seed(0)
+    theta0 = torch.randn(n, generator=gen)
+    ref = theta0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    theta = theta0.to(dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step = torch.zeros(1, device=dev, dtype=torch.int32)
+    for it in range(25):
+        grad = torch.randn(n, generator=gen) * (10.0 ** (it % 5 - 3))
+        ref.grad = grad.clone()
+        opt.step()
+        gd = grad.to(dev)
+        _hip.check(lib.cvf_adam_step(_hip.ptr(theta), _hip.ptr(gd), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8,
+                                     _hip.ptr(step), _hip.stream()), "adam")
+    assert int(step.item()) == 25
+    np.testing.assert_allclose(theta.cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-7)
