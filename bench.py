@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py - MD frames/sec through the EigenFunctionTask train step on MI355X.
+
+Workload (BASELINE.json config 3, SURVEY.md section 8d "C3"): alanine-dipeptide-shaped synthetic
+trajectory, 22 atoms, alignment on all atoms + position features (d_r = 66), EigenFunctionTask in
+generator mode with k = 3 nets [66,20,20,20,1], diffusion-weighted diag_coeff, alpha = 20, Adam.
+One "step" = one full train step on one batch resident in HBM: align+features (K1), nets forward and
+input gradients (K4a), q = J A J^T g (K2/K3), batch sums (K5), loss tail, parameter gradient (K4b),
+Adam (K6).  With N > 1 (one process per GPU, launched by torch.distributed.run) every rank owns its own
+shard of frames and the global batch is N x --batch frames (weak scaling); the two all-reduces of
+SURVEY.md section 8e (batch sums before the backward pass, flat gradient after it) run over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = frames of all ranks / second.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "colvars-finder_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+N_ATOMS, K_NETS, LAYERS = 22, 3, [66, 20, 20, 20, 1]
+ALPHA, EIG_W, BETA, LR = 20.0, [1.0, 0.75, 0.5], 1.0, 1e-3
+SEED = 20260103
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+
+# algorithmic work per frame (DESIGN.md section "Kernels")
+P_W = 66 * 20 + 20 * 20 + 20 * 20 + 20            # multiply-adds of one net's forward
+K1_BYTES = 12 * N_ATOMS + 4 + 4 * 66              # 532 B/frame
+FLOP_FWD = 2 * K_NETS * (P_W + (P_W - 66 * 20) + 66 * 20)            # forward + d-chain + g = W1^T d
+FLOP_BWD = 2 * K_NETS * (P_W + (P_W - 66 * 20) + P_W + 800 + 2 * P_W)  # fwd, d-chain, tangent, zbar-chain, outer products
+
+
+def make_shard(n_frames, rank):
+    from tests.synth import make_weights, random_rotations
+    ref = np.random.RandomState(SEED).normal(scale=2.0, size=(N_ATOMS, 3))
+    rs = np.random.RandomState(SEED + 1 + rank)
+    xi = rs.normal(scale=0.3, size=(n_frames, N_ATOMS, 3))
+    Q = random_rotations(rs, n_frames)
+    t = rs.normal(size=(n_frames, 1, 3))
+    x = (np.einsum("bij,baj->bai", Q, ref[None] + xi) + t).astype(np.float32)
+    return x, make_weights(rs, n_frames), ref
+
+
+def cpu_baseline(x, w, ref, a, sd0, batch, budget_s):
+    """The oracle's train step (pure PyTorch on the host cores, autograd through linalg.svd like the
+    reference's CPU path) on the same first batch; bounded to ~budget_s seconds."""
+    from oracle import losses
+    from oracle.pp import AlignFeature
+    ncores = min(len(os.sched_getaffinity(0)), 16)   # the GPU box grants a 16-core share per GPU
+    torch.set_num_threads(ncores)
+    pp = AlignFeature(list(range(N_ATOMS)), ref, [("position", tuple(range(N_ATOMS)))])
+    sd = {n: p.clone().requires_grad_(True) for n, p in sd0.items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=LR)
+    X0, w0 = torch.tensor(x[:batch]), torch.tensor(w[:batch], dtype=torch.float32)
+
+    def step():
+        X = X0.clone().requires_grad_(True)
+        opt.zero_grad(set_to_none=True)
+        loss = losses.ef_loss(sd, K_NETS, pp, X, w0, alpha=ALPHA, eig_w=EIG_W, diag_coeff=a, beta=BETA)[0]
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 100:
+            break
+    return dict(value=batch * n / el, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} train steps of the CPU oracle (PyTorch fp32, autograd through linalg.svd) on the same "
+                       f"first batch of {batch} frames, {el:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=20000, help="frames per GPU per step (reference notebook: 20000)")
+    ap.add_argument("--frames", type=int, default=100000, help="frames per GPU shard (config 3: 100k)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 disables it)")
+    args = ap.parse_args()
+
+    from colvarsfinder import _dist, core, nn, pp
+    from tests.synth import Traj, diag_coeff_for
+
+    _dist.init_from_env("nccl")
+    world, rank = _dist.world(), _dist.rank()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+
+    x, w, ref = make_shard(args.frames, rank)
+    a = torch.tensor(diag_coeff_for(N_ATOMS, SEED), dtype=torch.float32)
+    torch.manual_seed(SEED)
+    model = nn.EigenFunctions(LAYERS, K_NETS)
+    sd0 = {n: p.detach().clone() for n, p in model.state_dict().items()}
+    layer = pp.AlignFeatureLayer(N_ATOMS, list(range(N_ATOMS)), ref, [("position", tuple(range(N_ATOMS)))])
+    task = core.EigenFunctionTask(Traj(x, w, 1.0), layer, model, "/tmp/cvf_bench", ALPHA, EIG_W, diag_coeff=a, beta=BETA,
+                                  lag_tau=0, learning_rate=LR, k=K_NETS, batch_size=args.batch, device=dev, verbose=False,
+                                  save_model_every_step=0)
+    B = min(args.batch, args.frames)
+    n_batches = args.frames // B
+    X, Wt = task._traj, task._weights
+
+    def step(i):
+        s = (i % n_batches) * B
+        return task.train_step(X[s:s + B], Wt[s:s + B])
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    task._events = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss_vec = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events, task._events = task._events, None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax)
+    final_loss = float(loss_vec[0])
+    assert np.isfinite(final_loss), "training diverged"
+
+    # per-kernel average launch duration from the HIP events recorded inside the timed region
+    kern_ms = {name: float(np.mean([s_.elapsed_time(e_) for s_, e_ in ev])) for name, ev in events.items()}
+    if rank != 0:
+        return
+    dom = max(kern_ms, key=kern_ms.get)
+    if dom in ("cvf_ef_backward", "cvf_ef_mlp_fwd"):
+        flop = (FLOP_BWD if dom == "cvf_ef_backward" else FLOP_FWD) * B
+        ach = flop / (kern_ms[dom] * 1e-3) / 1e12
+        roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS,
+                    traffic=None, avg_launch_us=kern_ms[dom] * 1e3,
+                    note="fp32 work (VALU chains + f32-input MFMA weight gradients); peak = fp32 vector = fp32 MFMA rate")
+    else:
+        ach = K1_BYTES * B / (kern_ms[dom] * 1e-3) / 1e9
+        roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+                    avg_launch_us=kern_ms[dom] * 1e3)
+    k1 = kern_ms["cvf_align_feature_fwd"]
+    k1_gbs = K1_BYTES * B / (k1 * 1e-3) / 1e9
+    out = {
+        "metric": "MD frames/sec through EigenFunctionTask train step",
+        "value": world * B * args.steps / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: alanine-dipeptide-shaped EigenFunctionTask, generator mode, k=3, "
+                               "22 atoms, align+position features d_r=66, nets [66,20,20,20,1], diag_coeff, Adam",
+                   "frames_per_gpu": args.frames, "batch_per_gpu": B, "global_batch": world * B,
+                   "parallelism": f"dp{world} (frames sharded; all-reduce of batch sums + flat gradient)"},
+        "roofline": roof,
+        "roofline_align_feature": {"kernel": "cvf_align_feature_fwd", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": k1 * 1e3,
+                                   "bytes_per_frame": K1_BYTES, "frames_per_launch": B},
+        "kernel_avg_us": {n: v * 1e3 for n, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
+        "final_loss": final_loss,
+    }
+    if world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(x, w, ref, a, sd0, B, args.cpu_seconds)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -95,6 +95,16 @@ class _FlatParams:
                 assert (fin, fout, act) == (d.dims[l], d.dims[l + 1], d.act[l]), "nets must share one architecture"
                 d.w_off[i][l], d.b_off[i][l] = wo, bo
         self.desc = d
+        # second copy of the weights as MFMA fragments (EigenFunctions nets only; see csrc/cvf_pack.hpp)
+        n_pack = _hip.lib().cvf_ef_pack_floats(d) if isinstance(model, EigenFunctions) else 0
+        self.packed = torch.zeros(n_pack, device=device, dtype=torch.float32) if n_pack > 0 else None
+        self.repack()
+
+    def repack(self):
+        """Rebuild the fragment copy from theta (needed after the parameters were written from outside)."""
+        if self.packed is not None:
+            _hip.check(_hip.lib().cvf_ef_pack(self.desc, _hip.ptr(self.theta), _hip.ptr(self.packed), _hip.stream()),
+                       "cvf_ef_pack")
 
 
 class _FusedOptimizer:
@@ -112,15 +122,20 @@ class _FusedOptimizer:
     def zero_grad(self, set_to_none=True):
         pass  # the backward kernels overwrite the whole flat gradient
 
-    def step(self):
+    def step(self, advance=True):
+        """``advance=False`` when the gradient kernel of this step has already advanced the step counter
+        (the fused training loops); the public ``loss -> backward() -> optimizer.step()`` path advances here."""
         f, lib = self.flat, _hip.lib()
         lr = float(self.param_groups[0]["lr"])
+        if advance:
+            self.step_count += 1
         if self.name == "adam":
             _hip.check(lib.cvf_adam_step(_hip.ptr(f.theta), _hip.ptr(f.grad), _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq),
                                          f.n, lr, self.betas[0], self.betas[1], self.eps, _hip.ptr(self.step_count),
-                                         _hip.stream()), "cvf_adam_step")
+                                         f.desc, _hip.ptr(f.packed), _hip.stream()), "cvf_adam_step")
         else:
-            _hip.check(lib.cvf_sgd_step(_hip.ptr(f.theta), _hip.ptr(f.grad), f.n, lr, _hip.stream()), "cvf_sgd_step")
+            _hip.check(lib.cvf_sgd_step(_hip.ptr(f.theta), _hip.ptr(f.grad), f.n, lr, f.desc, _hip.ptr(f.packed),
+                                        _hip.stream()), "cvf_sgd_step")
 
 
 class TrainingTask(ABC):
@@ -150,6 +165,21 @@ class TrainingTask(ABC):
         if self.verbose:
             print('\n[Info] Log directory: {}\n'.format(self.model_path), flush=True)
         self.writer = _SummaryWriter(self.model_path) if _SummaryWriter is not None else _ScalarLog(self.model_path)
+
+    # -- every kernel launch goes through here; bench.py sets ``_events`` to time launches with HIP events
+    _events = None
+
+    def _call(self, name, fn, *args):
+        ev = self._events
+        if ev is not None:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn(*args)
+            b.record()
+            ev.setdefault(name, []).append((a, b))
+        else:
+            rc = fn(*args)
+        _hip.check(rc, name)
 
     # -- description of r(x) for the kernels
     def _pp_desc(self, n_coord):
@@ -236,7 +266,8 @@ class _EFWorkspace:
         self.stats = torch.empty(lib.cvf_ef_nstats(k, lag), **f64)
         self.loss_vec = torch.empty(3 + 2 * k, **f64)
         self.coef = torch.empty(4 * k + k * k, **f64)
-        self.slab = torch.empty(lib.cvf_ef_backward_slab_floats(mlp_desc, Tt), **f32)
+        self.slab_rows = lib.cvf_ef_backward_slab_rows(Tt)
+        self.slab = torch.empty(self.slab_rows * n_params, **f32)
 
 
 class EigenFunctionTask(TrainingTask):
@@ -321,46 +352,44 @@ class EigenFunctionTask(TrainingTask):
 
     def _forward(self, X, w, X_lag=None, w_lag=None):
         """Everything up to the loss for one (local) batch; leaves loss_vec / coef on the device."""
-        lib, s = _hip.lib(), _hip.stream()
+        lib, s, P = _hip.lib(), _hip.stream(), _hip.ptr
         B = X.shape[0]
         ws = self._workspace(B)
         fl, k, d_r = self._flat, self.k, self._pp.d_r
         lag = self.lag_idx
-        _hip.check(lib.cvf_align_feature_fwd(self._pp, _hip.ptr(X), B, _hip.ptr(ws.feat), None, _hip.ptr(ws.aux), s),
-                   "cvf_align_feature_fwd")
+        self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X), B, P(ws.feat), None, P(ws.aux), s)
         if lag > 0:
             feat_lag = ws.feat[ws.T * d_r * _hip.TILE:]
-            _hip.check(lib.cvf_align_feature_fwd(self._pp, _hip.ptr(X_lag), B, _hip.ptr(feat_lag), None, None, s),
-                       "cvf_align_feature_fwd(lagged)")
-        _hip.check(lib.cvf_ef_mlp_fwd(fl.desc, _hip.ptr(fl.theta), _hip.ptr(ws.feat), ws.Tt, _hip.ptr(ws.y),
-                                      _hip.ptr(ws.g) if lag == 0 else None, s), "cvf_ef_mlp_fwd")
+            self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X_lag), B, P(feat_lag), None, None, s)
+        self._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(ws.y),
+                   P(ws.g) if lag == 0 else None, s)
         if lag == 0:
-            _hip.check(lib.cvf_metric_apply(self._pp, _hip.ptr(X), B, _hip.ptr(ws.aux), _hip.ptr(self._diag_coeff), k,
-                                            _hip.ptr(ws.g), _hip.ptr(ws.q), _hip.ptr(ws.e), s), "cvf_metric_apply")
-            _hip.check(lib.cvf_ef_stats(self._cfg, B, _hip.ptr(w), _hip.ptr(ws.y), _hip.ptr(ws.e), None, None,
-                                        _hip.ptr(ws.scratch), _hip.ptr(ws.stats), s), "cvf_ef_stats")
+            self._call("cvf_metric_apply", lib.cvf_metric_apply, self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), k,
+                       P(ws.g), P(ws.q), P(ws.e), s)
+            self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), P(ws.e), None, None, P(ws.scratch),
+                       P(ws.stats), s)
         else:
             y_lag = ws.y[ws.T * k * _hip.TILE:]
-            _hip.check(lib.cvf_ef_stats(self._cfg, B, _hip.ptr(w), _hip.ptr(ws.y), None, _hip.ptr(w_lag), _hip.ptr(y_lag),
-                                        _hip.ptr(ws.scratch), _hip.ptr(ws.stats), s), "cvf_ef_stats")
+            self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), None, P(w_lag), P(y_lag),
+                       P(ws.scratch), P(ws.stats), s)
         _dist.allreduce_sum_(ws.stats)                                                   # collective #1
-        _hip.check(lib.cvf_ef_loss(self._cfg, _hip.ptr(ws.stats), _hip.ptr(ws.loss_vec), _hip.ptr(ws.coef), s), "cvf_ef_loss")
+        self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_vec), P(ws.coef), s)
         return ws
 
-    def _backward(self, ws, w, w_lag=None):
-        lib, fl = _hip.lib(), self._flat
-        _hip.check(lib.cvf_ef_backward(self._cfg, fl.desc, _hip.ptr(fl.theta), ws.B, _hip.ptr(w), _hip.ptr(w_lag),
-                                       _hip.ptr(ws.feat), _hip.ptr(ws.y), _hip.ptr(ws.q) if self.lag_idx == 0 else None,
-                                       _hip.ptr(ws.coef), _hip.ptr(ws.slab), _hip.ptr(fl.grad), _hip.stream()),
-                   "cvf_ef_backward")
+    def _backward(self, ws, w, w_lag=None, advance=False):
+        lib, fl, P = _hip.lib(), self._flat, _hip.ptr
+        self._call("cvf_ef_backward", lib.cvf_ef_backward, self._cfg, fl.desc, P(fl.theta), P(fl.packed), ws.B, P(w), P(w_lag),
+                   P(ws.feat), P(ws.y), P(ws.q) if self.lag_idx == 0 else None, P(ws.coef), P(ws.slab), _hip.stream())
+        self._call("cvf_slab_reduce", lib.cvf_slab_reduce, P(ws.slab), ws.slab_rows, fl.n, P(fl.grad),
+                   P(self.optimizer.step_count) if advance else None, _hip.stream())
         _dist.allreduce_sum_(fl.grad)                                                    # collective #2
 
     def train_step(self, X, w, X_lag=None, w_lag=None):
         """One optimisation step on device tensors; returns the device vector
         ``[loss, npl, pen, eig_1..k, cvec_1..k]`` (fp64) without synchronising the host."""
         ws = self._forward(X, w, X_lag, w_lag)
-        self._backward(ws, w, w_lag)
-        self.optimizer.step()
+        self._backward(ws, w, w_lag, advance=True)
+        self.optimizer.step(advance=False)
         return ws.loss_vec
 
     def _dev(self, t, dtype=torch.float32):
@@ -371,6 +400,7 @@ class EigenFunctionTask(TrainingTask):
         gradient of ``loss`` is obtained with :meth:`backward` (there is no autograd graph)."""
         X, weight = self._dev(X), self._dev(weight)
         X_lagged, weight_lagged = self._dev(X_lagged), self._dev(weight_lagged)
+        self._flat.repack()  # the caller may have modified the parameters through the nn.Module
         ws = self._forward(X, weight, X_lagged, weight_lagged)
         self._last = (ws, weight, weight_lagged)
         v = ws.loss_vec.cpu()
@@ -392,6 +422,7 @@ class EigenFunctionTask(TrainingTask):
     def train(self):
         """core.py:459-566 with the trajectory resident in HBM and one host copy of the losses per epoch."""
         k, lag = self.k, self.lag_idx
+        self._flat.repack()
         ll = self._traj.shape[0] - lag
         _split(ll, self.test_ratio)                                  # core.py:465 (drawn, discarded)
         idx_train, idx_test = _split(ll, self.test_ratio)            # core.py:468
@@ -512,7 +543,7 @@ class AutoEncoderTask(TrainingTask):
     def reg_model(self):
         return None
 
-    def _step(self, feat, idx, w, with_grad, inv_wsum=None):
+    def _step(self, feat, idx, w, with_grad, inv_wsum=None, advance=False):
         """One fused kernel: forward, weighted MSE, parameter gradient.  ``inv_wsum`` = 1 / (global sum of the
         batch weights); it does not depend on the model, so ``train`` computes it once per (static) batch."""
         lib, fl = _hip.lib(), self._flat
@@ -526,7 +557,8 @@ class AutoEncoderTask(TrainingTask):
             inv_wsum = 1.0 / float(wsum)
         _hip.check(lib.cvf_ae_step(fl.desc, _hip.ptr(fl.theta), _hip.ptr(feat), _hip.ptr(idx), B, _hip.ptr(w),
                                    inv_wsum, _hip.ptr(sc), _hip.ptr(self._out2),
-                                   _hip.ptr(fl.grad) if with_grad else None, _hip.stream()), "cvf_ae_step")
+                                   _hip.ptr(fl.grad) if with_grad else None,
+                                   _hip.ptr(self.optimizer.step_count) if advance else None, _hip.stream()), "cvf_ae_step")
         out = self._out2.clone()
         _dist.allreduce_sum_(out)
         if with_grad:
@@ -592,8 +624,8 @@ class AutoEncoderTask(TrainingTask):
         for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
             self.model.train()
             for it, (a, b) in enumerate(tr_batches):
-                log_tr[it] = self._step(self._feature_traj, itr[a:b], wtr[a:b], True, iw_tr[it])
-                self.optimizer.step()
+                log_tr[it] = self._step(self._feature_traj, itr[a:b], wtr[a:b], True, iw_tr[it], advance=True)
+                self.optimizer.step(advance=False)
             self.model.eval()
             for it, (a, b) in enumerate(te_batches):
                 log_te[it] = self._step(self._feature_traj, ite[a:b], wte[a:b], False, iw_te[it])

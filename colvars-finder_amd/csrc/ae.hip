@@ -188,8 +188,9 @@ __global__ __launch_bounds__(64) void ae_step_kernel(cvf_mlp_desc mlp, const flo
 }
 
 __global__ void ae_reduce_kernel(const float* __restrict__ slab, const double* __restrict__ partial, int nblocks, int Pn,
-                                 float* __restrict__ grad, double* __restrict__ out2) {
+                                 float* __restrict__ grad, double* __restrict__ out2, int32_t* __restrict__ step) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (grad && step && p == 0) *step += 1;  // one gradient per optimiser step
   if (grad && p < Pn) {
     float acc = 0.0f;
     for (int g = 0; g < nblocks; ++g) acc += slab[(int64_t)g * Pn + p];
@@ -239,7 +240,7 @@ extern "C" int64_t cvf_ae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B) {
 
 extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
                            int64_t B, const float* w, double inv_wsum, float* scratch, double* out2, float* grad,
-                           void* stream) {
+                           int32_t* step_count, void* stream) {
   CVF_REQUIRE(mlp && theta && feat_rows && w && scratch && out2 && B > 0, "cvf_ae_step: bad argument");
   CVF_REQUIRE(mlp->n_nets == 1 && mlp->n_layers >= 1 && mlp->n_layers <= CVF_MAX_LAYERS, "cvf_ae_step: one chain expected");
   CVF_REQUIRE(mlp->dims[0] == mlp->dims[mlp->n_layers], "cvf_ae_step: output width %d != input width %d",
@@ -258,7 +259,7 @@ extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const fl
   int rc = cvf_check_launch("ae_step_kernel");
   if (rc) return rc;
   const int Pn = mlp->n_params;
-  hipLaunchKernelGGL(ae_reduce_kernel, dim3((Pn + 255) / 256), dim3(256), 0, s, slab, partial, G, Pn, grad, out2);
+  hipLaunchKernelGGL(ae_reduce_kernel, dim3((Pn + 255) / 256), dim3(256), 0, s, slab, partial, G, Pn, grad, out2, step_count);
   return cvf_check_launch("ae_reduce_kernel");
 }
 

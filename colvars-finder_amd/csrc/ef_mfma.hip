@@ -1,0 +1,762 @@
+// K4a / K4b on the matrix cores: the k eigenfunction nets (colvarsfinder.nn.EigenFunctions,
+// nn.py:242-293; shape d0 -> H -> .. -> H -> 1, NH hidden layers, tanh) for one 64-frame tile.
+//
+// Every product of the nets is a small dense contraction [H x K] x [K x frames]; it runs on
+// v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: bitwise an fmaf chain, so the 1e-5 parity
+// bar holds) with the WEIGHTS as the A operand - fetched once per wave into VGPR fragments and
+// reused over the wave's 64 frames - and the activations as the B operand.
+//
+// Register layout ("acc layout") of a hidden vector X of width H over FT sub-tiles of 16 frames:
+//   f32x4 X[RT][FT];  X[rt][ft][r] (lane: col = lane&15, q = lane>>4) = feature 4*g + q of frame
+//   16*ft + col, with g = 4*rt + r the "k-group".  This is exactly the C/D layout of the MFMA
+//   when row rho = 4*qq + rr of row-tile rt is assigned feature 4*(4*rt + rr) + qq, and it makes
+//   register r of row-tile rt directly the B operand of k-step g = 4*rt + r of the next layer
+//   (k-slot q <-> feature 4*g + q): activations never leave registers between layers, and the
+//   K dimension of an H = 20 layer costs 5 k-steps, not 8.
+//
+// The weight gradients  W_l += sum_frames zbar_l (x) [h_{l-1}; 1] + d_l (x) [tdot_{l-1}; 0]  have
+// K = frames: their operands are transposed through wave-private LDS images [feature][frame]
+// (66-dword pitch, conflict-free) and accumulated across the block's tiles in an LDS image of the
+// net's parameters; each block writes one slab row, rows are summed in fixed order by cvf_slab_reduce.
+#include "cvf_common.hpp"
+#include "cvf_pack.hpp"
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kPitch = 66;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int H>
+struct Hid {
+  static constexpr int NG = (H + 3) / 4;   // k-groups of 4 features
+  static constexpr int RT = (NG + 3) / 4;  // 16-row tiles
+};
+
+template <int H, int FT>
+struct Vec {
+  f32x4 v[Hid<H>::RT][FT];
+};
+
+// X <- bias (hidden order)
+template <int H, int FT>
+__device__ __forceinline__ void init_bias(Vec<H, FT>& X, const float* __restrict__ b, int q) {
+#pragma unroll
+  for (int rt = 0; rt < Hid<H>::RT; ++rt) {
+    f32x4 bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = hid_feature(rt, r, q);
+      bv[r] = (b != nullptr && f < H) ? b[f] : 0.0f;
+    }
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) X.v[rt][ft] = bv;
+  }
+}
+
+// FT consecutive floats (the lane's frames 4*col + ft0 .. + FT-1 of one feature row)
+template <int FT>
+__device__ __forceinline__ void load_frames(const float* __restrict__ p, float (&b)[FT]) {
+  if constexpr (FT == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+  } else if constexpr (FT == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    b[0] = v.x; b[1] = v.y;
+  } else {
+    b[0] = p[0];
+  }
+}
+template <int FT>
+__device__ __forceinline__ void store_frames(float* __restrict__ p, const float (&b)[FT]) {
+  if constexpr (FT == 4) *reinterpret_cast<float4*>(p) = make_float4(b[0], b[1], b[2], b[3]);
+  else if constexpr (FT == 2) *reinterpret_cast<float2*>(p) = make_float2(b[0], b[1]);
+  else p[0] = b[0];
+}
+
+// first layer: X += W0 [H x D] * in.  `in_lane` = tiled global array (rows = features, 64 frames per row)
+// + the lane's frame offset 4*col + ft0; pk0 = packed fragments F0 of this net
+template <int H, int FT>
+__device__ __forceinline__ void layer0_apply(Vec<H, FT>& X, const float* __restrict__ pk0, int D,
+                                             const float* __restrict__ in_lane, int lane) {
+  constexpr int RT = Hid<H>::RT;
+  const int q = lane >> 4;
+  const int S = (D + 3) >> 2;
+#pragma unroll 4
+  for (int s = 0; s < S; ++s) {
+    const int kf = 4 * s + q;
+    float a[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = pk0[(s * RT + rt) * 64 + lane];
+    float b[FT];
+    load_frames<FT>(in_lane + (int64_t)(kf < D ? kf : 0) * CVF_TILE, b);  // rows past D meet zero weights
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) X.v[rt][ft] = mfma4(a[rt], b[ft], X.v[rt][ft]);
+  }
+}
+
+// hidden -> hidden: Y += op(W) [H x H] * X ; pk = packed fragments (Fh_l for W, Th_l for W^T)
+template <int H, int FT>
+__device__ __forceinline__ void hidden_apply(Vec<H, FT>& Y, const float* __restrict__ pk, const Vec<H, FT>& X, int lane) {
+  constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG;
+  float a[NG][RT];
+#pragma unroll
+  for (int s = 0; s < NG; ++s)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[s][rt] = pk[(s * RT + rt) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < NG; ++s)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) Y.v[rt][ft] = mfma4(a[s][rt], X.v[s >> 2][ft][s & 3], Y.v[rt][ft]);
+}
+
+template <int H, int FT>
+__device__ __forceinline__ void tanh_inplace(Vec<H, FT>& X) {
+#pragma unroll
+  for (int rt = 0; rt < Hid<H>::RT; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * rt + r < Hid<H>::NG) X.v[rt][ft][r] = cvf_tanh(X.v[rt][ft][r]);  // padding groups stay 0
+}
+
+// per-lane copy of a length-H vector in hidden order: c[rt][r] = v[hid_feature(rt,r,q)]
+template <int H>
+__device__ __forceinline__ void load_hid_const(const float* __restrict__ v, int q, float (&c)[Hid<H>::RT][4]) {
+#pragma unroll
+  for (int rt = 0; rt < Hid<H>::RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = hid_feature(rt, r, q);
+      c[rt][r] = f < H ? v[f] : 0.0f;
+    }
+}
+
+// forward chain of one net: h[l] = tanh(W_l h_{l-1} + b_l)
+template <int H, int NH, int FT>
+__device__ __forceinline__ void chain_forward(const cvf_mlp_desc& mlp, const float* __restrict__ theta,
+                                              const float* __restrict__ pk, const PackLayout& L, int net,
+                                              const float* __restrict__ in_lane, int lane, Vec<H, FT> (&h)[NH]) {
+  const int q = lane >> 4;
+  init_bias<H, FT>(h[0], theta + mlp.b_off[net][0], q);
+  layer0_apply<H, FT>(h[0], pk + L.f0(), mlp.dims[0], in_lane, lane);
+  tanh_inplace<H, FT>(h[0]);
+#pragma unroll
+  for (int l = 1; l < NH; ++l) {
+    init_bias<H, FT>(h[l], theta + mlp.b_off[net][l], q);
+    hidden_apply<H, FT>(h[l], pk + L.fh(l), h[l - 1], lane);
+    tanh_inplace<H, FT>(h[l]);
+  }
+}
+
+// sum over the 4 lane groups q (same col): after this every lane holds the full sum
+__device__ __forceinline__ float sum_over_q(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4a: y and g = dy/dfeat for one (sub-tile group, net)
+// ------------------------------------------------------------------------------------------------
+template <int H, int NH, int FT>
+__global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
+                                                          const float* __restrict__ packed,
+                                                          const float* __restrict__ feat, float* __restrict__ y_tiled,
+                                                          float* __restrict__ g_tiled) {
+  constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG;
+  constexpr int SUB = 4 / FT;  // blocks per 64-frame tile
+  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
+  const int64_t tile = blockIdx.x / SUB;
+  const int ft0 = (blockIdx.x % SUB) * FT;
+  const int net = blockIdx.y;
+  const int k = mlp.n_nets, D = mlp.dims[0];
+  const PackLayout L = pack_layout(H, NH, D);
+  const float* pk = packed + (int64_t)net * L.per_net;
+  const int fo = 4 * col + ft0;  // this lane's frames are fo .. fo+FT-1 of the tile
+  const float* in_lane = feat + tile * (int64_t)D * CVF_TILE + fo;
+
+  Vec<H, FT> h[NH];
+  chain_forward<H, NH, FT>(mlp, theta, pk, L, net, in_lane, lane, h);
+
+  float wl[RT][4];
+  load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
+  const float bL = theta[mlp.b_off[net][NH]];
+  {
+    float yv[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      float part = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(wl[rt][r], h[NH - 1].v[rt][ft][r], part);
+      yv[ft] = sum_over_q(part) + bL;
+    }
+    if (q == 0) store_frames<FT>(y_tiled + (tile * k + net) * CVF_TILE + fo, yv);
+  }
+  if (g_tiled == nullptr) return;
+
+  // d_{NH-1} = W_L .* (1 - h^2);  d_{l-1} = (W_l^T d_l) .* (1 - h_{l-1}^2)
+  Vec<H, FT> d;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = h[NH - 1].v[rt][ft][r];
+        d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
+      }
+#pragma unroll
+  for (int l = NH - 1; l >= 1; --l) {
+    Vec<H, FT> e;
+    init_bias<H, FT>(e, nullptr, q);
+    hidden_apply<H, FT>(e, pk + L.th(l), d, lane);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float hv = h[l - 1].v[rt][ft][r];
+          d.v[rt][ft][r] = e.v[rt][ft][r] * (1.0f - hv * hv);
+        }
+  }
+  // g = W0^T d_0 : rows = input features in natural order, K = H
+  const float* pT0 = pk + L.t0();
+  float* gout = g_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + fo;
+  const int CT = (D + 15) >> 4;
+  for (int rt = 0; rt < CT; ++rt) {
+    f32x4 acc[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) acc[ft] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < NG; ++s) {
+      const float a = pT0[(rt * NG + s) * 64 + lane];
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) acc[ft] = mfma4(a, d.v[s >> 2][ft][s & 3], acc[ft]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * rt + 4 * q + r;
+      if (i < D) {
+        float gv[FT];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) gv[ft] = acc[ft][r];
+        store_frames<FT>(gout + (int64_t)i * CVF_TILE, gv);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4b
+// ------------------------------------------------------------------------------------------------
+struct EfBwdArgs {
+  int k;
+  int lag_idx;
+  int64_t B;
+  int64_t T;
+  int64_t n_tiles;
+};
+
+template <int RT, int CT>
+__device__ __forceinline__ void mfma_outer(const float* __restrict__ A, const float* __restrict__ Bm, int lane,
+                                           f32x4 (&acc)[RT][CT]) {
+  const int row = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+  for (int s = 0; s < 16; ++s) {
+    float a[RT], b[CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = A[(16 * rt + row) * kPitch + 4 * s + kq];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) b[ct] = Bm[(16 * ct + row) * kPitch + 4 * s + kq];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = mfma4(a[rt], b[ct], acc[rt][ct]);
+  }
+}
+
+// write a hidden vector (acc layout) as a [feature][frame] LDS image, optionally scaled per frame;
+// the lane's 4 frames 4*col..4*col+3 are contiguous: two 8-byte stores per feature
+template <int H, bool SCALE>
+__device__ __forceinline__ void store_image(float* S, const Vec<H, 4>& X, const float (&sc)[4], int lane) {
+  const int col = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int rt = 0; rt < Hid<H>::RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = hid_feature(rt, r, q);
+      if (4 * rt + r < Hid<H>::NG && f < H) {
+        float2* dst = reinterpret_cast<float2*>(S + f * kPitch + 4 * col);
+        if (SCALE) {
+          dst[0] = make_float2(sc[0] * X.v[rt][0][r], sc[1] * X.v[rt][1][r]);
+          dst[1] = make_float2(sc[2] * X.v[rt][2][r], sc[3] * X.v[rt][3][r]);
+        } else {
+          dst[0] = make_float2(X.v[rt][0][r], X.v[rt][1][r]);
+          dst[1] = make_float2(X.v[rt][2][r], X.v[rt][3][r]);
+        }
+      }
+    }
+}
+
+template <int H, int NH>
+__global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp_desc mlp, const float* __restrict__ theta,
+                                                          const float* __restrict__ packed,
+                                                          const float* __restrict__ w, const float* __restrict__ w_lag,
+                                                          const float* __restrict__ feat, const float* __restrict__ y_tiled,
+                                                          const float* __restrict__ q_tiled, const double* __restrict__ coef,
+                                                          float* __restrict__ slab) {
+  constexpr int FT = 4;
+  constexpr int RT = Hid<H>::RT;
+  constexpr int RTO = (H + 15) / 16;      // row tiles of an H-row image (natural order)
+  constexpr int CTH = (H + 1 + 15) / 16;  // column tiles of [h ; 1]
+  constexpr int RA = RTO * 16, RB = CTH * 16;
+  // Operand images, packed: an image owns H (A side) or H+1 (B side) rows; the MFMA reads up to the next
+  // multiple of 16 rows, i.e. into the following image - finite values that only reach output rows/columns
+  // which are discarded.  Keeps the block under 40 KiB of LDS (4 blocks per CU).
+  constexpr int kRows = 2 * H + 2 * (H + 1) + 16;
+  __shared__ float IMG[kRows * kPitch];
+  float* SA1 = IMG;
+  float* SA2 = SA1 + H * kPitch;
+  float* SB1 = SA2 + H * kPitch;
+  float* SB2 = SB1 + (H + 1) * kPitch;
+  static_assert(RA <= H + 16 && RB <= H + 1 + 16, "image padding");
+  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
+  const int net = blockIdx.y;
+  const int k = args.k;
+  const int D = mlp.dims[0];
+  const int CT1 = (D + 1 + 15) / 16;
+  const bool tangent = args.lag_idx == 0;
+
+  for (int i = lane; i < kRows * kPitch; i += 64) IMG[i] = 0.0f;
+  __syncthreads();
+  SB1[H * kPitch + lane] = 1.0f;  // bias column of [h ; 1]  (row H of SB2 stays 0)
+
+  // this block's partial gradient of `net`, in the flat parameter order (the parameters of one net are
+  // contiguous), accumulated across the block's tiles in LDS: keeps ~100 accumulator registers free
+  extern __shared__ float GI[];
+  const int gbase = mlp.w_off[net][0];
+  const int gspan = mlp.b_off[net][NH] + 1 - gbase;
+  for (int i = lane; i < gspan; i += 64) GI[i] = 0.0f;
+  __syncthreads();
+  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int row16 = lane & 15, r0 = 4 * (lane >> 4);
+
+  const double* gS1 = coef;
+  const double* gS2 = coef + k;
+  const double* gEt = coef + k + k * k;
+  const double* gS1l = coef + 2 * k + k * k;
+  const double* gS2l = coef + 3 * k + k * k;
+
+  float wl[RT][4];
+  load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
+  const PackLayout L = pack_layout(H, NH, D);
+  const float* pk = packed + (int64_t)net * L.per_net;
+
+  for (int64_t tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x) {
+    const int pass = tile >= args.T ? 1 : 0;
+    const int64_t t0 = pass ? tile - args.T : tile;
+    // ---- per-frame coefficients for the 4 frames this lane sees (col + 16 ft)
+    float alpha[4], gamma[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const int64_t frame = t0 * CVF_TILE + 4 * col + ft;
+      const bool valid = frame < args.B;
+      const float wb = valid ? w[frame] : 0.0f;
+      const float* yb = y_tiled + t0 * k * CVF_TILE + 4 * col + ft;
+      gamma[ft] = 0.0f;
+      if (args.lag_idx == 0) {
+        double a = gS1[net];
+        for (int j = 0; j < k; ++j) a += (j == net ? 2.0 : 1.0) * gS2[net * k + j] * (double)yb[j * CVF_TILE];
+        alpha[ft] = (float)((double)wb * a);
+        gamma[ft] = (float)(2.0 * (double)wb * gEt[net]);
+      } else {
+        const float* yl = y_tiled + (args.T + t0) * k * CVF_TILE + 4 * col + ft;
+        const double diff = (double)yl[net * CVF_TILE] - (double)yb[net * CVF_TILE];
+        const double tterm = 2.0 * (double)wb * gEt[net] * diff;
+        if (pass == 0) {
+          double a = gS1[net];
+          for (int j = 0; j < k; ++j) a += (j == net ? 2.0 : 1.0) * gS2[net * k + j] * (double)yb[j * CVF_TILE];
+          alpha[ft] = (float)((double)wb * a - tterm);
+        } else {
+          const float wlg = valid ? w_lag[frame] : 0.0f;
+          alpha[ft] = (float)((double)wlg * (gS1l[net] + 2.0 * gS2l[net] * (double)yl[net * CVF_TILE]) + tterm);
+        }
+      }
+    }
+    const float* f_tile = feat + tile * (int64_t)D * CVF_TILE;
+    const float* q_tile = tangent ? q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE : nullptr;
+
+    // ---- chains (all in registers, MFMA)
+    Vec<H, FT> h[NH];
+    chain_forward<H, NH, FT>(mlp, theta, pk, L, net, f_tile + 4 * col, lane, h);
+    Vec<H, FT> e[NH > 1 ? NH - 1 : 1];  // e[l] = W_{l+1}^T d_{l+1}, l = 0..NH-2  (e_{NH-1} = W_L is the constant wl)
+    Vec<H, FT> t[NH];                   // t[l] = W_l tdot_{l-1}
+    if (tangent) {
+      // d-chain, keeping e_l
+      Vec<H, FT> d;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float hv = h[NH - 1].v[rt][ft][r];
+            d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
+          }
+#pragma unroll
+      for (int l = NH - 1; l >= 1; --l) {
+        init_bias<H, FT>(e[l - 1], nullptr, q);
+        hidden_apply<H, FT>(e[l - 1], pk + L.th(l), d, lane);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float hv = h[l - 1].v[rt][ft][r];
+              d.v[rt][ft][r] = e[l - 1].v[rt][ft][r] * (1.0f - hv * hv);
+            }
+      }
+      // tangent chain
+      init_bias<H, FT>(t[0], nullptr, q);
+      layer0_apply<H, FT>(t[0], pk + L.f0(), D, q_tile + 4 * col, lane);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[0].v[rt][ft][r] *= gamma[ft];
+#pragma unroll
+      for (int l = 1; l < NH; ++l) {
+        Vec<H, FT> td;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float hv = h[l - 1].v[rt][ft][r];
+              td.v[rt][ft][r] = (1.0f - hv * hv) * t[l - 1].v[rt][ft][r];
+            }
+        init_bias<H, FT>(t[l], nullptr, q);
+        hidden_apply<H, FT>(t[l], pk + L.fh(l), td, lane);
+      }
+    }
+
+    // ---- last layer (1 x H):  W_L += sum alpha h_{NH-1} + tdot_{NH-1} ; b_L += sum alpha
+    const float one4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    {
+      if (q == 0) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+          SA1[4 * col + ft] = alpha[ft];
+          if (tangent) SA2[4 * col + ft] = 1.0f;
+        }
+      }
+      store_image<H, false>(SB1, h[NH - 1], one4, lane);
+      if (tangent) {
+        Vec<H, FT> td;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float hv = h[NH - 1].v[rt][ft][r];
+              td.v[rt][ft][r] = (1.0f - hv * hv) * t[NH - 1].v[rt][ft][r];
+            }
+        store_image<H, false>(SB2, td, one4, lane);
+      }
+      __syncthreads();
+      f32x4 accL[1][CTH];
+#pragma unroll
+      for (int ct = 0; ct < CTH; ++ct) accL[0][ct] = zero4;
+      mfma_outer<1, CTH>(SA1, SB1, lane, accL);
+      if (tangent) mfma_outer<1, CTH>(SA2, SB2, lane, accL);
+      if (q == 0) {  // output row 0 lives in register 0 of lanes 0..15
+        const int wo = mlp.w_off[net][NH] - gbase, bo = mlp.b_off[net][NH] - gbase;
+#pragma unroll
+        for (int ct = 0; ct < CTH; ++ct) {
+          const int i = 16 * ct + row16;
+          if (i < H) GI[wo + i] += accL[0][ct][0];
+          else if (i == H) GI[bo] += accL[0][ct][0];
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- reverse sweep
+    Vec<H, FT> hbar;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hbar.v[rt][ft][r] = alpha[ft] * wl[rt][r];
+#pragma unroll
+    for (int l = NH - 1; l >= 0; --l) {
+      Vec<H, FT> zbar, dl;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float hv = h[l].v[rt][ft][r];
+            const float om = 1.0f - hv * hv;
+            float hb = hbar.v[rt][ft][r];
+            if (tangent) {
+              const float ev = (l == NH - 1) ? wl[rt][r] : e[l < NH - 1 ? l : 0].v[rt][ft][r];
+              hb = fmaf(-2.0f * hv * t[l].v[rt][ft][r], ev, hb);
+              dl.v[rt][ft][r] = ev * om;
+            }
+            zbar.v[rt][ft][r] = om * hb;
+          }
+      store_image<H, false>(SA1, zbar, one4, lane);
+      if (tangent) {
+        if (l == 0) store_image<H, true>(SA2, dl, gamma, lane);
+        else store_image<H, false>(SA2, dl, one4, lane);
+      }
+      if (l > 0) {
+        store_image<H, false>(SB1, h[l - 1], one4, lane);
+        if (tangent) {
+          Vec<H, FT> td;
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float hv = h[l - 1].v[rt][ft][r];
+                td.v[rt][ft][r] = (1.0f - hv * hv) * t[l - 1].v[rt][ft][r];
+              }
+          store_image<H, false>(SB2, td, one4, lane);
+        }
+        __syncthreads();
+        {
+          f32x4 accH[RTO][CTH];
+#pragma unroll
+          for (int rt = 0; rt < RTO; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CTH; ++ct) accH[rt][ct] = zero4;
+          mfma_outer<RTO, CTH>(SA1, SB1, lane, accH);
+          if (tangent) mfma_outer<RTO, CTH>(SA2, SB2, lane, accH);
+          const int wo = mlp.w_off[net][l] - gbase, bo = mlp.b_off[net][l] - gbase;
+#pragma unroll
+          for (int rt = 0; rt < RTO; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CTH; ++ct) {
+              const int i = 16 * ct + row16;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int o = 16 * rt + r0 + r;
+                if (o < H) {
+                  if (i < H) GI[wo + o * H + i] += accH[rt][ct][r];
+                  else if (i == H) GI[bo + o] += accH[rt][ct][r];
+                }
+              }
+            }
+        }
+        __syncthreads();
+        // hbar_{l-1} = W_l^T zbar_l
+        init_bias<H, FT>(hbar, nullptr, q);
+        hidden_apply<H, FT>(hbar, pk + L.th(l), zbar, lane);
+      } else {
+        __syncthreads();
+        const int wo = mlp.w_off[net][0] - gbase, bo = mlp.b_off[net][0] - gbase;
+        for (int ct = 0; ct < CT1; ++ct) {
+          const int i = 16 * ct + row16;
+          f32x4 acc[RTO];
+#pragma unroll
+          for (int rt = 0; rt < RTO; ++rt) acc[rt] = zero4;
+#pragma unroll 4
+          for (int s = 0; s < 16; ++s) {
+            const int fr = 4 * s + q;
+            const float b1 = i < D ? f_tile[(int64_t)i * CVF_TILE + fr] : (i == D ? 1.0f : 0.0f);
+#pragma unroll
+            for (int rt = 0; rt < RTO; ++rt) acc[rt] = mfma4(SA1[(16 * rt + row16) * kPitch + fr], b1, acc[rt]);
+            if (tangent) {
+              const float b2 = i < D ? q_tile[(int64_t)i * CVF_TILE + fr] : 0.0f;
+#pragma unroll
+              for (int rt = 0; rt < RTO; ++rt) acc[rt] = mfma4(SA2[(16 * rt + row16) * kPitch + fr], b2, acc[rt]);
+            }
+          }
+#pragma unroll
+          for (int rt = 0; rt < RTO; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int o = 16 * rt + r0 + r;
+              if (o < H) {
+                if (i < D) GI[wo + o * D + i] += acc[rt][r];
+                else if (i == D) GI[bo + o] += acc[rt][r];
+              }
+            }
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- flush this block's partial gradient of `net` into its slab row
+  __syncthreads();
+  float* out = slab + (int64_t)blockIdx.x * mlp.n_params + gbase;
+  for (int i = lane; i < gspan; i += 64) out[i] = GI[i];
+}
+
+// grad[p] = sum over slab rows, fixed order: 16 row groups (strided) per parameter, then the 16
+// sub-sums in sequence -> bitwise reproducible without atomics.  Also advances the optimiser's
+// step counter (one reduce per train step) so that Adam needs no extra launch for it.
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nrows, int P,
+                                                            float* __restrict__ grad, int32_t* __restrict__ step) {
+  __shared__ float sub[16][64];
+  const int px = threadIdx.x, gy = threadIdx.y;
+  const int p = blockIdx.x * 64 + px;
+  float acc = 0.0f;
+  if (p < P)
+    for (int64_t g = gy; g < nrows; g += 16) acc += slab[g * P + p];
+  sub[gy][px] = acc;
+  __syncthreads();
+  if (gy == 0 && p < P) {
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += sub[t][px];
+    grad[p] = s;
+  }
+  if (step != nullptr && blockIdx.x == 0 && px == 0 && gy == 0) *step += 1;
+}
+
+bool ef_shape(const cvf_mlp_desc* m, int* H, int* NH) {
+  if (m->n_layers < 2 || m->n_layers > CVF_MAX_LAYERS || m->dims[m->n_layers] != 1) return false;
+  *H = m->dims[1];
+  *NH = m->n_layers - 1;
+  for (int l = 1; l < m->n_layers; ++l)
+    if (m->dims[l] != *H) return false;
+  for (int l = 0; l < m->n_layers; ++l)
+    if (m->act[l] != (l + 1 < m->n_layers ? 1 : 0)) return false;
+  return true;
+}
+
+int64_t bwd_grid(int64_t n_tiles) { return n_tiles < 1024 ? n_tiles : 1024; }
+
+template <class F>
+bool ef_dispatch(int H, int NH, F&& f) {
+#define EF_CASE(H_, NH_)                                                        \
+  if (H == H_ && NH == NH_) {                                                   \
+    f(std::integral_constant<int, H_>{}, std::integral_constant<int, NH_>{});   \
+    return true;                                                                \
+  }
+  EF_CASE(8, 1) EF_CASE(8, 2) EF_CASE(8, 3)
+  EF_CASE(12, 1) EF_CASE(12, 2) EF_CASE(12, 3)
+  EF_CASE(16, 1) EF_CASE(16, 2) EF_CASE(16, 3)
+  EF_CASE(20, 1) EF_CASE(20, 2) EF_CASE(20, 3)
+  EF_CASE(24, 2) EF_CASE(24, 3)
+  EF_CASE(32, 2) EF_CASE(32, 3)
+#undef EF_CASE
+  return false;
+}
+
+}  // namespace
+
+__global__ void ef_pack_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta, float* __restrict__ packed) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < mlp.n_params) pack_scatter(mlp, p, theta[p], packed);
+}
+
+extern "C" int64_t cvf_ef_pack_floats(const cvf_mlp_desc* mlp) {
+  int H, NH;
+  if (!mlp || !ef_shape(mlp, &H, &NH)) return 0;
+  return (int64_t)mlp->n_nets * pack_layout(H, NH, mlp->dims[0]).per_net;
+}
+
+extern "C" int cvf_ef_pack(const cvf_mlp_desc* mlp, const float* theta, float* packed, void* stream) {
+  CVF_REQUIRE(mlp && theta && packed, "cvf_ef_pack: bad argument");
+  int H, NH;
+  CVF_REQUIRE(ef_shape(mlp, &H, &NH), "cvf_ef_pack: unsupported net shape");
+  (void)hipMemsetAsync(packed, 0, sizeof(float) * cvf_ef_pack_floats(mlp), (hipStream_t)stream);
+  hipLaunchKernelGGL(ef_pack_kernel, dim3((mlp->n_params + 255) / 256), dim3(256), 0, (hipStream_t)stream, *mlp, theta, packed);
+  return cvf_check_launch("ef_pack_kernel");
+}
+
+extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* packed, const float* feat_tiled,
+                              int64_t n_tiles, float* y_tiled, float* g_tiled, void* stream) {
+  CVF_REQUIRE(mlp && theta && packed && feat_tiled && y_tiled && n_tiles > 0, "cvf_ef_mlp_fwd: bad argument");
+  int H, NH;
+  CVF_REQUIRE(ef_shape(mlp, &H, &NH),
+              "cvf_ef_mlp_fwd: nets must be d0->H->..->H->1 with tanh between layers (got %d layers)", mlp->n_layers);
+  CVF_REQUIRE(mlp->n_nets >= 1 && mlp->n_nets <= CVF_MAX_NETS, "cvf_ef_mlp_fwd: k=%d out of range", mlp->n_nets);
+  // few tiles: split each 64-frame tile over two waves so that the launch still fills the 1024 SIMDs
+  const bool split = n_tiles * mlp->n_nets < 2048;
+  const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
+    constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
+    if (split)
+      hipLaunchKernelGGL((ef_fwd_mfma_kernel<kH, kNH, 2>), dim3((unsigned)(2 * n_tiles), mlp->n_nets), dim3(64), 0,
+                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
+    else
+      hipLaunchKernelGGL((ef_fwd_mfma_kernel<kH, kNH, 4>), dim3((unsigned)n_tiles, mlp->n_nets), dim3(64), 0,
+                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
+  });
+  CVF_REQUIRE(launched, "cvf_ef_mlp_fwd: no kernel instance for hidden width %d x %d layers", H, NH);
+  return cvf_check_launch("ef_fwd_mfma_kernel");
+}
+
+extern "C" int64_t cvf_ef_backward_slab_rows(int64_t n_tiles) { return bwd_grid(n_tiles); }
+
+extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
+                               int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
+                               const float* y_tiled, const float* q_tiled, const double* coef, float* slab, void* stream) {
+  CVF_REQUIRE(cfg && mlp && theta && packed && w && feat_tiled && y_tiled && coef && slab && B > 0,
+              "cvf_ef_backward: bad argument");
+  CVF_REQUIRE(cfg->lag_idx > 0 || q_tiled, "cvf_ef_backward: generator mode needs q");
+  CVF_REQUIRE(cfg->lag_idx == 0 || w_lag, "cvf_ef_backward: transfer mode needs w_lag");
+  int H, NH;
+  CVF_REQUIRE(ef_shape(mlp, &H, &NH), "cvf_ef_backward: unsupported net shape");
+  EfBwdArgs a;
+  a.k = cfg->k;
+  a.lag_idx = cfg->lag_idx;
+  a.B = B;
+  a.T = cvf_ntiles(B);
+  a.n_tiles = cfg->lag_idx > 0 ? 2 * a.T : a.T;
+  const int64_t G = bwd_grid(a.n_tiles);
+  dim3 grid((unsigned)G, cfg->k);
+  // the LDS gradient image relies on each net's parameters being one contiguous run of the flat buffer
+  const int span = mlp->b_off[0][NH] + 1 - mlp->w_off[0][0];
+  int covered = 0;
+  for (int n = 0; n < mlp->n_nets; ++n) {
+    CVF_REQUIRE(mlp->b_off[n][NH] + 1 - mlp->w_off[n][0] == span, "cvf_ef_backward: nets are not laid out contiguously");
+    for (int l = 0; l <= NH; ++l)
+      CVF_REQUIRE(mlp->w_off[n][l] >= mlp->w_off[n][0] && mlp->b_off[n][l] < mlp->w_off[n][0] + span,
+                  "cvf_ef_backward: nets are not laid out contiguously");
+    covered += span;
+  }
+  CVF_REQUIRE(covered == mlp->n_params, "cvf_ef_backward: flat buffer holds parameters outside the nets");
+  const size_t lds_dyn = (size_t)span * sizeof(float);
+  const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
+    constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
+    hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH>), grid, dim3(64), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed, w,
+                       w_lag, feat_tiled, y_tiled, q_tiled, coef, slab);
+  });
+  CVF_REQUIRE(launched, "cvf_ef_backward: no kernel instance for hidden width %d x %d layers", H, NH);
+  return cvf_check_launch("ef_bwd_mfma_kernel");
+}
+
+extern "C" int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, int32_t* step_count,
+                               void* stream) {
+  CVF_REQUIRE(slab && grad && n_rows > 0 && n_params > 0, "cvf_slab_reduce: bad argument");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n_params + 63) / 64)), dim3(64, 16), 0, (hipStream_t)stream, slab,
+                     n_rows, (int)n_params, grad, step_count);
+  return cvf_check_launch("slab_reduce_kernel");
+}

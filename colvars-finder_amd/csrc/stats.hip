@@ -3,8 +3,10 @@
 // data-parallel job must derive the same ordering cvec from the reduced vector), the scalar
 // tail of the loss (core.py:426-457) with its partial derivatives, and K6: Adam.
 #include "cvf_common.hpp"
+#include "cvf_pack.hpp"
 #include <stdarg.h>
 #include <stdio.h>
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------
 // error plumbing shared by all translation units
@@ -34,85 +36,93 @@ extern "C" int cvf_ef_nstats(int k, int lag_idx) {
 
 namespace {
 
-constexpr int kStatBlocks = 256;
+constexpr int kStatBlocks = 512;
 constexpr int kMaxStats = 1 + CVF_MAX_NETS + CVF_NPAIR(CVF_MAX_NETS) + 1 + 3 * CVF_MAX_NETS;
 
-// one wave per block; block g handles tiles g, g+G, ...; lane = frame
-__global__ __launch_bounds__(64) void ef_stats_partial_kernel(int k, int lag_idx, int64_t B, const float* __restrict__ w,
+// one wave per block; block g handles tiles g, g+G, ...; lane = frame.  K is a template
+// parameter so that every accumulator lives in a register (no runtime-indexed arrays).
+template <int K, bool LAG>
+__global__ __launch_bounds__(64) void ef_stats_partial_kernel(int64_t B, const float* __restrict__ w,
                                                                const float* __restrict__ y, const float* __restrict__ e,
                                                                const float* __restrict__ w_lag,
                                                                const float* __restrict__ y_lag,
                                                                double* __restrict__ partial) {
+  constexpr int NP = K * (K + 1) / 2;
+  constexpr int NS = LAG ? 1 + K + NP + 1 + 3 * K : 1 + K + NP + K;
+  constexpr int O = 1 + K + NP;
   const int lane = threadIdx.x;
   const int64_t T = (B + CVF_TILE - 1) / CVF_TILE;
-  const int npair = CVF_NPAIR(k);
-  double acc[kMaxStats];
+  double acc[NS];
 #pragma unroll
-  for (int i = 0; i < kMaxStats; ++i) acc[i] = 0.0;
+  for (int i = 0; i < NS; ++i) acc[i] = 0.0;
   for (int64_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
     const int64_t frame = tile * CVF_TILE + lane;
     const bool valid = frame < B;
     const double wb = valid ? (double)w[frame] : 0.0;
-    double yv[CVF_MAX_NETS];
+    double yv[K];
 #pragma unroll
-    for (int i = 0; i < CVF_MAX_NETS; ++i) yv[i] = i < k ? (double)y[(tile * k + i) * CVF_TILE + lane] : 0.0;
+    for (int i = 0; i < K; ++i) yv[i] = (double)y[(tile * K + i) * CVF_TILE + lane];
     acc[0] += wb;
     int p = 0;
 #pragma unroll
-    for (int i = 0; i < CVF_MAX_NETS; ++i) {
-      if (i < k) {
-        acc[1 + i] += wb * yv[i];
+    for (int i = 0; i < K; ++i) {
+      acc[1 + i] += wb * yv[i];
 #pragma unroll
-        for (int j = i; j < CVF_MAX_NETS; ++j)
-          if (j < k) acc[1 + k + p++] += wb * yv[i] * yv[j];
-      }
+      for (int j = i; j < K; ++j) acc[1 + K + p++] += wb * yv[i] * yv[j];
     }
-    const int o = 1 + k + npair;
-    if (lag_idx == 0) {
+    if (!LAG) {
 #pragma unroll
-      for (int i = 0; i < CVF_MAX_NETS; ++i)
-        if (i < k) acc[o + i] += wb * (double)e[(tile * k + i) * CVF_TILE + lane];
+      for (int i = 0; i < K; ++i) acc[O + i] += wb * (double)e[(tile * K + i) * CVF_TILE + lane];
     } else {
       const double wl = valid ? (double)w_lag[frame] : 0.0;
-      acc[o] += wl;
+      acc[O] += wl;
 #pragma unroll
-      for (int i = 0; i < CVF_MAX_NETS; ++i)
-        if (i < k) {
-          const double yl = (double)y_lag[(tile * k + i) * CVF_TILE + lane];
-          acc[o + 1 + i] += wl * yl;
-          acc[o + 1 + k + i] += wl * yl * yl;
-          const double df = yl - yv[i];
-          acc[o + 1 + 2 * k + i] += wb * df * df;
-        }
+      for (int i = 0; i < K; ++i) {
+        const double yl = (double)y_lag[(tile * K + i) * CVF_TILE + lane];
+        acc[O + 1 + i] += wl * yl;
+        acc[O + 1 + K + i] += wl * yl * yl;
+        const double df = yl - yv[i];
+        acc[O + 1 + 2 * K + i] += wb * df * df;
+      }
     }
   }
-  const int ns = lag_idx == 0 ? 1 + k + npair + k : 1 + k + npair + 1 + 3 * k;
 #pragma unroll
-  for (int i = 0; i < kMaxStats; ++i)
-    if (i < ns) {
-      const double s = wave_sum(acc[i]);
-      if (lane == 0) partial[(int64_t)blockIdx.x * ns + i] = s;
-    }
+  for (int i = 0; i < NS; ++i) {
+    const double s = wave_sum(acc[i]);
+    if (lane == 0) partial[(int64_t)blockIdx.x * NS + i] = s;
+  }
 }
 
+// second stage: stat i is summed by 8 threads (strided over the partial rows), then the 8 sub-sums
+// are added in a fixed order -> bitwise reproducible
 __global__ void ef_stats_final_kernel(int ns, int nblocks, const double* __restrict__ partial, double* __restrict__ stats) {
-  const int i = threadIdx.x;
-  if (i >= ns) return;
-  double s = 0.0;
-  for (int g = 0; g < nblocks; ++g) s += partial[(int64_t)g * ns + i];
-  stats[i] = s;
+  __shared__ double sub[8 * kMaxStats];
+  const int j = threadIdx.x & 7, i = threadIdx.x >> 3;
+  if (i < ns) {
+    double s = 0.0;
+    for (int g = j; g < nblocks; g += 8) s += partial[(int64_t)g * ns + i];
+    sub[i * 8 + j] = s;
+  }
+  __syncthreads();
+  if (i < ns && j == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s += sub[i * 8 + t];
+    stats[i] = s;
+  }
 }
 
 // the scalar tail of loss_func, one thread, fp64
+template <int KT>
 __global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats, double* __restrict__ loss_vec,
                                double* __restrict__ coef) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int k = cfg.k;
+  constexpr int k = KT;
   const int npair = CVF_NPAIR(k);
   const double W = stats[0];
   const double* S1 = stats + 1;
   const double* S2 = stats + 1 + k;
-  double m[CVF_MAX_NETS], v[CVF_MAX_NETS], s2[CVF_MAX_NETS][CVF_MAX_NETS];
+  double m[KT], v[KT], s2[KT][KT];
   {
     int p = 0;
     for (int i = 0; i < k; ++i)
@@ -124,9 +134,9 @@ __global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats,
     m[i] = S1[i] / W;                       // core.py:409
     v[i] = s2[i][i] / W - m[i] * m[i];      // core.py:410
   }
-  double eig[CVF_MAX_NETS], num[CVF_MAX_NETS], den[CVF_MAX_NETS];
+  double eig[KT], num[KT], den[KT];
   double pref;
-  double vl[CVF_MAX_NETS], ml[CVF_MAX_NETS], Wl = 1.0;
+  double vl[KT], ml[KT], Wl = 1.0;
   const int o = 1 + k + npair;
   if (cfg.lag_idx == 0) {
     pref = 1.0 / (W * cfg.beta);            // core.py:426,438
@@ -147,7 +157,8 @@ __global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats,
     for (int i = 0; i < k; ++i) eig[i] = pref * num[i] / den[i];
   }
   // cvec = argsort(eig) (core.py:432), stable insertion sort
-  int cvec[CVF_MAX_NETS];
+  int cvec[KT];
+#pragma unroll
   for (int i = 0; i < k; ++i) cvec[i] = i;
   if (cfg.sort_eigvals) {
     for (int i = 1; i < k; ++i) {
@@ -163,7 +174,7 @@ __global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats,
   // variational objective; generator: numerator AND denominator at cvec[idx] (core.py:438);
   // transfer: numerator at idx, denominator at cvec[idx] (core.py:440, reproduced as is)
   double npl = 0.0;
-  double gnum[CVF_MAX_NETS], gden[CVF_MAX_NETS];
+  double gnum[KT], gden[KT];
   for (int i = 0; i < k; ++i) gnum[i] = gden[i] = 0.0;
   for (int idx = 0; idx < k; ++idx) {
     const int c = cvec[idx];
@@ -174,7 +185,7 @@ __global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats,
   }
   npl *= pref;
   double pen = 0.0;
-  double cov[CVF_MAX_NETS][CVF_MAX_NETS];
+  double cov[KT][KT];
   for (int i = 0; i < k; ++i) pen += (v[i] - 1.0) * (v[i] - 1.0);           // core.py:446
   for (int i = 0; i < k; ++i)
     for (int j = i + 1; j < k; ++j) {
@@ -216,10 +227,10 @@ __global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats,
 
 __global__ void adam_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                            const int32_t* __restrict__ step_in) {
+                            const int32_t* __restrict__ step_in, cvf_mlp_desc mlp, float* __restrict__ packed) {
   // torch.optim.Adam (single-tensor path): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
   // theta -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-  const int t = *step_in + 1;
+  const int t = *step_in;   // advanced by the gradient reduce kernel of this step (cvf_slab_reduce / cvf_ae_step)
   const double bc1 = 1.0 - pow((double)b1, (double)t);
   const double bc2 = 1.0 - pow((double)b2, (double)t);
   const float step_size = (float)((double)lr / bc1);
@@ -231,20 +242,33 @@ __global__ void adam_kernel(float* __restrict__ theta, const float* __restrict__
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    theta[i] -= step_size * (mi / denom);
+    const float th = theta[i] - step_size * (mi / denom);
+    theta[i] = th;
+    if (packed != nullptr) pack_scatter(mlp, (int)i, th, packed);  // keep the MFMA fragments in step
   }
 }
-__global__ void bump_step_kernel(int32_t* step) { *step += 1; }
 
-__global__ void sgd_kernel(float* __restrict__ theta, const float* __restrict__ grad, int64_t n, float lr) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    theta[i] -= lr * grad[i];
+__global__ void sgd_kernel(float* __restrict__ theta, const float* __restrict__ grad, int64_t n, float lr, cvf_mlp_desc mlp,
+                           float* __restrict__ packed) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float th = theta[i] - lr * grad[i];
+    theta[i] = th;
+    if (packed != nullptr) pack_scatter(mlp, (int)i, th, packed);
+  }
 }
 
 }  // namespace
 
 extern "C" int64_t cvf_ef_stats_scratch_doubles(int k, int lag_idx) {
   return (int64_t)kStatBlocks * cvf_ef_nstats(k, lag_idx);
+}
+
+template <class F>
+static bool k_dispatch(int k, F&& f) {
+#define K_CASE(K_) if (k == K_) { f(std::integral_constant<int, K_>{}); return true; }
+  K_CASE(1) K_CASE(2) K_CASE(3) K_CASE(4) K_CASE(5) K_CASE(6) K_CASE(7) K_CASE(8)
+#undef K_CASE
+  return false;
 }
 
 extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
@@ -257,36 +281,52 @@ extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, co
   const int64_t T = cvf_ntiles(B);
   const int G = (int)(T < kStatBlocks ? T : kStatBlocks);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(ef_stats_partial_kernel, dim3(G), dim3(64), 0, s, cfg->k, cfg->lag_idx, B, w, y_tiled, e_tiled,
-                     w_lag, y_lag_tiled, scratch);
+  const bool lag = cfg->lag_idx > 0;
+  k_dispatch(cfg->k, [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    if (lag)
+      hipLaunchKernelGGL((ef_stats_partial_kernel<K, true>), dim3(G), dim3(64), 0, s, B, w, y_tiled, e_tiled, w_lag,
+                         y_lag_tiled, scratch);
+    else
+      hipLaunchKernelGGL((ef_stats_partial_kernel<K, false>), dim3(G), dim3(64), 0, s, B, w, y_tiled, e_tiled, w_lag,
+                         y_lag_tiled, scratch);
+  });
   int rc = cvf_check_launch("ef_stats_partial_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(ef_stats_final_kernel, dim3(1), dim3(64), 0, s, ns, G, scratch, stats);
+  hipLaunchKernelGGL(ef_stats_final_kernel, dim3(1), dim3(8 * kMaxStats), 0, s, ns, G, scratch, stats);
   return cvf_check_launch("ef_stats_final_kernel");
 }
 
 extern "C" int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* loss_vec, double* coef, void* stream) {
   CVF_REQUIRE(cfg && stats && loss_vec && coef, "cvf_ef_loss: bad argument");
   CVF_REQUIRE(cfg->k >= 1 && cfg->k <= CVF_MAX_NETS, "cvf_ef_loss: k=%d out of range", cfg->k);
-  hipLaunchKernelGGL(ef_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *cfg, stats, loss_vec, coef);
+  k_dispatch(cfg->k, [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    hipLaunchKernelGGL((ef_loss_kernel<K>), dim3(1), dim3(64), 0, (hipStream_t)stream, *cfg, stats, loss_vec, coef);
+  });
   return cvf_check_launch("ef_loss_kernel");
 }
 
 extern "C" int cvf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
-                             double beta2, double eps, int32_t* step_count, void* stream) {
+                             double beta2, double eps, int32_t* step_count, const cvf_mlp_desc* mlp, float* packed,
+                             void* stream) {
   CVF_REQUIRE(theta && grad && m && v && step_count && n > 0, "cvf_adam_step: bad argument");
+  CVF_REQUIRE(packed == nullptr || (mlp != nullptr && mlp->n_params == n), "cvf_adam_step: packed buffer needs its mlp desc");
+  cvf_mlp_desc none = {};
+  const cvf_mlp_desc& md = packed ? *mlp : none;
   const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, grad, m, v, n, (float)lr,
-                     (float)beta1, (float)beta2, (float)eps, step_count);
-  int rc = cvf_check_launch("adam_kernel");
-  if (rc) return rc;
-  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_count);
-  return cvf_check_launch("bump_step_kernel");
+                     (float)beta1, (float)beta2, (float)eps, step_count, md, packed);
+  return cvf_check_launch("adam_kernel");
 }
 
-extern "C" int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, void* stream) {
+extern "C" int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, const cvf_mlp_desc* mlp, float* packed,
+                            void* stream) {
   CVF_REQUIRE(theta && grad && n > 0, "cvf_sgd_step: bad argument");
+  CVF_REQUIRE(packed == nullptr || (mlp != nullptr && mlp->n_params == n), "cvf_sgd_step: packed buffer needs its mlp desc");
+  cvf_mlp_desc none = {};
+  const cvf_mlp_desc& md = packed ? *mlp : none;
   const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-  hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, grad, n, (float)lr);
+  hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, grad, n, (float)lr, md, packed);
   return cvf_check_launch("sgd_kernel");
 }

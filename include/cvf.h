@@ -107,11 +107,17 @@ int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, floa
 int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled, const float* a,
                      int k, const float* g_tiled, float* q_tiled, float* e_tiled, void* stream);
 
+/* --- packed MFMA weight fragments of the nets (a second copy of the weights in the order the
+ * matrix-core kernels consume them; see csrc/cvf_pack.hpp).  cvf_ef_pack rebuilds it from theta;
+ * cvf_adam_step / cvf_sgd_step keep it in step when given the buffer. */
+int64_t cvf_ef_pack_floats(const cvf_mlp_desc* mlp);
+int cvf_ef_pack(const cvf_mlp_desc* mlp, const float* theta, float* packed, void* stream);
+
 /* --- K4a: k nets forward (+ gradient of each output w.r.t. the features).
  * Replaces self.model(...) at core.py:403,414 (nn.py:293).
  * y_tiled [T][k][64]; g_tiled [T][k][d0][64] or NULL. */
-int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* feat_tiled, int64_t n_tiles,
-                   float* y_tiled, float* g_tiled, void* stream);
+int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* packed, const float* feat_tiled,
+                   int64_t n_tiles, float* y_tiled, float* g_tiled, void* stream);
 
 /* --- K5: batch statistics (core.py:406-416,426,428,446-452), fp64, fixed-order two
  * stage reduction.  w [B]; y_tiled [T][k][64]; generator: e_tiled [T][k][64];
@@ -127,13 +133,16 @@ int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* loss_vec, do
 
 /* --- K4b: parameter gradient of the loss given the coefficients (what loss.backward()
  * does at core.py:517): reverse mode over the nets and, in generator mode, over their
- * directional derivative along q.  Partial sums per block go to `slab`
- * (cvf_ef_backward_slab_floats floats), then are summed in fixed order into grad [P].
- * transfer mode: feat/y hold 2T tiles (frames then their lagged partners). */
-int64_t cvf_ef_backward_slab_floats(const cvf_mlp_desc* mlp, int64_t n_tiles);
-int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, int64_t B, const float* w,
-                    const float* w_lag, const float* feat_tiled, const float* y_tiled, const float* q_tiled,
-                    const double* coef, float* slab, float* grad, void* stream);
+ * directional derivative along q.  Each block writes its partial sum to one row of
+ * `slab` [cvf_ef_backward_slab_rows(n_tiles)][n_params]; cvf_slab_reduce then sums the rows
+ * in fixed order into grad [n_params] (bitwise reproducible, no atomics).
+ * transfer mode: feat/y hold 2T tiles (frames then their lagged partners); n_tiles = 2T. */
+int64_t cvf_ef_backward_slab_rows(int64_t n_tiles);
+int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed, int64_t B,
+                    const float* w, const float* w_lag, const float* feat_tiled, const float* y_tiled,
+                    const float* q_tiled, const double* coef, float* slab, void* stream);
+int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, int32_t* step_count,
+                    void* stream); /* step_count (may be NULL): the optimiser's step counter, advanced by one */
 
 /* --- AutoEncoder: weighted reconstruction loss and its parameter gradient in one pass
  * (core.py:664-666,708).  feat_rows [n][d0] row-major (the precomputed feature
@@ -142,7 +151,8 @@ int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float*
  * grad may be NULL (test pass, core.py:725-735). */
 int64_t cvf_ae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B);
 int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx, int64_t B,
-                const float* w, double inv_wsum, float* scratch, double* out2, float* grad, void* stream);
+                const float* w, double inv_wsum, float* scratch, double* out2, float* grad, int32_t* step_count,
+                void* stream); /* step_count (may be NULL) is advanced by one when grad != NULL */
 
 /* --- nets forward on row-major features (inference: colvar_model(), core.py:372-382,
  * 640-647).  out [B][n_out] where n_out = n_nets * d_L; upto_layer < n_layers stops a
@@ -152,10 +162,13 @@ int cvf_mlp_eval_rows(const cvf_mlp_desc* mlp, const float* theta, const float* 
 
 /* --- K6: Adam (torch.optim.Adam defaults as constructed at core.py:164: betas
  * (0.9,0.999), eps 1e-8, no weight decay, no amsgrad), one launch over the flat buffer.
- * step_count is a device int32 incremented by the kernel (graph-replay safe). */
+ * step_count is a device int32 holding the number t of the CURRENT step (>= 1): it is advanced by the
+ * gradient-producing call of the step (cvf_slab_reduce / cvf_ae_step), so a captured step replays
+ * correctly without host involvement. */
 int cvf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
-                  double beta2, double eps, int32_t* step_count, void* stream);
-int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, void* stream);
+                  double beta2, double eps, int32_t* step_count, const cvf_mlp_desc* mlp, float* packed, void* stream);
+int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, const cvf_mlp_desc* mlp, float* packed,
+                 void* stream); /* mlp/packed: NULL, or the nets' desc + fragment buffer to refresh */
 
 #ifdef __cplusplus
 }

@@ -237,8 +237,10 @@ def test_fused_adam_matches_torch(dev):
         grad = torch.randn(n, generator=gen) * (10.0 ** (it % 5 - 3))
         ref.grad = grad.clone()
         opt.step()
-        gd = grad.to(dev)
+        gd = torch.empty(n, device=dev)
+        # the gradient reduce of a step also advances the step counter (one-row slab here)
+        _hip.check(lib.cvf_slab_reduce(_hip.ptr(grad.to(dev)), 1, n, _hip.ptr(gd), _hip.ptr(step), _hip.stream()), "reduce")
         _hip.check(lib.cvf_adam_step(_hip.ptr(theta), _hip.ptr(gd), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8,
-                                     _hip.ptr(step), _hip.stream()), "adam")
+                                     _hip.ptr(step), None, None, _hip.stream()), "adam")
     assert int(step.item()) == 25
     np.testing.assert_allclose(theta.cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-7)
