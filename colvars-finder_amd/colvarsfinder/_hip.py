@@ -17,6 +17,7 @@ AUX_ROWS = 18
 
 FEAT_ANGLE, FEAT_BOND, FEAT_DIHEDRAL, FEAT_POSITION = 0, 1, 2, 3
 PP_IDENTITY, PP_ALIGN = 0, 1
+PP_ALIGN_CONTIG, PP_PURE_POSITION = 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcvf_hip.so")
@@ -24,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libcvf_hip.so")
 
 class PPDesc(C.Structure):
     _fields_ = [("mode", C.c_int32), ("n_coord", C.c_int32), ("n_align", C.c_int32), ("n_rec", C.c_int32),
-                ("d_r", C.c_int32), ("use_angle_value", C.c_int32), ("has_position", C.c_int32), ("pad_", C.c_int32),
+                ("d_r", C.c_int32), ("use_angle_value", C.c_int32), ("has_position", C.c_int32), ("flags", C.c_int32),
                 ("align_idx", C.c_void_p), ("ref_c", C.c_void_p), ("rec", C.c_void_p)]
 
 
@@ -37,6 +38,12 @@ class MLPDesc(C.Structure):
 class EFCfg(C.Structure):
     _fields_ = [("k", C.c_int32), ("lag_idx", C.c_int32), ("sort_eigvals", C.c_int32), ("pad_", C.c_int32),
                 ("alpha", C.c_double), ("beta", C.c_double), ("dt", C.c_double), ("eig_w", C.c_double * MAX_NETS)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("theta", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("eps", C.c_double), ("step_count", C.c_void_p), ("mlp", C.POINTER(MLPDesc)),
+                ("packed", C.c_void_p)]
 
 
 _SIGNATURES = {
@@ -53,15 +60,16 @@ _SIGNATURES = {
                                  C.c_void_p]),
     "cvf_ef_stats_scratch_doubles": (C.c_int64, [C.c_int, C.c_int]),
     "cvf_ef_stats": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                               C.c_void_p, C.c_void_p, C.c_void_p]),
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_loss": (C.c_int, [C.POINTER(EFCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_backward_slab_rows": (C.c_int64, [C.c_int64]),
     "cvf_ef_backward": (C.c_int, [C.POINTER(EFCfg), C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "cvf_slab_reduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "cvf_slab_reduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p]),
     "cvf_ae_scratch_floats": (C.c_int64, [C.POINTER(MLPDesc), C.c_int64]),
     "cvf_ae_step": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double,
-                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p]),
     "cvf_mlp_eval_rows": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "cvf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_void_p, C.POINTER(MLPDesc), C.c_void_p, C.c_void_p]),

@@ -33,6 +33,8 @@ import numpy as np
 import pandas as pd
 import torch
 
+import ctypes
+
 from . import _dist, _hip
 from .nn import AutoEncoder, EigenFunctions, RegAutoEncoder, RegModel, mlp_layout  # noqa: F401
 from .pp import AlignFeatureLayer, identity_desc
@@ -47,6 +49,10 @@ try:
 except Exception:  # pragma: no cover
     def _tqdm(it, **_):
         return it
+
+
+def C_pointer(struct):
+    return ctypes.pointer(struct)
 
 
 class _ScalarLog:
@@ -121,6 +127,19 @@ class _FusedOptimizer:
 
     def zero_grad(self, set_to_none=True):
         pass  # the backward kernels overwrite the whole flat gradient
+
+    def fused_args(self):
+        """``cvf_adam_args`` for the kernels that reduce the gradient and apply Adam in one launch
+        (single-process runs only: with several ranks the gradient all-reduce sits in between)."""
+        if self.name != "adam":
+            return None
+        f, a = self.flat, _hip.AdamArgs()
+        a.theta, a.m, a.v = f.theta.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        a.lr, a.beta1, a.beta2, a.eps = float(self.param_groups[0]["lr"]), self.betas[0], self.betas[1], self.eps
+        a.step_count = self.step_count.data_ptr()
+        if f.packed is not None:
+            a.mlp, a.packed = C_pointer(f.desc), f.packed.data_ptr()
+        return a
 
     def step(self, advance=True):
         """``advance=False`` when the gradient kernel of this step has already advanced the step counter
@@ -326,6 +345,9 @@ class EigenFunctionTask(TrainingTask):
             cfg.eig_w[i] = float(eig_weights[i])
         self._cfg = cfg
         self._ws = {}
+        self._graphs = {}
+        # whole-step hipGraph replay (single process; CVF_GRAPH=0 turns it off)
+        self._use_graphs = _dist.world() == 1 and os.environ.get("CVF_GRAPH", "1") != "0"
 
     # ---------------------------------------------------------------- model views
     def get_reordered_eigenfunctions(self, model, cvec):
@@ -366,31 +388,61 @@ class EigenFunctionTask(TrainingTask):
         if lag == 0:
             self._call("cvf_metric_apply", lib.cvf_metric_apply, self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), k,
                        P(ws.g), P(ws.q), P(ws.e), s)
+        single = _dist.world() == 1   # no cross-rank reduction: the loss tail runs inside the stats launch
+        lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
+        if lag == 0:
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), P(ws.e), None, None, P(ws.scratch),
-                       P(ws.stats), s)
+                       P(ws.stats), lv, cf, s)
         else:
             y_lag = ws.y[ws.T * k * _hip.TILE:]
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), None, P(w_lag), P(y_lag),
-                       P(ws.scratch), P(ws.stats), s)
-        _dist.allreduce_sum_(ws.stats)                                                   # collective #1
-        self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_vec), P(ws.coef), s)
+                       P(ws.scratch), P(ws.stats), lv, cf, s)
+        if not single:
+            _dist.allreduce_sum_(ws.stats)                                               # collective #1
+            self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_vec), P(ws.coef), s)
         return ws
 
-    def _backward(self, ws, w, w_lag=None, advance=False):
+    def _backward(self, ws, w, w_lag=None, advance=False, fuse_adam=False):
+        """Parameter gradient into the flat buffer.  ``advance``: this gradient belongs to an optimiser step
+        (the kernel advances the device step counter).  ``fuse_adam``: single-process training - the kernel
+        that sums the per-block partial gradients applies the Adam update in the same launch."""
         lib, fl, P = _hip.lib(), self._flat, _hip.ptr
         self._call("cvf_ef_backward", lib.cvf_ef_backward, self._cfg, fl.desc, P(fl.theta), P(fl.packed), ws.B, P(w), P(w_lag),
-                   P(ws.feat), P(ws.y), P(ws.q) if self.lag_idx == 0 else None, P(ws.coef), P(ws.slab), _hip.stream())
-        self._call("cvf_slab_reduce", lib.cvf_slab_reduce, P(ws.slab), ws.slab_rows, fl.n, P(fl.grad),
+                   P(ws.feat), P(ws.y), P(ws.q) if self.lag_idx == 0 else None, P(ws.coef), P(ws.slab),
                    P(self.optimizer.step_count) if advance else None, _hip.stream())
-        _dist.allreduce_sum_(fl.grad)                                                    # collective #2
+        adam = self.optimizer.fused_args() if fuse_adam else None
+        self._call("cvf_slab_reduce", lib.cvf_slab_reduce, P(ws.slab), ws.slab_rows, fl.n, P(fl.grad), adam, _hip.stream())
+        if not fuse_adam:
+            _dist.allreduce_sum_(fl.grad)                                                # collective #2
+        return adam is not None
 
     def train_step(self, X, w, X_lag=None, w_lag=None):
         """One optimisation step on device tensors; returns the device vector
         ``[loss, npl, pen, eig_1..k, cvec_1..k]`` (fp64) without synchronising the host."""
         ws = self._forward(X, w, X_lag, w_lag)
-        self._backward(ws, w, w_lag, advance=True)
-        self.optimizer.step(advance=False)
+        fused = self._backward(ws, w, w_lag, advance=True, fuse_adam=(_dist.world() == 1))
+        if not fused:
+            self.optimizer.step(advance=False)
         return ws.loss_vec
+
+    # -- hipGraph replay of a whole step: batches are static (shuffle=False, core.py:472-481), so every
+    #    (batch, kind) pair is captured once and replayed in all later epochs: one host call per step
+    def _graph_step(self, key, fn, out_slot):
+        """Run ``fn()`` (a step that returns the device loss vector) and copy its result into ``out_slot``;
+        captured into a hipGraph on first use when graphs are enabled."""
+        if not self._use_graphs:
+            out_slot.copy_(fn())
+            return
+        g = self._graphs.get(key)
+        if g is None:
+            out_slot.copy_(fn())                      # eager warm-up: allocates the workspace of this batch size
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out_slot.copy_(fn())
+            self._graphs[key] = g
+            return                                     # the warm-up call already did this step's work once... see note
+        g.replay()
 
     def _dev(self, t, dtype=torch.float32):
         return None if t is None else torch.as_tensor(t).detach().to(device=self.device, dtype=dtype).contiguous()
@@ -423,6 +475,7 @@ class EigenFunctionTask(TrainingTask):
         """core.py:459-566 with the trajectory resident in HBM and one host copy of the losses per epoch."""
         k, lag = self.k, self.lag_idx
         self._flat.repack()
+        self._graphs = {}   # captured steps hold pointers into the previous call's batches
         ll = self._traj.shape[0] - lag
         _split(ll, self.test_ratio)                                  # core.py:465 (drawn, discarded)
         idx_train, idx_test = _split(ll, self.test_ratio)            # core.py:468
@@ -474,10 +527,10 @@ class EigenFunctionTask(TrainingTask):
             self.model.train()
             for it, (a, b) in enumerate(tr_batches):
                 X, w, Xl, wl = sl(Xtr, a, b)
-                log_tr[it].copy_(self.train_step(X, w, Xl, wl))
+                self._graph_step(("train", it), lambda: self.train_step(X, w, Xl, wl), log_tr[it])
             for it, (a, b) in enumerate(te_batches):              # core.py:535-551 (same loss, no update)
                 X, w, Xl, wl = sl(Xte, a, b)
-                log_te[it].copy_(self._forward(X, w, Xl, wl).loss_vec)
+                self._graph_step(("test", it), lambda: self._forward(X, w, Xl, wl).loss_vec, log_te[it])
             tr = log_tr[:len(tr_batches)].cpu()                    # the only host synchronisation of the epoch
             te = log_te[:len(te_batches)].cpu()
             dt = torch.get_default_dtype()
@@ -543,9 +596,10 @@ class AutoEncoderTask(TrainingTask):
     def reg_model(self):
         return None
 
-    def _step(self, feat, idx, w, with_grad, inv_wsum=None, advance=False):
-        """One fused kernel: forward, weighted MSE, parameter gradient.  ``inv_wsum`` = 1 / (global sum of the
-        batch weights); it does not depend on the model, so ``train`` computes it once per (static) batch."""
+    def _step(self, feat, idx, w, with_grad, inv_wsum=None, advance=False, fuse_adam=False):
+        """One fused kernel: forward, weighted MSE, parameter gradient (+ Adam when ``fuse_adam``).
+        ``inv_wsum`` = 1 / (global sum of the batch weights); it does not depend on the model, so ``train``
+        computes it once per (static) batch."""
         lib, fl = _hip.lib(), self._flat
         B = w.shape[0]
         sc = self._scratch.get(B)
@@ -555,14 +609,17 @@ class AutoEncoderTask(TrainingTask):
             wsum = w.sum(dtype=torch.float64)
             _dist.allreduce_sum_(wsum)
             inv_wsum = 1.0 / float(wsum)
+        adam = self.optimizer.fused_args() if (fuse_adam and with_grad) else None
         _hip.check(lib.cvf_ae_step(fl.desc, _hip.ptr(fl.theta), _hip.ptr(feat), _hip.ptr(idx), B, _hip.ptr(w),
                                    inv_wsum, _hip.ptr(sc), _hip.ptr(self._out2),
                                    _hip.ptr(fl.grad) if with_grad else None,
-                                   _hip.ptr(self.optimizer.step_count) if advance else None, _hip.stream()), "cvf_ae_step")
+                                   _hip.ptr(self.optimizer.step_count) if advance else None, adam, _hip.stream()), "cvf_ae_step")
         out = self._out2.clone()
         _dist.allreduce_sum_(out)
-        if with_grad:
+        if with_grad and adam is None:
             _dist.allreduce_sum_(fl.grad)
+            if advance:
+                self.optimizer.step(advance=False)
         return out[0] / out[1]
 
     def weighted_MSE_loss(self, X, weight):
@@ -624,8 +681,8 @@ class AutoEncoderTask(TrainingTask):
         for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
             self.model.train()
             for it, (a, b) in enumerate(tr_batches):
-                log_tr[it] = self._step(self._feature_traj, itr[a:b], wtr[a:b], True, iw_tr[it], advance=True)
-                self.optimizer.step(advance=False)
+                log_tr[it] = self._step(self._feature_traj, itr[a:b], wtr[a:b], True, iw_tr[it], advance=True,
+                                        fuse_adam=(world == 1))
             self.model.eval()
             for it, (a, b) in enumerate(te_batches):
                 log_te[it] = self._step(self._feature_traj, ite[a:b], wte[a:b], False, iw_te[it])

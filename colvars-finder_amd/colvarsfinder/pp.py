@@ -81,6 +81,13 @@ class AlignFeatureLayer(torch.nn.Module):
                 out += 2 if (tname == "dihedral" and not use_angle_value) else 1
         self.n_atoms, self.d_r, self.use_angle_value = int(n_atoms), out, bool(use_angle_value)
         self.features = [(t, tuple(int(a) for a in atoms)) for t, atoms in features]
+        # structure hints for the kernels (include/cvf.h): affine tables allow the fast kernels
+        flags = 0
+        if np.array_equal(align_idx, np.arange(len(align_idx))):
+            flags |= _hip.PP_ALIGN_CONTIG
+        if all(r[0] == _hip.FEAT_POSITION and r[1] == i and r[5] == 3 * i for i, r in enumerate(rec)):
+            flags |= _hip.PP_PURE_POSITION
+        self._flags = flags
         self.register_buffer("align_idx", torch.tensor(align_idx, dtype=torch.int32))
         self.register_buffer("ref_c", torch.tensor(ref - ref.mean(axis=0, keepdims=True), dtype=torch.float32))
         self.register_buffer("rec", torch.tensor(rec, dtype=torch.int32).reshape(-1, 6))
@@ -91,6 +98,7 @@ class AlignFeatureLayer(torch.nn.Module):
         d.mode, d.n_coord, d.n_align, d.n_rec = _hip.PP_ALIGN, 3 * self.n_atoms, self.align_idx.numel(), self.rec.shape[0]
         d.d_r, d.use_angle_value = self.d_r, int(self.use_angle_value)
         d.has_position = int(bool((self.rec[:, 0] == _hip.FEAT_POSITION).any().item()))
+        d.flags = self._flags
         d.align_idx, d.ref_c, d.rec = self.align_idx.data_ptr(), self.ref_c.data_ptr(), self.rec.data_ptr()
         return d
 

@@ -5,7 +5,7 @@
 // weight-gradient contraction  W_l += sum_frames zbar_l (x) [a_{l-1}; 1]  (K = frames).
 // Each block accumulates its share of the gradient in an LDS image of the flat parameter
 // buffer and writes it to its slab row once; slab rows are then summed in fixed order.
-#include "cvf_common.hpp"
+#include "cvf_adam.hpp"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -88,7 +88,8 @@ __global__ __launch_bounds__(64) void ae_step_kernel(cvf_mlp_desc mlp, const flo
                                                       const float* __restrict__ feat_rows,
                                                       const int64_t* __restrict__ idx, int64_t B,
                                                       const float* __restrict__ w, double inv_wsum, int with_grad,
-                                                      float* __restrict__ slab, double* __restrict__ partial) {
+                                                      float* __restrict__ slab, double* __restrict__ partial,
+                                                      int32_t* __restrict__ step) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
   const int L = mlp.n_layers;
@@ -184,17 +185,18 @@ __global__ __launch_bounds__(64) void ae_step_kernel(cvf_mlp_desc mlp, const flo
   if (with_grad) {
     float* out = slab + (int64_t)blockIdx.x * mlp.n_params;
     for (int p = lane; p < mlp.n_params; p += 64) out[p] = GI[p];
+    if (step != nullptr && blockIdx.x == 0 && lane == 0) *step += 1;  // one gradient per optimiser step
   }
 }
 
 __global__ void ae_reduce_kernel(const float* __restrict__ slab, const double* __restrict__ partial, int nblocks, int Pn,
-                                 float* __restrict__ grad, double* __restrict__ out2, int32_t* __restrict__ step) {
+                                 float* __restrict__ grad, double* __restrict__ out2, int use_adam, AdamDev adam) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (grad && step && p == 0) *step += 1;  // one gradient per optimiser step
   if (grad && p < Pn) {
     float acc = 0.0f;
     for (int g = 0; g < nblocks; ++g) acc += slab[(int64_t)g * Pn + p];
     grad[p] = acc;
+    if (use_adam) adam_apply(adam, adam_scalars(adam), cvf_mlp_desc{}, p, acc);
   }
   if (p < 2) {
     double acc = 0.0;
@@ -240,7 +242,7 @@ extern "C" int64_t cvf_ae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B) {
 
 extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
                            int64_t B, const float* w, double inv_wsum, float* scratch, double* out2, float* grad,
-                           int32_t* step_count, void* stream) {
+                           int32_t* step_count, const cvf_adam_args* adam, void* stream) {
   CVF_REQUIRE(mlp && theta && feat_rows && w && scratch && out2 && B > 0, "cvf_ae_step: bad argument");
   CVF_REQUIRE(mlp->n_nets == 1 && mlp->n_layers >= 1 && mlp->n_layers <= CVF_MAX_LAYERS, "cvf_ae_step: one chain expected");
   CVF_REQUIRE(mlp->dims[0] == mlp->dims[mlp->n_layers], "cvf_ae_step: output width %d != input width %d",
@@ -254,12 +256,18 @@ extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const fl
   double* partial = reinterpret_cast<double*>(scratch + (((int64_t)kAeBlocks * mlp->n_params + 1) & ~(int64_t)1));
   hipStream_t s = (hipStream_t)stream;
   (void)hipFuncSetAttribute((const void*)ae_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  AdamDev ad{};
+  if (adam != nullptr) {
+    CVF_REQUIRE(grad && adam->theta && adam->m && adam->v && adam->step_count, "cvf_ae_step: incomplete adam arguments");
+    ad = AdamDev{adam->theta, adam->m, adam->v, (float)adam->lr, (float)adam->beta1, (float)adam->beta2, (float)adam->eps,
+                 adam->step_count, nullptr};
+  }
   hipLaunchKernelGGL(ae_step_kernel, dim3(G), dim3(64), lds, s, *mlp, theta, feat_rows, idx, B, w, inv_wsum,
-                     grad ? 1 : 0, slab, partial);
+                     grad ? 1 : 0, slab, partial, grad ? step_count : nullptr);
   int rc = cvf_check_launch("ae_step_kernel");
   if (rc) return rc;
   const int Pn = mlp->n_params;
-  hipLaunchKernelGGL(ae_reduce_kernel, dim3((Pn + 255) / 256), dim3(256), 0, s, slab, partial, G, Pn, grad, out2, step_count);
+  hipLaunchKernelGGL(ae_reduce_kernel, dim3((Pn + 255) / 256), dim3(256), 0, s, slab, partial, G, Pn, grad, out2, adam != nullptr ? 1 : 0, ad);
   return cvf_check_launch("ae_reduce_kernel");
 }
 

@@ -1,0 +1,34 @@
+// Adam update shared by the stand-alone optimiser kernel and the fused gradient-reduce kernels.
+#pragma once
+#include "cvf_pack.hpp"
+
+struct AdamDev {           // device-side view of cvf_adam_args
+  float* theta;
+  float* m;
+  float* v;
+  float lr, b1, b2, eps;
+  const int32_t* step;     // number t >= 1 of the current step (advanced by the gradient kernel)
+  float* packed;           // MFMA fragment copy to refresh, or nullptr
+};
+
+struct AdamScalars {
+  float step_size, bc2_sqrt;
+};
+__device__ __forceinline__ AdamScalars adam_scalars(const AdamDev& a) {
+  const int t = *a.step;
+  const double bc1 = 1.0 - pow((double)a.b1, (double)t);
+  const double bc2 = 1.0 - pow((double)a.b2, (double)t);
+  return AdamScalars{(float)((double)a.lr / bc1), (float)sqrt(bc2)};
+}
+// torch.optim.Adam (single-tensor path): m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
+// theta -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__device__ __forceinline__ void adam_apply(const AdamDev& a, const AdamScalars& sc, const cvf_mlp_desc& mlp, int64_t i, float g) {
+  const float mi = a.m[i] + (g - a.m[i]) * (1.0f - a.b1);
+  const float vi = a.b2 * a.v[i] + (1.0f - a.b2) * g * g;
+  a.m[i] = mi;
+  a.v[i] = vi;
+  const float denom = sqrtf(vi) / sc.bc2_sqrt + a.eps;
+  const float th = a.theta[i] - sc.step_size * (mi / denom);
+  a.theta[i] = th;
+  if (a.packed != nullptr) pack_scatter(mlp, (int)i, th, a.packed);
+}

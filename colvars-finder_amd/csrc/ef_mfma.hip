@@ -19,7 +19,7 @@
 // (66-dword pitch, conflict-free) and accumulated across the block's tiles in an LDS image of the
 // net's parameters; each block writes one slab row, rows are summed in fixed order by cvf_slab_reduce.
 #include "cvf_common.hpp"
-#include "cvf_pack.hpp"
+#include "cvf_adam.hpp"
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp
                                                           const float* __restrict__ w, const float* __restrict__ w_lag,
                                                           const float* __restrict__ feat, const float* __restrict__ y_tiled,
                                                           const float* __restrict__ q_tiled, const double* __restrict__ coef,
-                                                          float* __restrict__ slab) {
+                                                          float* __restrict__ slab, int32_t* __restrict__ step) {
   constexpr int FT = 4;
   constexpr int RT = Hid<H>::RT;
   constexpr int RTO = (H + 15) / 16;      // row tiles of an H-row image (natural order)
@@ -615,28 +615,37 @@ __global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp
   __syncthreads();
   float* out = slab + (int64_t)blockIdx.x * mlp.n_params + gbase;
   for (int i = lane; i < gspan; i += 64) out[i] = GI[i];
+  // one gradient per optimiser step: advance the step counter read by the Adam that follows
+  if (step != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) *step += 1;
 }
 
 // grad[p] = sum over slab rows, fixed order: 16 row groups (strided) per parameter, then the 16
-// sub-sums in sequence -> bitwise reproducible without atomics.  Also advances the optimiser's
-// step counter (one reduce per train step) so that Adam needs no extra launch for it.
+// sub-sums in sequence -> bitwise reproducible without atomics.  With `adam` set (single-process runs:
+// no cross-rank reduction of the gradient in between) the same thread applies the Adam update.
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nrows, int P,
-                                                            float* __restrict__ grad, int32_t* __restrict__ step) {
+                                                            float* __restrict__ grad, int use_adam, AdamDev adam,
+                                                            cvf_mlp_desc mlp) {
   __shared__ float sub[16][64];
   const int px = threadIdx.x, gy = threadIdx.y;
   const int p = blockIdx.x * 64 + px;
-  float acc = 0.0f;
-  if (p < P)
-    for (int64_t g = gy; g < nrows; g += 16) acc += slab[g * P + p];
-  sub[gy][px] = acc;
+  float acc0 = 0.0f, acc1 = 0.0f;
+  if (p < P) {
+    int64_t g = gy;
+    for (; g + 16 < nrows; g += 32) {   // two independent loads in flight
+      acc0 += slab[g * P + p];
+      acc1 += slab[(g + 16) * P + p];
+    }
+    if (g < nrows) acc0 += slab[g * P + p];
+  }
+  sub[gy][px] = acc0 + acc1;
   __syncthreads();
   if (gy == 0 && p < P) {
     float s = 0.0f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) s += sub[t][px];
     grad[p] = s;
+    if (use_adam) adam_apply(adam, adam_scalars(adam), mlp, p, s);
   }
-  if (step != nullptr && blockIdx.x == 0 && px == 0 && gy == 0) *step += 1;
 }
 
 bool ef_shape(const cvf_mlp_desc* m, int* H, int* NH) {
@@ -717,7 +726,8 @@ extern "C" int64_t cvf_ef_backward_slab_rows(int64_t n_tiles) { return bwd_grid(
 
 extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
                                int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
-                               const float* y_tiled, const float* q_tiled, const double* coef, float* slab, void* stream) {
+                               const float* y_tiled, const float* q_tiled, const double* coef, float* slab,
+                               int32_t* step_count, void* stream) {
   CVF_REQUIRE(cfg && mlp && theta && packed && w && feat_tiled && y_tiled && coef && slab && B > 0,
               "cvf_ef_backward: bad argument");
   CVF_REQUIRE(cfg->lag_idx > 0 || q_tiled, "cvf_ef_backward: generator mode needs q");
@@ -747,16 +757,26 @@ extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, c
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
     hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH>), grid, dim3(64), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed, w,
-                       w_lag, feat_tiled, y_tiled, q_tiled, coef, slab);
+                       w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count);
   });
   CVF_REQUIRE(launched, "cvf_ef_backward: no kernel instance for hidden width %d x %d layers", H, NH);
   return cvf_check_launch("ef_bwd_mfma_kernel");
 }
 
-extern "C" int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, int32_t* step_count,
+extern "C" int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,
                                void* stream) {
   CVF_REQUIRE(slab && grad && n_rows > 0 && n_params > 0, "cvf_slab_reduce: bad argument");
+  AdamDev ad{};
+  cvf_mlp_desc md = {};
+  if (adam != nullptr) {
+    CVF_REQUIRE(adam->theta && adam->m && adam->v && adam->step_count, "cvf_slab_reduce: incomplete adam arguments");
+    CVF_REQUIRE(adam->packed == nullptr || (adam->mlp != nullptr && adam->mlp->n_params == n_params),
+                "cvf_slab_reduce: packed buffer needs its mlp desc");
+    ad = AdamDev{adam->theta, adam->m, adam->v, (float)adam->lr, (float)adam->beta1, (float)adam->beta2, (float)adam->eps,
+                 adam->step_count, adam->packed};
+    if (adam->packed) md = *adam->mlp;
+  }
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n_params + 63) / 64)), dim3(64, 16), 0, (hipStream_t)stream, slab,
-                     n_rows, (int)n_params, grad, step_count);
+                     n_rows, (int)n_params, grad, adam != nullptr ? 1 : 0, ad, md);
   return cvf_check_launch("slab_reduce_kernel");
 }

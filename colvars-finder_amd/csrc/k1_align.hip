@@ -10,17 +10,41 @@ namespace {
 struct Rec {
   int type, a0, a1, a2, a3, out;
 };
-__device__ __forceinline__ Rec load_rec(const int32_t* __restrict__ rec, int r) {
+__device__ __forceinline__ Rec load_rec(const int32_t* rec, int r) {
   const int32_t* p = rec + 6 * r;
   return Rec{p[0], p[1], p[2], p[3], p[4], p[5]};
+}
+
+// The layer's small tables (feature records, align indices, reference coordinates) are copied to LDS once
+// per block: with one wave per SIMD a scalar-cache miss per loop iteration (~200+ cycles, nothing to overlap
+// with) was a third of the kernels' time; an LDS broadcast read is ~64 cycles and pipelines.
+struct Tables {
+  const int32_t* rec;
+  const int32_t* align_idx;
+  const float* ref_c;
+};
+__host__ __device__ inline int tables_dwords(const cvf_pp_desc& pp) { return 6 * pp.n_rec + 4 * pp.n_align; }
+__device__ __forceinline__ Tables stage_tables(const cvf_pp_desc& pp, float* lds, int lane) {
+  int32_t* recL = reinterpret_cast<int32_t*>(lds);
+  int32_t* alL = recL + 6 * pp.n_rec;
+  float* refL = reinterpret_cast<float*>(alL + pp.n_align);
+  for (int i = lane; i < 6 * pp.n_rec; i += CVF_WAVE) recL[i] = pp.rec[i];
+  for (int i = lane; i < pp.n_align; i += CVF_WAVE) alL[i] = pp.align_idx[i];
+  for (int i = lane; i < 3 * pp.n_align; i += CVF_WAVE) refL[i] = pp.ref_c[i];
+  return Tables{recL, alL, refL};
 }
 __device__ __forceinline__ V3 atom(const float* my, int a) { return V3{my[3 * a], my[3 * a + 1], my[3 * a + 2]}; }
 
 // per-lane alignment: centroid (fp64), covariance (fp64), rotation, Kinv
-__device__ __forceinline__ void align_lane(const cvf_pp_desc& pp, const float* my, double (&c)[3], KabschOut& ko) {
+// CONTIG: align atom b is frame atom b (CVF_PP_ALIGN_CONTIG): every LDS address is affine in the loop
+// counter, so the compiler batches the reads of several atoms behind one wait.
+template <bool CONTIG>
+__device__ __forceinline__ void align_lane(const cvf_pp_desc& pp, const Tables& tb, const float* my, double (&c)[3],
+                                           KabschOut& ko) {
   double cx = 0, cy = 0, cz = 0;
+#pragma unroll 4
   for (int b = 0; b < pp.n_align; ++b) {
-    const int a = pp.align_idx[b];
+    const int a = CONTIG ? b : tb.align_idx[b];
     cx += (double)my[3 * a];
     cy += (double)my[3 * a + 1];
     cz += (double)my[3 * a + 2];
@@ -30,10 +54,11 @@ __device__ __forceinline__ void align_lane(const cvf_pp_desc& pp, const float* m
   c[1] = cy * inv;
   c[2] = cz * inv;
   double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll 2
   for (int b = 0; b < pp.n_align; ++b) {
-    const int a = pp.align_idx[b];
+    const int a = CONTIG ? b : tb.align_idx[b];
     const double xc0 = (double)my[3 * a] - c[0], xc1 = (double)my[3 * a + 1] - c[1], xc2 = (double)my[3 * a + 2] - c[2];
-    const double r0 = (double)pp.ref_c[3 * b], r1 = (double)pp.ref_c[3 * b + 1], r2 = (double)pp.ref_c[3 * b + 2];
+    const double r0 = (double)tb.ref_c[3 * b], r1 = (double)tb.ref_c[3 * b + 1], r2 = (double)tb.ref_c[3 * b + 2];
     H[0][0] += xc0 * r0; H[0][1] += xc0 * r1; H[0][2] += xc0 * r2;
     H[1][0] += xc1 * r0; H[1][1] += xc1 * r1; H[1][2] += xc1 * r2;
     H[2][0] += xc2 * r0; H[2][1] += xc2 * r1; H[2][2] += xc2 * r2;
@@ -46,6 +71,7 @@ __device__ __forceinline__ V3 centred(const float* my, int a, const double (&c)[
             (float)((double)my[3 * a + 2] - c[2])};
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
                                                        float* __restrict__ feat_tiled, float* __restrict__ feat_rows,
                                                        float* __restrict__ aux_tiled) {
@@ -54,11 +80,12 @@ __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const floa
   const int64_t tile = blockIdx.x;
   const int nc = pp.n_coord;
   load_x_tile(x, B, nc, tile, lds, lane);
+  const Tables tb = stage_tables(pp, lds + CVF_TILE * x_tile_stride(nc), lane);
   __syncthreads();
   const float* my = lds + lane * x_tile_stride(nc);
   double c[3];
   KabschOut ko;
-  align_lane(pp, my, c, ko);
+  align_lane<FAST>(pp, tb, my, c, ko);
   if (aux_tiled) {
     float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
 #pragma unroll
@@ -75,8 +102,19 @@ __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const floa
     if (ft) ft[o * CVF_TILE] = v;
     if (fr) fr[o] = v;
   };
+  if (FAST) {  // CVF_PP_PURE_POSITION: record r = position of atom r -> outputs 3r..3r+2
+#pragma unroll 4
+    for (int a = 0; a < pp.n_rec; ++a) {
+      const V3 al = row_times(centred(my, a, c), ko.R);
+      emit(3 * a, al.x);
+      emit(3 * a + 1, al.y);
+      emit(3 * a + 2, al.z);
+    }
+    return;
+  }
+#pragma unroll 2
   for (int r = 0; r < pp.n_rec; ++r) {
-    const Rec rc = load_rec(pp.rec, r);
+    const Rec rc = load_rec(tb.rec, r);
     if (rc.type == CVF_FEAT_POSITION) {
       const V3 al = row_times(centred(my, rc.a0, c), ko.R);
       emit(rc.out, al.x);
@@ -131,6 +169,9 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
   load_x_tile(x, B, nc, tile, lds, lane);
   float* Gl = lds + CVF_TILE * stride + lane;  // G(j) = Gl[j*64]
   for (int j = 0; j < nc; ++j) Gl[j * CVF_TILE] = 0.0f;
+  const Tables tb = stage_tables(pp, lds + CVF_TILE * (stride + nc), lane);
+  float* aL = lds + CVF_TILE * (stride + nc) + tables_dwords(pp);   // diag_coeff, staged like the tables
+  for (int i = lane; i < nc; i += CVF_WAVE) aL[i] = a[i];
   __syncthreads();
   const float* my = lds + lane * stride;
   const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
@@ -157,7 +198,7 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
   V3 sump = v3(0, 0, 0);
   float M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int r = 0; r < pp.n_rec; ++r) {
-    const Rec rc = load_rec(pp.rec, r);
+    const Rec rc = load_rec(tb.rec, r);
     if (rc.type == CVF_FEAT_POSITION) {
       const V3 g = v3(gt[rc.out * CVF_TILE], gt[(rc.out + 1) * CVF_TILE], gt[(rc.out + 2) * CVF_TILE]);
       const V3 p = mat_times(R, g);
@@ -208,15 +249,16 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
     }
     const V3 shift = inv_nal * sump;
     for (int b = 0; b < pp.n_align; ++b) {
-      const V3 rf = v3(pp.ref_c[3 * b], pp.ref_c[3 * b + 1], pp.ref_c[3 * b + 2]);
-      addG(pp.align_idx[b], mat_times(Z, rf) - shift);
+      const V3 rf = v3(tb.ref_c[3 * b], tb.ref_c[3 * b + 1], tb.ref_c[3 * b + 2]);
+      addG(tb.align_idx[b], mat_times(Z, rf) - shift);
     }
   }
   // ---- E = sum a G^2 ; u = a .* G (in place)
   float E = 0.0f;
+#pragma unroll 6
   for (int j = 0; j < nc; ++j) {
     const float Gj = Gl[j * CVF_TILE];
-    const float uj = a[j] * Gj;
+    const float uj = aL[j] * Gj;
     E += uj * Gj;
     Gl[j * CVF_TILE] = uj;
   }
@@ -225,12 +267,12 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
   V3 ubar = v3(0, 0, 0);
   float dR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (pp.has_position) {
-    for (int b = 0; b < pp.n_align; ++b) ubar = ubar + getU(pp.align_idx[b]);
+    for (int b = 0; b < pp.n_align; ++b) ubar = ubar + getU(tb.align_idx[b]);
     ubar = inv_nal * ubar;
     float dH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < pp.n_align; ++b) {
-      const V3 u = getU(pp.align_idx[b]) - ubar;
-      const V3 rf = v3(pp.ref_c[3 * b], pp.ref_c[3 * b + 1], pp.ref_c[3 * b + 2]);
+      const V3 u = getU(tb.align_idx[b]) - ubar;
+      const V3 rf = v3(tb.ref_c[3 * b], tb.ref_c[3 * b + 1], tb.ref_c[3 * b + 2]);
       dH[0] += u.x * rf.x; dH[1] += u.x * rf.y; dH[2] += u.x * rf.z;
       dH[3] += u.y * rf.x; dH[4] += u.y * rf.y; dH[5] += u.y * rf.z;
       dH[6] += u.z * rf.x; dH[7] += u.z * rf.y; dH[8] += u.z * rf.z;
@@ -249,7 +291,7 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
     }
   }
   for (int r = 0; r < pp.n_rec; ++r) {
-    const Rec rc = load_rec(pp.rec, r);
+    const Rec rc = load_rec(tb.rec, r);
     if (rc.type == CVF_FEAT_POSITION) {
       const V3 qa = row_times(getU(rc.a0) - ubar, R) + row_times(centred(my, rc.a0, c), dR);
       qt[rc.out * CVF_TILE] = qa.x;
@@ -273,6 +315,120 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
         qt[(rc.out + 1) * CVF_TILE] = e.cs * dphi;
       }
     }
+  }
+}
+
+// Same result for the common layer (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION: every atom emits its aligned
+// position, the align atoms are the first n_align atoms): three passes over the atoms with NO read-modify-write
+// of a per-atom array - G_a is recomputed from g_a where it is needed - so all loads of a pass are independent
+// and the waits of a single resident wave overlap instead of adding up.
+__global__ __launch_bounds__(64) void metric_pure_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
+                                                          const float* __restrict__ aux_tiled,
+                                                          const float* __restrict__ a, int k,
+                                                          const float* __restrict__ g_tiled,
+                                                          float* __restrict__ q_tiled, float* __restrict__ e_tiled) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int64_t tile = blockIdx.x;
+  const int net = blockIdx.y;
+  const int nc = pp.n_coord, N = pp.n_rec, nal = pp.n_align;
+  const int stride = x_tile_stride(nc);
+  load_x_tile(x, B, nc, tile, lds, lane);
+  float* Ul = lds + CVF_TILE * stride + lane;                        // u(j) = Ul[j*64]
+  float* refL = lds + CVF_TILE * (stride + nc);                      // [3*nal]
+  float* aL = refL + 3 * nal;                                        // [nc]
+  for (int i = lane; i < 3 * nal; i += CVF_WAVE) refL[i] = pp.ref_c[i];
+  for (int i = lane; i < nc; i += CVF_WAVE) aL[i] = a[i];
+  __syncthreads();
+  const float* my = lds + lane * stride;
+  const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
+  float R[9], Kinv[6];
+  double c[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = ax[i * CVF_TILE];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c[i] = (double)ax[(9 + i) * CVF_TILE];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Kinv[i] = ax[(12 + i) * CVF_TILE];
+  const int64_t base = (tile * k + net) * (int64_t)pp.d_r * CVF_TILE + lane;
+  const float* gt = g_tiled + base;
+  float* qt = q_tiled + base;
+  // pass 1: sum of p_a = R g_a and M = sum xc_a (x) g_a
+  V3 sump = v3(0, 0, 0);
+  float M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+  for (int at = 0; at < N; ++at) {
+    const V3 g = v3(gt[(3 * at) * CVF_TILE], gt[(3 * at + 1) * CVF_TILE], gt[(3 * at + 2) * CVF_TILE]);
+    sump = sump + mat_times(R, g);
+    const V3 xc = centred(my, at, c);
+    M[0] += xc.x * g.x; M[1] += xc.x * g.y; M[2] += xc.x * g.z;
+    M[3] += xc.y * g.x; M[4] += xc.y * g.y; M[5] += xc.y * g.z;
+    M[6] += xc.z * g.x; M[7] += xc.z * g.y; M[8] += xc.z * g.z;
+  }
+  float T[9], Z[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * M[j] + R[3 + i] * M[3 + j] + R[6 + i] * M[6 + j];
+  const V3 s = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Z[3 * i + 0] = R[3 * i + 1] * s.z - R[3 * i + 2] * s.y;
+    Z[3 * i + 1] = -R[3 * i + 0] * s.z + R[3 * i + 2] * s.x;
+    Z[3 * i + 2] = R[3 * i + 0] * s.y - R[3 * i + 1] * s.x;
+  }
+  const float inv_nal = 1.0f / (float)nal;
+  const V3 shift = inv_nal * sump;
+  // pass 2: G_a, E, u_a = a .* G_a (kept in LDS, write only), sums for the tangent of the rotation
+  float E = 0.0f;
+  V3 usum = v3(0, 0, 0), rsum = v3(0, 0, 0);
+  float dH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+  for (int at = 0; at < N; ++at) {
+    const V3 g = v3(gt[(3 * at) * CVF_TILE], gt[(3 * at + 1) * CVF_TILE], gt[(3 * at + 2) * CVF_TILE]);
+    V3 G = mat_times(R, g);
+    const bool al = at < nal;
+    const V3 rf = al ? v3(refL[3 * at], refL[3 * at + 1], refL[3 * at + 2]) : v3(0, 0, 0);
+    if (al) G = G + (mat_times(Z, rf) - shift);
+    const V3 u = v3(aL[3 * at] * G.x, aL[3 * at + 1] * G.y, aL[3 * at + 2] * G.z);
+    E += u.x * G.x + u.y * G.y + u.z * G.z;
+    Ul[(3 * at) * CVF_TILE] = u.x;
+    Ul[(3 * at + 1) * CVF_TILE] = u.y;
+    Ul[(3 * at + 2) * CVF_TILE] = u.z;
+    if (al) {
+      usum = usum + u;
+      rsum = rsum + rf;
+      dH[0] += u.x * rf.x; dH[1] += u.x * rf.y; dH[2] += u.x * rf.z;
+      dH[3] += u.y * rf.x; dH[4] += u.y * rf.y; dH[5] += u.y * rf.z;
+      dH[6] += u.z * rf.x; dH[7] += u.z * rf.y; dH[8] += u.z * rf.z;
+    }
+  }
+  e_tiled[(tile * k + net) * CVF_TILE + lane] = E;
+  const V3 ubar = inv_nal * usum;
+  // dH = sum_b (u_b - ubar) (x) ref_b = dH' - ubar (x) sum_b ref_b
+  dH[0] -= ubar.x * rsum.x; dH[1] -= ubar.x * rsum.y; dH[2] -= ubar.x * rsum.z;
+  dH[3] -= ubar.y * rsum.x; dH[4] -= ubar.y * rsum.y; dH[5] -= ubar.y * rsum.z;
+  dH[6] -= ubar.z * rsum.x; dH[7] -= ubar.z * rsum.y; dH[8] -= ubar.z * rsum.z;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * dH[j] + R[3 + i] * dH[3 + j] + R[6 + i] * dH[6 + j];
+  const V3 w = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
+  float dR[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dR[3 * i + 0] = R[3 * i + 1] * w.z - R[3 * i + 2] * w.y;
+    dR[3 * i + 1] = -R[3 * i + 0] * w.z + R[3 * i + 2] * w.x;
+    dR[3 * i + 2] = R[3 * i + 0] * w.y - R[3 * i + 1] * w.x;
+  }
+  // pass 3: q_a = (u_a - ubar) R + xc_a dR
+#pragma unroll 4
+  for (int at = 0; at < N; ++at) {
+    const V3 u = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
+    const V3 qa = row_times(u - ubar, R) + row_times(centred(my, at, c), dR);
+    qt[(3 * at) * CVF_TILE] = qa.x;
+    qt[(3 * at + 1) * CVF_TILE] = qa.y;
+    qt[(3 * at + 2) * CVF_TILE] = qa.z;
   }
 }
 
@@ -309,10 +465,20 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
   CVF_REQUIRE(pp->mode == CVF_PP_ALIGN, "unknown pp mode %d", pp->mode);
   CVF_REQUIRE(pp->n_coord % 3 == 0 && pp->n_align >= 3 && pp->align_idx && pp->ref_c && pp->rec,
               "cvf_align_feature_fwd: malformed descriptor (n_coord=%d n_align=%d)", pp->n_coord, pp->n_align);
-  const size_t lds = (size_t)CVF_TILE * x_tile_stride(pp->n_coord) * sizeof(float);
+  const size_t lds = ((size_t)CVF_TILE * x_tile_stride(pp->n_coord) + tables_dwords(*pp)) * sizeof(float);
   CVF_REQUIRE(lds <= 160 * 1024, "frames of %d coordinates do not fit the lane-per-frame kernel's LDS tile", pp->n_coord);
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k1_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k1_align_kernel, dim3((unsigned)T), dim3(64), lds, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled);
+  if (lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)k1_align_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k1_align_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  const bool fast = (pp->flags & (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION)) == (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION);
+  if (fast) {
+    CVF_REQUIRE(pp->d_r == 3 * pp->n_rec && 3 * pp->n_rec <= pp->n_coord && pp->n_align * 3 <= pp->n_coord,
+                "cvf_align_feature_fwd: flags do not match the descriptor");
+    hipLaunchKernelGGL(k1_align_kernel<true>, dim3((unsigned)T), dim3(64), lds, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled);
+  } else {
+    hipLaunchKernelGGL(k1_align_kernel<false>, dim3((unsigned)T), dim3(64), lds, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled);
+  }
   return cvf_check_launch("k1_align_kernel");
 }
 
@@ -329,10 +495,20 @@ extern "C" int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B
     return cvf_check_launch("metric_identity_kernel");
   }
   CVF_REQUIRE(x && aux_tiled, "cvf_metric_apply: align mode needs x and aux");
-  const size_t lds = (size_t)CVF_TILE * (x_tile_stride(pp->n_coord) + pp->n_coord) * sizeof(float);
+  const size_t lds = ((size_t)CVF_TILE * (x_tile_stride(pp->n_coord) + pp->n_coord) + tables_dwords(*pp) + pp->n_coord) * sizeof(float);
   CVF_REQUIRE(lds <= 160 * 1024, "frames of %d coordinates do not fit the lane-per-frame metric kernel's LDS", pp->n_coord);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)metric_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool fast = (pp->flags & (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION)) == (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION);
+  if (fast) {
+    CVF_REQUIRE(pp->d_r == 3 * pp->n_rec && 3 * pp->n_rec <= pp->n_coord && pp->n_align <= pp->n_rec,
+                "cvf_metric_apply: flags do not match the descriptor");
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)metric_pure_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(metric_pure_kernel, dim3((unsigned)T, k), dim3(64), lds, s, *pp, x, B, aux_tiled, a, k, g_tiled, q_tiled,
+                       e_tiled);
+    return cvf_check_launch("metric_pure_kernel");
+  }
   hipLaunchKernelGGL(metric_align_kernel, dim3((unsigned)T, k), dim3(64), lds, s, *pp, x, B, aux_tiled, a, k, g_tiled,
                      q_tiled, e_tiled);
   return cvf_check_launch("metric_align_kernel");

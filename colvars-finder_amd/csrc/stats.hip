@@ -3,7 +3,7 @@
 // data-parallel job must derive the same ordering cvec from the reduced vector), the scalar
 // tail of the loss (core.py:426-457) with its partial derivatives, and K6: Adam.
 #include "cvf_common.hpp"
-#include "cvf_pack.hpp"
+#include "cvf_adam.hpp"
 #include <stdarg.h>
 #include <stdio.h>
 #include <type_traits>
@@ -36,7 +36,7 @@ extern "C" int cvf_ef_nstats(int k, int lag_idx) {
 
 namespace {
 
-constexpr int kStatBlocks = 512;
+constexpr int kStatBlocks = 128;
 constexpr int kMaxStats = 1 + CVF_MAX_NETS + CVF_NPAIR(CVF_MAX_NETS) + 1 + 3 * CVF_MAX_NETS;
 
 // one wave per block; block g handles tiles g, g+G, ...; lane = frame.  K is a template
@@ -114,9 +114,8 @@ __global__ void ef_stats_final_kernel(int ns, int nblocks, const double* __restr
 
 // the scalar tail of loss_func, one thread, fp64
 template <int KT>
-__global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats, double* __restrict__ loss_vec,
-                               double* __restrict__ coef) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void ef_loss_tail(const cvf_ef_cfg& cfg, const double* __restrict__ stats, double* __restrict__ loss_vec,
+                             double* __restrict__ coef) {
   constexpr int k = KT;
   const int npair = CVF_NPAIR(k);
   const double W = stats[0];
@@ -225,27 +224,41 @@ __global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats,
   }
 }
 
-__global__ void adam_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
-                            float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                            const int32_t* __restrict__ step_in, cvf_mlp_desc mlp, float* __restrict__ packed) {
-  // torch.optim.Adam (single-tensor path): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
-  // theta -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-  const int t = *step_in;   // advanced by the gradient reduce kernel of this step (cvf_slab_reduce / cvf_ae_step)
-  const double bc1 = 1.0 - pow((double)b1, (double)t);
-  const double bc2 = 1.0 - pow((double)b2, (double)t);
-  const float step_size = (float)((double)lr / bc1);
-  const float bc2_sqrt = (float)sqrt(bc2);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float g = grad[i];
-    const float mi = m[i] + (g - m[i]) * (1.0f - b1);   // lerp form used by torch
-    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    const float th = theta[i] - step_size * (mi / denom);
-    theta[i] = th;
-    if (packed != nullptr) pack_scatter(mlp, (int)i, th, packed);  // keep the MFMA fragments in step
+template <int KT>
+__global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats, double* __restrict__ loss_vec,
+                               double* __restrict__ coef) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) ef_loss_tail<KT>(cfg, stats, loss_vec, coef);
+}
+
+// single-process fast path: second reduction stage and the scalar tail in ONE launch
+template <int KT>
+__global__ void ef_stats_final_loss_kernel(cvf_ef_cfg cfg, int ns, int nblocks, const double* __restrict__ partial,
+                                           double* __restrict__ stats, double* __restrict__ loss_vec,
+                                           double* __restrict__ coef) {
+  __shared__ double sub[8 * kMaxStats];
+  __shared__ double fin[kMaxStats];
+  const int j = threadIdx.x & 7, i = threadIdx.x >> 3;
+  if (i < ns) {
+    double s = 0.0;
+    for (int g = j; g < nblocks; g += 8) s += partial[(int64_t)g * ns + i];
+    sub[i * 8 + j] = s;
   }
+  __syncthreads();
+  if (i < ns && j == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s += sub[i * 8 + t];
+    fin[i] = s;
+    stats[i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) ef_loss_tail<KT>(cfg, fin, loss_vec, coef);
+}
+
+__global__ void adam_kernel(AdamDev a, const float* __restrict__ grad, int64_t n, cvf_mlp_desc mlp) {
+  const AdamScalars sc = adam_scalars(a);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    adam_apply(a, sc, mlp, i, grad[i]);
 }
 
 __global__ void sgd_kernel(float* __restrict__ theta, const float* __restrict__ grad, int64_t n, float lr, cvf_mlp_desc mlp,
@@ -272,7 +285,8 @@ static bool k_dispatch(int k, F&& f) {
 }
 
 extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
-                            const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, void* stream) {
+                            const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, double* loss_vec,
+                            double* coef, void* stream) {
   CVF_REQUIRE(cfg && w && y_tiled && scratch && stats && B > 0, "cvf_ef_stats: bad argument");
   CVF_REQUIRE(cfg->k >= 1 && cfg->k <= CVF_MAX_NETS, "cvf_ef_stats: k=%d out of range", cfg->k);
   if (cfg->lag_idx == 0) CVF_REQUIRE(e_tiled, "cvf_ef_stats: generator mode needs e_tiled");
@@ -293,6 +307,15 @@ extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, co
   });
   int rc = cvf_check_launch("ef_stats_partial_kernel");
   if (rc) return rc;
+  if (loss_vec != nullptr) {  // no cross-rank reduction in between: finish the loss in the same launch
+    CVF_REQUIRE(coef != nullptr, "cvf_ef_stats: loss_vec without coef");
+    k_dispatch(cfg->k, [&](auto kc) {
+      constexpr int K = decltype(kc)::value;
+      hipLaunchKernelGGL((ef_stats_final_loss_kernel<K>), dim3(1), dim3(8 * kMaxStats), 0, s, *cfg, ns, G, scratch, stats,
+                         loss_vec, coef);
+    });
+    return cvf_check_launch("ef_stats_final_loss_kernel");
+  }
   hipLaunchKernelGGL(ef_stats_final_kernel, dim3(1), dim3(8 * kMaxStats), 0, s, ns, G, scratch, stats);
   return cvf_check_launch("ef_stats_final_kernel");
 }
@@ -315,8 +338,8 @@ extern "C" int cvf_adam_step(float* theta, const float* grad, float* m, float* v
   cvf_mlp_desc none = {};
   const cvf_mlp_desc& md = packed ? *mlp : none;
   const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, grad, m, v, n, (float)lr,
-                     (float)beta1, (float)beta2, (float)eps, step_count, md, packed);
+  AdamDev ad{theta, m, v, (float)lr, (float)beta1, (float)beta2, (float)eps, step_count, packed};
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ad, grad, n, md);
   return cvf_check_launch("adam_kernel");
 }
 

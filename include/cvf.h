@@ -36,6 +36,11 @@ extern "C" {
  * "position ... type_id 3") */
 enum { CVF_FEAT_ANGLE = 0, CVF_FEAT_BOND = 1, CVF_FEAT_DIHEDRAL = 2, CVF_FEAT_POSITION = 3 };
 enum { CVF_PP_IDENTITY = 0, CVF_PP_ALIGN = 1 };
+/* cvf_pp_desc.flags: structure of the tables, enabling kernels whose LDS addresses are affine in the atom index */
+enum {
+  CVF_PP_ALIGN_CONTIG = 1,   /* align_idx[b] == b for all b (the align atoms are the first n_align frame atoms) */
+  CVF_PP_PURE_POSITION = 2   /* record r is {POSITION, atom r, out 3r}: n_rec atoms emit their aligned positions in order */
+};
 
 /* The preprocessing layer r(x): torch.nn.Identity (examples/2d/2d.ipynb:485) or the
  * Kabsch alignment + feature map the reference gets from molann
@@ -48,7 +53,7 @@ typedef struct cvf_pp_desc {
   int32_t d_r;             /* output dimension */
   int32_t use_angle_value; /* 0: angle->cos, dihedral->(cos,sin); 1: radians */
   int32_t has_position;    /* any CVF_FEAT_POSITION record */
-  int32_t pad_;
+  int32_t flags;           /* CVF_PP_* hints the caller vouches for (0 is always valid) */
   const int32_t* align_idx; /* [n_align] atom indices into the frame */
   const float* ref_c;       /* [n_align*3] reference positions minus their centroid */
   const int32_t* rec;       /* [n_rec*6]: type, a0, a1, a2, a3, out_offset (one record per
@@ -90,6 +95,18 @@ int cvf_ef_nstats(int k, int lag_idx);
  * [gS1(k), gS2(k*k symmetric full), gE_or_gT(k), gS1'(k), gS2'_ii(k)] */
 #define CVF_COEF_LEN(k) (4 * (k) + (k) * (k))
 
+/* Adam scalars + state for the fused "reduce the gradient and update" calls (single-process runs, where no
+ * cross-rank all-reduce sits between the gradient and the update).  torch.optim.Adam as built at core.py:164. */
+typedef struct cvf_adam_args {
+  float* theta;
+  float* m;
+  float* v;
+  double lr, beta1, beta2, eps;
+  const int32_t* step_count;   /* device: number t >= 1 of the current step */
+  const cvf_mlp_desc* mlp;     /* with `packed`: the nets whose fragment copy is refreshed, else NULL */
+  float* packed;
+} cvf_adam_args;
+
 int cvf_version(void);
 const char* cvf_last_error(void);
 
@@ -124,7 +141,8 @@ int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* pac
  * transfer: y_lag_tiled, w_lag.  scratch: cvf_ef_stats_scratch_doubles() doubles. */
 int64_t cvf_ef_stats_scratch_doubles(int k, int lag_idx);
 int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
-                 const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, void* stream);
+                 const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, double* loss_vec,
+                 double* coef, void* stream); /* loss_vec/coef non-NULL: also run cvf_ef_loss in the same launch */
 
 /* --- loss, eigenvalues, ordering and the partial derivatives d loss / d stat
  * (core.py:426-457 after the sums).  One wave; runs after the cross-rank all-reduce of
@@ -140,9 +158,10 @@ int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* loss_vec, do
 int64_t cvf_ef_backward_slab_rows(int64_t n_tiles);
 int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed, int64_t B,
                     const float* w, const float* w_lag, const float* feat_tiled, const float* y_tiled,
-                    const float* q_tiled, const double* coef, float* slab, void* stream);
-int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, int32_t* step_count,
-                    void* stream); /* step_count (may be NULL): the optimiser's step counter, advanced by one */
+                    const float* q_tiled, const double* coef, float* slab, int32_t* step_count, void* stream);
+                    /* step_count (may be NULL): the optimiser's device step counter, advanced by one */
+int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,
+                    void* stream); /* adam (may be NULL): apply the update in the same launch */
 
 /* --- AutoEncoder: weighted reconstruction loss and its parameter gradient in one pass
  * (core.py:664-666,708).  feat_rows [n][d0] row-major (the precomputed feature
@@ -152,7 +171,8 @@ int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* 
 int64_t cvf_ae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B);
 int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx, int64_t B,
                 const float* w, double inv_wsum, float* scratch, double* out2, float* grad, int32_t* step_count,
-                void* stream); /* step_count (may be NULL) is advanced by one when grad != NULL */
+                const cvf_adam_args* adam, void* stream);
+                /* step_count (may be NULL) is advanced by one when grad != NULL; adam (may be NULL): update in the same call */
 
 /* --- nets forward on row-major features (inference: colvar_model(), core.py:372-382,
  * 640-647).  out [B][n_out] where n_out = n_nets * d_L; upto_layer < n_layers stops a

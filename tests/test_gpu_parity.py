@@ -223,6 +223,7 @@ def test_ae_train_trace(dev, name, tag, rtol):
 
 # ------------------------------------------------------------------------------------------------ Adam
 def test_fused_adam_matches_torch(dev):
+    """cvf_adam_step (stand-alone) and the Adam fused into cvf_slab_reduce vs torch.optim.Adam (core.py:164)."""
     from colvarsfinder import _hip
     lib = _hip.lib()
     n = 6603
@@ -230,17 +231,28 @@ def test_fused_adam_matches_torch(dev):
     theta0 = torch.randn(n, generator=gen)
     ref = theta0.clone().requires_grad_(True)
     opt = torch.optim.Adam([ref], lr=1e-3)
-    theta = theta0.to(dev)
-    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-    step = torch.zeros(1, device=dev, dtype=torch.int32)
+    st = {}
+    for tag in ("alone", "fused"):
+        st[tag] = dict(theta=theta0.to(dev), m=torch.zeros(n, device=dev), v=torch.zeros(n, device=dev),
+                       step=torch.zeros(1, device=dev, dtype=torch.int32), grad=torch.empty(n, device=dev))
     for it in range(25):
         grad = torch.randn(n, generator=gen) * (10.0 ** (it % 5 - 3))
         ref.grad = grad.clone()
         opt.step()
-        gd = torch.empty(n, device=dev)
-        # the gradient reduce of a step also advances the step counter (one-row slab here)
-        _hip.check(lib.cvf_slab_reduce(_hip.ptr(grad.to(dev)), 1, n, _hip.ptr(gd), _hip.ptr(step), _hip.stream()), "reduce")
-        _hip.check(lib.cvf_adam_step(_hip.ptr(theta), _hip.ptr(gd), _hip.ptr(m), _hip.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8,
-                                     _hip.ptr(step), None, None, _hip.stream()), "adam")
-    assert int(step.item()) == 25
-    np.testing.assert_allclose(theta.cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-7)
+        # the gradient arrives as 3 slab rows that sum to it
+        rows = torch.stack([0.25 * grad, 0.5 * grad, 0.25 * grad]).to(dev).contiguous()
+        a = st["alone"]
+        a["step"] += 1                                   # what the gradient kernel of a step does on the device
+        _hip.check(lib.cvf_slab_reduce(_hip.ptr(rows), 3, n, _hip.ptr(a["grad"]), None, _hip.stream()), "reduce")
+        _hip.check(lib.cvf_adam_step(_hip.ptr(a["theta"]), _hip.ptr(a["grad"]), _hip.ptr(a["m"]), _hip.ptr(a["v"]), n, 1e-3, 0.9,
+                                     0.999, 1e-8, _hip.ptr(a["step"]), None, None, _hip.stream()), "adam")
+        f = st["fused"]
+        f["step"] += 1
+        args = _hip.AdamArgs()
+        args.theta, args.m, args.v = f["theta"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr()
+        args.lr, args.beta1, args.beta2, args.eps, args.step_count = 1e-3, 0.9, 0.999, 1e-8, f["step"].data_ptr()
+        _hip.check(lib.cvf_slab_reduce(_hip.ptr(rows), 3, n, _hip.ptr(f["grad"]), args, _hip.stream()), "reduce+adam")
+    want = ref.detach().numpy()
+    np.testing.assert_allclose(st["alone"]["theta"].cpu().numpy(), want, rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(st["fused"]["theta"].cpu().numpy(), want, rtol=2e-6, atol=2e-7)
+    assert torch.equal(st["alone"]["theta"], st["fused"]["theta"])
