@@ -12,17 +12,38 @@
 // Also returns Kinv = (tr(P) I - P)^-1, P = sym(R^T H): the 3x3 solve of the analytic
 // derivative dR = R [Kinv ax(R^T dH)]x used by the VJP/JVP kernels.
 // ------------------------------------------------------------------------------------
+// fp64 reciprocal / reciprocal square root / square root from the hardware seeds (v_rcp_f64, v_rsq_f64:
+// ~2^-26 relative) + Newton steps to full double precision.  The IEEE division / sqrt sequences the compiler
+// emits otherwise (scale, fixup, denormal handling) are 3-4x longer, and this eigen-solve is the serial part of
+// a kernel that runs one wave per SIMD.  Inputs here are sums of squares of O(1..1e4) numbers: no denormals.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  // r <- r + r*(1 - x r^2)/2, twice
+  double e = fma(-x * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  e = fma(-x * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  return r;
+}
+__device__ __forceinline__ double fast_sqrt(double x) { return x > 0.0 ? x * fast_rsqrt(x) : 0.0; }
+
+// One Jacobi rotation annihilating A[P][Q].  With d = aqq - app, b = 2 apq:
+//   t = tan(phi) = sgn(d) b / (|d| + sqrt(d^2 + b^2)),  c = 1/sqrt(1+t^2),  s = t c
+// (the usual t = sgn(tau)/(|tau| + sqrt(1+tau^2)), tau = d/b, without dividing by b: b = 0 gives t = 0).
 template <int P, int Q>
 __device__ __forceinline__ void jacobi_rot(double (&A)[3][3], double (&V)[3][3]) {
   const double apq = A[P][Q];
   const double app = A[P][P], aqq = A[Q][Q];
-  // guard: rotation angle 0 when the off-diagonal entry is already negligible
-  const bool skip = fabs(apq) <= 1e-300 + 1e-18 * (fabs(app) + fabs(aqq));
-  const double theta = (aqq - app) / (2.0 * (skip ? 1.0 : apq));
-  double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
-  t = theta < 0.0 ? -t : t;
-  t = skip ? 0.0 : t;
-  const double c = 1.0 / sqrt(t * t + 1.0);
+  const double d = aqq - app, b = 2.0 * apq;
+  const double den = fabs(d) + fast_sqrt(fma(d, d, b * b)) + 1e-300;
+  const double t = (d < 0.0 ? -b : b) * fast_rcp(den);
+  const double c = fast_rsqrt(fma(t, t, 1.0));
   const double s = t * c;
   constexpr int R = 3 - P - Q;  // the remaining index
   A[P][P] = app - t * apq;
@@ -54,7 +75,7 @@ __device__ __forceinline__ void kabsch_from_H(const double (&H)[3][3], KabschOut
       V[i][j] = (i == j) ? 1.0 : 0.0;
     }
 #pragma unroll 1
-  for (int sweep = 0; sweep < 6; ++sweep) {
+  for (int sweep = 0; sweep < 5; ++sweep) {
     jacobi_rot<0, 1>(A, V);
     jacobi_rot<0, 2>(A, V);
     jacobi_rot<1, 2>(A, V);
@@ -79,15 +100,15 @@ __device__ __forceinline__ void kabsch_from_H(const double (&H)[3][3], KabschOut
     u1[i] = H[i][0] * v1[0] + H[i][1] * v1[1] + H[i][2] * v1[2];
     u2[i] = H[i][0] * v2[0] + H[i][1] * v2[1] + H[i][2] * v2[2];
   }
-  double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
-  n1 = n1 > 1e-300 ? 1.0 / n1 : 0.0;
+  double n1 = u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2];
+  n1 = n1 > 1e-300 ? fast_rsqrt(n1) : 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) u1[i] *= n1;
   const double pr = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
 #pragma unroll
   for (int i = 0; i < 3; ++i) u2[i] -= pr * u1[i];
-  double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
-  n2 = n2 > 1e-300 ? 1.0 / n2 : 0.0;
+  double n2 = u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2];
+  n2 = n2 > 1e-300 ? fast_rsqrt(n2) : 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) u2[i] *= n2;
   const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
@@ -111,7 +132,7 @@ __device__ __forceinline__ void kabsch_from_H(const double (&H)[3][3], KabschOut
   const double c00 = k11 * k22 - k12 * k12, c01 = k02 * k12 - k01 * k22, c02 = k01 * k12 - k02 * k11;
   const double c11 = k00 * k22 - k02 * k02, c12 = k01 * k02 - k00 * k12, c22 = k00 * k11 - k01 * k01;
   double det = k00 * c00 + k01 * c01 + k02 * c02;
-  det = fabs(det) > 1e-300 ? 1.0 / det : 0.0;
+  det = fabs(det) > 1e-300 ? fast_rcp(det) : 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll

@@ -20,9 +20,23 @@
 // net's parameters; each block writes one slab row, rows are summed in fixed order by cvf_slab_reduce.
 #include "cvf_common.hpp"
 #include "cvf_adam.hpp"
+#include <stdlib.h>
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Developer aid: tools/stamp_ef.hip compiles this file with -DCVF_STAMPS to read s_memtime at phase
+// boundaries of one wave per block; in the shipped library the macro is empty.
+#ifdef CVF_STAMPS
+__device__ unsigned long long g_stamps[64 * 4096];
+#define CVF_STAMP(i)                                                                              \
+  do {                                                                                            \
+    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 4096)                          \
+      g_stamps[(blockIdx.x * 2 + (threadIdx.x >> 6)) % 4096 * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define CVF_STAMP(i) do {} while (0)
+#endif
 
 namespace {
 
@@ -52,7 +66,11 @@ __device__ __forceinline__ void init_bias(Vec<H, FT>& X, const float* __restrict
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = hid_feature(rt, r, q);
-      bv[r] = (b != nullptr && f < H) ? b[f] : 0.0f;
+      bv[r] = 0.0f;
+      if (b != nullptr) {
+        const float x = b[f < H ? f : H - 1];
+        bv[r] = f < H ? x : 0.0f;
+      }
     }
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) X.v[rt][ft] = bv;
@@ -79,44 +97,126 @@ __device__ __forceinline__ void store_frames(float* __restrict__ p, const float 
   else p[0] = b[0];
 }
 
-// first layer: X += W0 [H x D] * in.  `in_lane` = tiled global array (rows = features, 64 frames per row)
-// + the lane's frame offset 4*col + ft0; pk0 = packed fragments F0 of this net
-template <int H, int FT>
-__device__ __forceinline__ void layer0_apply(Vec<H, FT>& X, const float* __restrict__ pk0, int D,
-                                             const float* __restrict__ in_lane, int lane) {
-  constexpr int RT = Hid<H>::RT;
-  const int q = lane >> 4;
-  const int S = (D + 3) >> 2;
-#pragma unroll 4
-  for (int s = 0; s < S; ++s) {
-    const int kf = 4 * s + q;
-    float a[RT];
+// ---- explicit prefetch.  At small batch sizes every wave of a launch starts together and each dependent
+// round trip to L2 / Infinity Cache costs 500-900 cycles with nothing else resident to cover it, so the
+// kernels issue the loads of a later phase (next chunk of k-steps, next layer's fragments) BEFORE the MFMAs
+// of the current one and keep them in registers.
+
+// A fragments of one H x H layer: NG k-steps x RT row tiles
+template <int H>
+struct HFrag {
+  float a[Hid<H>::NG][Hid<H>::RT];
+};
+template <int H>
+__device__ __forceinline__ void load_hfrag(HFrag<H>& f, const float* __restrict__ pk, int lane) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[rt] = pk0[(s * RT + rt) * 64 + lane];
-    float b[FT];
-    load_frames<FT>(in_lane + (int64_t)(kf < D ? kf : 0) * CVF_TILE, b);  // rows past D meet zero weights
+  for (int s = 0; s < Hid<H>::NG; ++s)
+#pragma unroll
+    for (int rt = 0; rt < Hid<H>::RT; ++rt) f.a[s][rt] = pk[(s * Hid<H>::RT + rt) * 64 + lane];
+}
+// Y += op(W) X with the fragments already in registers
+template <int H, int FT>
+__device__ __forceinline__ void hidden_mul(Vec<H, FT>& Y, const HFrag<H>& f, const Vec<H, FT>& X) {
+#pragma unroll
+  for (int s = 0; s < Hid<H>::NG; ++s)
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) X.v[rt][ft] = mfma4(a[rt], b[ft], X.v[rt][ft]);
+      for (int rt = 0; rt < Hid<H>::RT; ++rt) Y.v[rt][ft] = mfma4(f.a[s][rt], X.v[s >> 2][ft][s & 3], Y.v[rt][ft]);
+}
+// hidden -> hidden with a just-in-time fragment load (kept for call sites with nothing to overlap)
+template <int H, int FT>
+__device__ __forceinline__ void hidden_apply(Vec<H, FT>& Y, const float* __restrict__ pk, const Vec<H, FT>& X, int lane) {
+  HFrag<H> f;
+  load_hfrag<H>(f, pk, lane);
+  hidden_mul<H, FT>(Y, f, X);
+}
+
+// first layer: X += W0 [H x D] * in.  `in_lane` = tiled global array (rows = features, 64 frames per row)
+// + the lane's frame offset 4*col + ft0; pk0 = packed fragments F0 of this net.  k-steps are processed in
+// chunks of CH with the next chunk's operands (weights and activations) loading while the current one runs.
+template <int H, int FT, int CH>
+struct L0Chunk {
+  float a[CH][Hid<H>::RT];
+  float b[CH][FT];
+};
+template <int H, int FT, int CH>
+__device__ __forceinline__ void load_l0chunk(L0Chunk<H, FT, CH>& c, const float* __restrict__ pk0, int D, int S,
+                                             const float* __restrict__ in_lane, int s0, int lane) {
+  constexpr int RT = Hid<H>::RT;
+  const int q = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    // no branches around the loads (steps past S read step S-1 and are zeroed by a select): with straight-line
+    // code the compiler counts outstanding loads exactly and waits only for the chunk it is about to use
+    const int s = s0 + i;
+    const bool live = s < S;
+    const int se = live ? s : S - 1;
+    const int kf = 4 * se + q;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#ifdef CVF_EXP_NOW
+      const float v = 0.01f * (float)(se + rt);
+#else
+      const float v = pk0[(se * RT + rt) * 64 + lane];
+#endif
+      c.a[i][rt] = live ? v : 0.0f;
+    }
+#ifdef CVF_EXP_NOFEAT
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) c.b[i][ft] = 0.5f + 0.01f * (float)kf;
+#else
+    load_frames<FT>(in_lane + (int64_t)(kf < D ? kf : 0) * CVF_TILE, c.b[i]);  // rows past D meet zero weights
+#endif
+  }
+}
+template <int H, int FT, int CH>
+__device__ __forceinline__ void mul_l0chunk(Vec<H, FT>& X, const L0Chunk<H, FT, CH>& c) {
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < Hid<H>::RT; ++rt) X.v[rt][ft] = mfma4(c.a[i][rt], c.b[i][ft], X.v[rt][ft]);
+}
+template <int H, int FT, int CH = 6>
+__device__ __forceinline__ void layer0_apply(Vec<H, FT>& X, const float* __restrict__ pk0, int D,
+                                             const float* __restrict__ in_lane, int lane) {
+  const int S = (D + 3) >> 2;
+  L0Chunk<H, FT, CH> c0, c1;
+  load_l0chunk<H, FT, CH>(c0, pk0, D, S, in_lane, 0, lane);
+  for (int s0 = 0; s0 < S; s0 += 2 * CH) {
+    load_l0chunk<H, FT, CH>(c1, pk0, D, S, in_lane, s0 + CH, lane);
+    mul_l0chunk<H, FT, CH>(X, c0);
+    load_l0chunk<H, FT, CH>(c0, pk0, D, S, in_lane, s0 + 2 * CH, lane);
+    mul_l0chunk<H, FT, CH>(X, c1);
   }
 }
 
-// hidden -> hidden: Y += op(W) [H x H] * X ; pk = packed fragments (Fh_l for W, Th_l for W^T)
+// per-lane bias / last-layer weights in hidden order
+template <int H>
+struct HConst {
+  float c[Hid<H>::RT][4];
+};
+template <int H>
+__device__ __forceinline__ void load_hconst(HConst<H>& o, const float* __restrict__ v, int q) {
+#pragma unroll
+  for (int rt = 0; rt < Hid<H>::RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = hid_feature(rt, r, q);
+      const float x = v[f < H ? f : H - 1];   // unconditional load + select: no branch, no early wait
+      o.c[rt][r] = f < H ? x : 0.0f;
+    }
+}
 template <int H, int FT>
-__device__ __forceinline__ void hidden_apply(Vec<H, FT>& Y, const float* __restrict__ pk, const Vec<H, FT>& X, int lane) {
-  constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG;
-  float a[NG][RT];
+__device__ __forceinline__ void set_const(Vec<H, FT>& X, const HConst<H>& b) {
 #pragma unroll
-  for (int s = 0; s < NG; ++s)
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[s][rt] = pk[(s * RT + rt) * 64 + lane];
-#pragma unroll
-  for (int s = 0; s < NG; ++s)
+  for (int rt = 0; rt < Hid<H>::RT; ++rt)
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) Y.v[rt][ft] = mfma4(a[s][rt], X.v[s >> 2][ft][s & 3], Y.v[rt][ft]);
+      for (int r = 0; r < 4; ++r) X.v[rt][ft][r] = b.c[rt][r];
 }
 
 template <int H, int FT>
@@ -138,23 +238,47 @@ __device__ __forceinline__ void load_hid_const(const float* __restrict__ v, int 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = hid_feature(rt, r, q);
-      c[rt][r] = f < H ? v[f] : 0.0f;
+      const float x = v[f < H ? f : H - 1];
+      c[rt][r] = f < H ? x : 0.0f;
     }
 }
 
-// forward chain of one net: h[l] = tanh(W_l h_{l-1} + b_l)
-template <int H, int NH, int FT>
+// forward chain of one net: h[l] = tanh(W_l h_{l-1} + b_l).  All biases and the hidden layers' fragments are
+// requested before the first layer's MFMAs, so their latency is covered by that layer.
+// LEAN (register-starved callers): no cross-layer prefetch, smaller first-layer chunks.
+template <int H, int NH, int FT, bool LEAN = false>
 __device__ __forceinline__ void chain_forward(const cvf_mlp_desc& mlp, const float* __restrict__ theta,
                                               const float* __restrict__ pk, const PackLayout& L, int net,
                                               const float* __restrict__ in_lane, int lane, Vec<H, FT> (&h)[NH]) {
   const int q = lane >> 4;
-  init_bias<H, FT>(h[0], theta + mlp.b_off[net][0], q);
+  if constexpr (LEAN) {
+    init_bias<H, FT>(h[0], theta + mlp.b_off[net][0], q);
+    layer0_apply<H, FT, 3>(h[0], pk + L.f0(), mlp.dims[0], in_lane, lane);
+    tanh_inplace<H, FT>(h[0]);
+#pragma unroll
+    for (int l = 1; l < NH; ++l) {
+      init_bias<H, FT>(h[l], theta + mlp.b_off[net][l], q);
+      hidden_apply<H, FT>(h[l], pk + L.fh(l), h[l - 1], lane);
+      tanh_inplace<H, FT>(h[l]);
+    }
+    return;
+  }
+  HConst<H> bias[NH];
+#pragma unroll
+  for (int l = 0; l < NH; ++l) load_hconst<H>(bias[l], theta + mlp.b_off[net][l], q);
+  HFrag<H> hf[NH > 1 ? NH - 1 : 1];
+#pragma unroll
+  for (int l = 1; l < NH; ++l) load_hfrag<H>(hf[l - 1], pk + L.fh(l), lane);
+  CVF_STAMP(1);
+  set_const<H, FT>(h[0], bias[0]);
   layer0_apply<H, FT>(h[0], pk + L.f0(), mlp.dims[0], in_lane, lane);
+  CVF_STAMP(2);
   tanh_inplace<H, FT>(h[0]);
+  CVF_STAMP(3);
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
-    init_bias<H, FT>(h[l], theta + mlp.b_off[net][l], q);
-    hidden_apply<H, FT>(h[l], pk + L.fh(l), h[l - 1], lane);
+    set_const<H, FT>(h[l], bias[l]);
+    hidden_mul<H, FT>(h[l], hf[l - 1], h[l - 1]);
     tanh_inplace<H, FT>(h[l]);
   }
 }
@@ -186,12 +310,21 @@ __global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const
   const int fo = 4 * col + ft0;  // this lane's frames are fo .. fo+FT-1 of the tile
   const float* in_lane = feat + tile * (int64_t)D * CVF_TILE + fo;
 
+  CVF_STAMP(0);
   Vec<H, FT> h[NH];
   chain_forward<H, NH, FT>(mlp, theta, pk, L, net, in_lane, lane, h);
+  CVF_STAMP(4);
 
   float wl[RT][4];
   load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
   const float bL = theta[mlp.b_off[net][NH]];
+  // fragments of the d-chain (W_l^T) and the first chunk of W0^T are requested now: the output reduction,
+  // its cross-lane sums and the stores cover their latency
+  HFrag<H> tf[NH > 1 ? NH - 1 : 1];
+  if (g_tiled != nullptr) {
+#pragma unroll
+    for (int l = 1; l < NH; ++l) load_hfrag<H>(tf[l - 1], pk + L.th(l), lane);
+  }
   {
     float yv[FT];
 #pragma unroll
@@ -205,6 +338,7 @@ __global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const
     }
     if (q == 0) store_frames<FT>(y_tiled + (tile * k + net) * CVF_TILE + fo, yv);
   }
+  CVF_STAMP(5);
   if (g_tiled == nullptr) return;
 
   // d_{NH-1} = W_L .* (1 - h^2);  d_{l-1} = (W_l^T d_l) .* (1 - h_{l-1}^2)
@@ -222,7 +356,7 @@ __global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const
   for (int l = NH - 1; l >= 1; --l) {
     Vec<H, FT> e;
     init_bias<H, FT>(e, nullptr, q);
-    hidden_apply<H, FT>(e, pk + L.th(l), d, lane);
+    hidden_mul<H, FT>(e, tf[l - 1], d);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -233,19 +367,30 @@ __global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const
           d.v[rt][ft][r] = e.v[rt][ft][r] * (1.0f - hv * hv);
         }
   }
-  // g = W0^T d_0 : rows = input features in natural order, K = H
+  CVF_STAMP(6);
+  // g = W0^T d_0 : rows = input features in natural order, K = H; the fragments of row tile rt+1 load
+  // while row tile rt multiplies
   const float* pT0 = pk + L.t0();
   float* gout = g_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + fo;
   const int CT = (D + 15) >> 4;
+  float an[NG];
+#pragma unroll
+  for (int s = 0; s < NG; ++s) an[s] = pT0[s * 64 + lane];
   for (int rt = 0; rt < CT; ++rt) {
+    float ac[NG];
+#pragma unroll
+    for (int s = 0; s < NG; ++s) ac[s] = an[s];
+    if (rt + 1 < CT) {
+#pragma unroll
+      for (int s = 0; s < NG; ++s) an[s] = pT0[((rt + 1) * NG + s) * 64 + lane];
+    }
     f32x4 acc[FT];
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) acc[ft] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int s = 0; s < NG; ++s) {
-      const float a = pT0[(rt * NG + s) * 64 + lane];
 #pragma unroll
-      for (int ft = 0; ft < FT; ++ft) acc[ft] = mfma4(a, d.v[s >> 2][ft][s & 3], acc[ft]);
+      for (int ft = 0; ft < FT; ++ft) acc[ft] = mfma4(ac[s], d.v[s >> 2][ft][s & 3], acc[ft]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -258,6 +403,7 @@ __global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const
       }
     }
   }
+  CVF_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -271,89 +417,111 @@ struct EfBwdArgs {
   int64_t n_tiles;
 };
 
-template <int RT, int CT>
-__device__ __forceinline__ void mfma_outer(const float* __restrict__ A, const float* __restrict__ Bm, int lane,
-                                           f32x4 (&acc)[RT][CT]) {
+// One 16x16 tile of a weight gradient over the block's 64 frames:  A (rows 16*rt..) x B (rows 16*ct..),
+// operand images [feature][frame] with pitch kPitch.  All 16 k-steps are unrolled: 32-64 LDS reads in flight.
+__device__ __forceinline__ f32x4 outer_tile(const float* __restrict__ A1, const float* __restrict__ B1,
+                                            const float* __restrict__ A2, const float* __restrict__ B2, int rt, int ct,
+                                            bool two, int lane) {
   const int row = lane & 15, kq = lane >> 4;
-#pragma unroll 4
-  for (int s = 0; s < 16; ++s) {
-    float a[RT], b[CT];
+  const float* a1 = A1 + (16 * rt + row) * kPitch + kq;
+  const float* b1 = B1 + (16 * ct + row) * kPitch + kq;
+  const float* a2 = A2 + (16 * rt + row) * kPitch + kq;
+  const float* b2 = B2 + (16 * ct + row) * kPitch + kq;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[rt] = A[(16 * rt + row) * kPitch + 4 * s + kq];
+  for (int s = 0; s < 16; ++s) acc = mfma4(a1[4 * s], b1[4 * s], acc);
+  if (two) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) b[ct] = Bm[(16 * ct + row) * kPitch + 4 * s + kq];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = mfma4(a[rt], b[ct], acc[rt][ct]);
+    for (int s = 0; s < 16; ++s) acc = mfma4(a2[4 * s], b2[4 * s], acc);
   }
+  return acc;
 }
 
-// write a hidden vector (acc layout) as a [feature][frame] LDS image, optionally scaled per frame;
-// the lane's 4 frames 4*col..4*col+3 are contiguous: two 8-byte stores per feature
-template <int H, bool SCALE>
-__device__ __forceinline__ void store_image(float* S, const Vec<H, 4>& X, const float (&sc)[4], int lane) {
-  const int col = lane & 15, q = lane >> 4;
+// write a hidden vector (acc layout, this wave's FT frames per lane) into a [feature][frame] LDS image,
+// optionally scaled per frame; the lane's frames fo..fo+FT-1 are contiguous
+template <int H, int FT, bool SCALE>
+__device__ __forceinline__ void store_image(float* S, const Vec<H, FT>& X, const float (&sc)[FT], int lane, int fo) {
+  const int q = lane >> 4;
 #pragma unroll
   for (int rt = 0; rt < Hid<H>::RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = hid_feature(rt, r, q);
       if (4 * rt + r < Hid<H>::NG && f < H) {
-        float2* dst = reinterpret_cast<float2*>(S + f * kPitch + 4 * col);
-        if (SCALE) {
-          dst[0] = make_float2(sc[0] * X.v[rt][0][r], sc[1] * X.v[rt][1][r]);
-          dst[1] = make_float2(sc[2] * X.v[rt][2][r], sc[3] * X.v[rt][3][r]);
+        float v[FT];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) v[ft] = SCALE ? sc[ft] * X.v[rt][ft][r] : X.v[rt][ft][r];
+        float* dst = S + f * kPitch + fo;
+        if constexpr (FT == 4) {
+          reinterpret_cast<float2*>(dst)[0] = make_float2(v[0], v[1]);   // rows are 8-byte aligned (pitch 66)
+          reinterpret_cast<float2*>(dst)[1] = make_float2(v[2], v[3]);
+        } else if constexpr (FT == 2) {
+          *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
         } else {
-          dst[0] = make_float2(X.v[rt][0][r], X.v[rt][1][r]);
-          dst[1] = make_float2(X.v[rt][2][r], X.v[rt][3][r]);
+          dst[0] = v[0];
         }
       }
     }
 }
 
-template <int H, int NH>
-__global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp_desc mlp, const float* __restrict__ theta,
-                                                          const float* __restrict__ packed,
-                                                          const float* __restrict__ w, const float* __restrict__ w_lag,
-                                                          const float* __restrict__ feat, const float* __restrict__ y_tiled,
-                                                          const float* __restrict__ q_tiled, const double* __restrict__ coef,
-                                                          float* __restrict__ slab, int32_t* __restrict__ step) {
-  constexpr int FT = 4;
+// tdot = (1 - h^2) .* t
+template <int H, int FT>
+__device__ __forceinline__ void tangent_of(Vec<H, FT>& td, const Vec<H, FT>& h, const Vec<H, FT>& t) {
+#pragma unroll
+  for (int rt = 0; rt < Hid<H>::RT; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = h.v[rt][ft][r];
+        td.v[rt][ft][r] = (1.0f - hv * hv) * t.v[rt][ft][r];
+      }
+}
+
+// K4b.  Block = WPB waves sharing one 64-frame tile (and its LDS images); wave w owns the frames
+// 4*col + w*FT .. + FT-1 (FT = 4/WPB) for the register-resident chains, and every WPB-th 16x16 tile of
+// each weight-gradient product.  Splitting the tile over waves shortens each wave's dependent chain and
+// puts two waves on every SIMD, which is what hides the LDS / L2 latencies at small batch sizes.
+template <int H, int NH, int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp_desc mlp,
+                                                               const float* __restrict__ theta,
+                                                               const float* __restrict__ packed,
+                                                               const float* __restrict__ w, const float* __restrict__ w_lag,
+                                                               const float* __restrict__ feat,
+                                                               const float* __restrict__ y_tiled,
+                                                               const float* __restrict__ q_tiled,
+                                                               const double* __restrict__ coef, float* __restrict__ slab,
+                                                               int32_t* __restrict__ step) {
+  constexpr int FT = 4 / WPB;
   constexpr int RT = Hid<H>::RT;
   constexpr int RTO = (H + 15) / 16;      // row tiles of an H-row image (natural order)
   constexpr int CTH = (H + 1 + 15) / 16;  // column tiles of [h ; 1]
-  constexpr int RA = RTO * 16, RB = CTH * 16;
+  constexpr int NT = 64 * WPB;
   // Operand images, packed: an image owns H (A side) or H+1 (B side) rows; the MFMA reads up to the next
   // multiple of 16 rows, i.e. into the following image - finite values that only reach output rows/columns
   // which are discarded.  Keeps the block under 40 KiB of LDS (4 blocks per CU).
   constexpr int kRows = 2 * H + 2 * (H + 1) + 16;
   __shared__ float IMG[kRows * kPitch];
+  extern __shared__ float GI[];  // this block's partial gradient of `net` (flat parameter order)
   float* SA1 = IMG;
   float* SA2 = SA1 + H * kPitch;
   float* SB1 = SA2 + H * kPitch;
   float* SB2 = SB1 + (H + 1) * kPitch;
-  static_assert(RA <= H + 16 && RB <= H + 1 + 16, "image padding");
-  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, q = lane >> 4, row16 = col, r0 = 4 * q;
+  const int ft0 = wave * FT, fo = 4 * col + ft0;
   const int net = blockIdx.y;
   const int k = args.k;
   const int D = mlp.dims[0];
   const int CT1 = (D + 1 + 15) / 16;
   const bool tangent = args.lag_idx == 0;
-
-  for (int i = lane; i < kRows * kPitch; i += 64) IMG[i] = 0.0f;
-  __syncthreads();
-  SB1[H * kPitch + lane] = 1.0f;  // bias column of [h ; 1]  (row H of SB2 stays 0)
-
-  // this block's partial gradient of `net`, in the flat parameter order (the parameters of one net are
-  // contiguous), accumulated across the block's tiles in LDS: keeps ~100 accumulator registers free
-  extern __shared__ float GI[];
   const int gbase = mlp.w_off[net][0];
   const int gspan = mlp.b_off[net][NH] + 1 - gbase;
-  for (int i = lane; i < gspan; i += 64) GI[i] = 0.0f;
+
+  for (int i = tid; i < kRows * kPitch; i += NT) IMG[i] = 0.0f;
+  for (int i = tid; i < gspan; i += NT) GI[i] = 0.0f;
   __syncthreads();
-  const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-  const int row16 = lane & 15, r0 = 4 * (lane >> 4);
+  if (tid < 64) SB1[H * kPitch + tid] = 1.0f;  // bias column of [h ; 1]  (row H of SB2 stays 0)
 
   const double* gS1 = coef;
   const double* gS2 = coef + k;
@@ -365,18 +533,37 @@ __global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp
   load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
   const PackLayout L = pack_layout(H, NH, D);
   const float* pk = packed + (int64_t)net * L.per_net;
+  float one[FT];
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) one[ft] = 1.0f;
+
+  // add a finished 16x16 tile of layer `l` (rows = outputs, columns = inputs + bias) into the gradient image
+  auto add_tile = [&](int l, int n_out, int n_in, int rt, int ct, const f32x4& acc) {
+    const int wo = mlp.w_off[net][l] - gbase, bo = mlp.b_off[net][l] - gbase;
+    const int i = 16 * ct + row16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 16 * rt + r0 + r;
+      if (o < n_out) {
+        if (i < n_in) GI[wo + o * n_in + i] += acc[r];
+        else if (i == n_in) GI[bo + o] += acc[r];
+      }
+    }
+  };
 
   for (int64_t tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x) {
     const int pass = tile >= args.T ? 1 : 0;
     const int64_t t0 = pass ? tile - args.T : tile;
-    // ---- per-frame coefficients for the 4 frames this lane sees (col + 16 ft)
-    float alpha[4], gamma[4];
+    // ---- per-frame coefficients for the FT frames this lane owns
+    float alpha[FT], gamma[FT];
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-      const int64_t frame = t0 * CVF_TILE + 4 * col + ft;
+    for (int ft = 0; ft < FT; ++ft) {
+      const int64_t frame = t0 * CVF_TILE + fo + ft;
       const bool valid = frame < args.B;
-      const float wb = valid ? w[frame] : 0.0f;
-      const float* yb = y_tiled + t0 * k * CVF_TILE + 4 * col + ft;
+      const int64_t fc = valid ? frame : args.B - 1;
+      const float wraw = w[fc];
+      const float wb = valid ? wraw : 0.0f;
+      const float* yb = y_tiled + t0 * k * CVF_TILE + fo + ft;
       gamma[ft] = 0.0f;
       if (args.lag_idx == 0) {
         double a = gS1[net];
@@ -384,7 +571,7 @@ __global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp
         alpha[ft] = (float)((double)wb * a);
         gamma[ft] = (float)(2.0 * (double)wb * gEt[net]);
       } else {
-        const float* yl = y_tiled + (args.T + t0) * k * CVF_TILE + 4 * col + ft;
+        const float* yl = y_tiled + (args.T + t0) * k * CVF_TILE + fo + ft;
         const double diff = (double)yl[net * CVF_TILE] - (double)yb[net * CVF_TILE];
         const double tterm = 2.0 * (double)wb * gEt[net] * diff;
         if (pass == 0) {
@@ -392,7 +579,8 @@ __global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp
           for (int j = 0; j < k; ++j) a += (j == net ? 2.0 : 1.0) * gS2[net * k + j] * (double)yb[j * CVF_TILE];
           alpha[ft] = (float)((double)wb * a - tterm);
         } else {
-          const float wlg = valid ? w_lag[frame] : 0.0f;
+          const float wlraw = w_lag[fc];
+          const float wlg = valid ? wlraw : 0.0f;
           alpha[ft] = (float)((double)wlg * (gS1l[net] + 2.0 * gS2l[net] * (double)yl[net * CVF_TILE]) + tterm);
         }
       }
@@ -400,40 +588,32 @@ __global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp
     const float* f_tile = feat + tile * (int64_t)D * CVF_TILE;
     const float* q_tile = tangent ? q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE : nullptr;
 
-    // ---- chains (all in registers, MFMA)
+    // ---- chains (registers, MFMA) for this wave's frames
     Vec<H, FT> h[NH];
-    chain_forward<H, NH, FT>(mlp, theta, pk, L, net, f_tile + 4 * col, lane, h);
+    chain_forward<H, NH, FT, true>(mlp, theta, pk, L, net, f_tile + fo, lane, h);
     Vec<H, FT> e[NH > 1 ? NH - 1 : 1];  // e[l] = W_{l+1}^T d_{l+1}, l = 0..NH-2  (e_{NH-1} = W_L is the constant wl)
     Vec<H, FT> t[NH];                   // t[l] = W_l tdot_{l-1}
     if (tangent) {
-      // d-chain, keeping e_l
-      Vec<H, FT> d;
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float hv = h[NH - 1].v[rt][ft][r];
-            d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
-          }
-#pragma unroll
-      for (int l = NH - 1; l >= 1; --l) {
-        init_bias<H, FT>(e[l - 1], nullptr, q);
-        hidden_apply<H, FT>(e[l - 1], pk + L.th(l), d, lane);
+      {
+        Vec<H, FT> d;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float hv = h[l - 1].v[rt][ft][r];
-              d.v[rt][ft][r] = e[l - 1].v[rt][ft][r] * (1.0f - hv * hv);
+              const float hv = h[NH - 1].v[rt][ft][r];
+              d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
             }
+#pragma unroll
+        for (int l = NH - 1; l >= 1; --l) {
+          init_bias<H, FT>(e[l - 1], nullptr, q);
+          hidden_apply<H, FT>(e[l - 1], pk + L.th(l), d, lane);
+          tangent_of<H, FT>(d, h[l - 1], e[l - 1]);   // d_{l-1} = (1 - h^2) .* e_{l-1}
+        }
       }
-      // tangent chain
       init_bias<H, FT>(t[0], nullptr, q);
-      layer0_apply<H, FT>(t[0], pk + L.f0(), D, q_tile + 4 * col, lane);
+      layer0_apply<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -443,57 +623,35 @@ __global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp
 #pragma unroll
       for (int l = 1; l < NH; ++l) {
         Vec<H, FT> td;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float hv = h[l - 1].v[rt][ft][r];
-              td.v[rt][ft][r] = (1.0f - hv * hv) * t[l - 1].v[rt][ft][r];
-            }
+        tangent_of<H, FT>(td, h[l - 1], t[l - 1]);
         init_bias<H, FT>(t[l], nullptr, q);
         hidden_apply<H, FT>(t[l], pk + L.fh(l), td, lane);
       }
     }
 
     // ---- last layer (1 x H):  W_L += sum alpha h_{NH-1} + tdot_{NH-1} ; b_L += sum alpha
-    const float one4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     {
       if (q == 0) {
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-          SA1[4 * col + ft] = alpha[ft];
-          if (tangent) SA2[4 * col + ft] = 1.0f;
+        for (int ft = 0; ft < FT; ++ft) {
+          SA1[fo + ft] = alpha[ft];
+          if (tangent) SA2[fo + ft] = 1.0f;
         }
       }
-      store_image<H, false>(SB1, h[NH - 1], one4, lane);
+      store_image<H, FT, false>(SB1, h[NH - 1], one, lane, fo);
       if (tangent) {
         Vec<H, FT> td;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float hv = h[NH - 1].v[rt][ft][r];
-              td.v[rt][ft][r] = (1.0f - hv * hv) * t[NH - 1].v[rt][ft][r];
-            }
-        store_image<H, false>(SB2, td, one4, lane);
+        tangent_of<H, FT>(td, h[NH - 1], t[NH - 1]);
+        store_image<H, FT, false>(SB2, td, one, lane, fo);
       }
       __syncthreads();
-      f32x4 accL[1][CTH];
-#pragma unroll
-      for (int ct = 0; ct < CTH; ++ct) accL[0][ct] = zero4;
-      mfma_outer<1, CTH>(SA1, SB1, lane, accL);
-      if (tangent) mfma_outer<1, CTH>(SA2, SB2, lane, accL);
-      if (q == 0) {  // output row 0 lives in register 0 of lanes 0..15
-        const int wo = mlp.w_off[net][NH] - gbase, bo = mlp.b_off[net][NH] - gbase;
-#pragma unroll
-        for (int ct = 0; ct < CTH; ++ct) {
+      for (int ct = wave; ct < CTH; ct += WPB) {
+        const f32x4 acc = outer_tile(SA1, SB1, SA2, SB2, 0, ct, tangent, lane);
+        if (q == 0) {  // output row 0 lives in register 0 of lanes 0..15
+          const int wo = mlp.w_off[net][NH] - gbase, bo = mlp.b_off[net][NH] - gbase;
           const int i = 16 * ct + row16;
-          if (i < H) GI[wo + i] += accL[0][ct][0];
-          else if (i == H) GI[bo] += accL[0][ct][0];
+          if (i < H) GI[wo + i] += acc[0];
+          else if (i == H) GI[bo] += acc[0];
         }
       }
       __syncthreads();
@@ -526,85 +684,55 @@ __global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp
             }
             zbar.v[rt][ft][r] = om * hb;
           }
-      store_image<H, false>(SA1, zbar, one4, lane);
+      store_image<H, FT, false>(SA1, zbar, one, lane, fo);
       if (tangent) {
-        if (l == 0) store_image<H, true>(SA2, dl, gamma, lane);
-        else store_image<H, false>(SA2, dl, one4, lane);
+        if (l == 0) store_image<H, FT, true>(SA2, dl, gamma, lane, fo);
+        else store_image<H, FT, false>(SA2, dl, one, lane, fo);
       }
       if (l > 0) {
-        store_image<H, false>(SB1, h[l - 1], one4, lane);
+        store_image<H, FT, false>(SB1, h[l - 1], one, lane, fo);
         if (tangent) {
           Vec<H, FT> td;
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float hv = h[l - 1].v[rt][ft][r];
-                td.v[rt][ft][r] = (1.0f - hv * hv) * t[l - 1].v[rt][ft][r];
-              }
-          store_image<H, false>(SB2, td, one4, lane);
+          tangent_of<H, FT>(td, h[l - 1], t[l - 1]);
+          store_image<H, FT, false>(SB2, td, one, lane, fo);
         }
         __syncthreads();
-        {
-          f32x4 accH[RTO][CTH];
-#pragma unroll
-          for (int rt = 0; rt < RTO; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < CTH; ++ct) accH[rt][ct] = zero4;
-          mfma_outer<RTO, CTH>(SA1, SB1, lane, accH);
-          if (tangent) mfma_outer<RTO, CTH>(SA2, SB2, lane, accH);
-          const int wo = mlp.w_off[net][l] - gbase, bo = mlp.b_off[net][l] - gbase;
-#pragma unroll
-          for (int rt = 0; rt < RTO; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < CTH; ++ct) {
-              const int i = 16 * ct + row16;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int o = 16 * rt + r0 + r;
-                if (o < H) {
-                  if (i < H) GI[wo + o * H + i] += accH[rt][ct][r];
-                  else if (i == H) GI[bo + o] += accH[rt][ct][r];
-                }
-              }
-            }
+        for (int pr = wave; pr < RTO * CTH; pr += WPB) {
+          const int rt = pr / CTH, ct = pr - rt * CTH;
+          add_tile(l, H, H, rt, ct, outer_tile(SA1, SB1, SA2, SB2, rt, ct, tangent, lane));
         }
-        __syncthreads();
-        // hbar_{l-1} = W_l^T zbar_l
+        // hbar_{l-1} = W_l^T zbar_l  (registers; overlaps the other wave's outer products)
         init_bias<H, FT>(hbar, nullptr, q);
         hidden_apply<H, FT>(hbar, pk + L.th(l), zbar, lane);
+        __syncthreads();
       } else {
         __syncthreads();
-        const int wo = mlp.w_off[net][0] - gbase, bo = mlp.b_off[net][0] - gbase;
-        for (int ct = 0; ct < CT1; ++ct) {
+        // first layer: the B operands are the feature tile (+ ones row) and q, read straight from global
+        // memory in operand order (the tile was just streamed by the chains: L2 hits), 16 loads in flight
+        for (int pr = wave; pr < RTO * CT1; pr += WPB) {
+          const int rt = pr / CT1, ct = pr - rt * CT1;
           const int i = 16 * ct + row16;
-          f32x4 acc[RTO];
+          const float* a1 = SA1 + (16 * rt + row16) * kPitch + q;
+          const float* a2 = SA2 + (16 * rt + row16) * kPitch + q;
+          // (no MFMA under lane-divergent control flow: operand values are selected per lane, the MFMAs are uniform)
+          const int ic = i < D ? i : D - 1;
+          const float* fb = f_tile + (int64_t)ic * CVF_TILE + q;
+          const float pad1 = i == D ? 1.0f : 0.0f;   // bias column; columns past it stay 0
+          float b1[16];
 #pragma unroll
-          for (int rt = 0; rt < RTO; ++rt) acc[rt] = zero4;
-#pragma unroll 4
-          for (int s = 0; s < 16; ++s) {
-            const int fr = 4 * s + q;
-            const float b1 = i < D ? f_tile[(int64_t)i * CVF_TILE + fr] : (i == D ? 1.0f : 0.0f);
+          for (int s = 0; s < 16; ++s) b1[s] = fb[4 * s];
+          f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int rt = 0; rt < RTO; ++rt) acc[rt] = mfma4(SA1[(16 * rt + row16) * kPitch + fr], b1, acc[rt]);
-            if (tangent) {
-              const float b2 = i < D ? q_tile[(int64_t)i * CVF_TILE + fr] : 0.0f;
+          for (int s = 0; s < 16; ++s) acc = mfma4(a1[4 * s], i < D ? b1[s] : pad1, acc);
+          if (tangent) {
+            const float* qb = q_tile + (int64_t)ic * CVF_TILE + q;
+            float b2[16];
 #pragma unroll
-              for (int rt = 0; rt < RTO; ++rt) acc[rt] = mfma4(SA2[(16 * rt + row16) * kPitch + fr], b2, acc[rt]);
-            }
+            for (int s = 0; s < 16; ++s) b2[s] = qb[4 * s];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = mfma4(a2[4 * s], i < D ? b2[s] : 0.0f, acc);
           }
-#pragma unroll
-          for (int rt = 0; rt < RTO; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int o = 16 * rt + r0 + r;
-              if (o < H) {
-                if (i < D) GI[wo + o * D + i] += acc[rt][r];
-                else if (i == D) GI[bo + o] += acc[rt][r];
-              }
-            }
+          add_tile(0, H, D, rt, ct, acc);
         }
         __syncthreads();
       }
@@ -614,9 +742,9 @@ __global__ __launch_bounds__(64) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp
   // ---- flush this block's partial gradient of `net` into its slab row
   __syncthreads();
   float* out = slab + (int64_t)blockIdx.x * mlp.n_params + gbase;
-  for (int i = lane; i < gspan; i += 64) out[i] = GI[i];
+  for (int i = tid; i < gspan; i += NT) out[i] = GI[i];
   // one gradient per optimiser step: advance the step counter read by the Adam that follows
-  if (step != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) *step += 1;
+  if (step != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *step += 1;
 }
 
 // grad[p] = sum over slab rows, fixed order: 16 row groups (strided) per parameter, then the 16
@@ -708,7 +836,8 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
               "cvf_ef_mlp_fwd: nets must be d0->H->..->H->1 with tanh between layers (got %d layers)", mlp->n_layers);
   CVF_REQUIRE(mlp->n_nets >= 1 && mlp->n_nets <= CVF_MAX_NETS, "cvf_ef_mlp_fwd: k=%d out of range", mlp->n_nets);
   // few tiles: split each 64-frame tile over two waves so that the launch still fills the 1024 SIMDs
-  const bool split = n_tiles * mlp->n_nets < 2048;
+  bool split = n_tiles * mlp->n_nets < 2048;
+  if (getenv("CVF_FWD_SPLIT")) split = atoi(getenv("CVF_FWD_SPLIT")) != 0;   // developer override
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
     if (split)
@@ -756,8 +885,8 @@ extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, c
   const size_t lds_dyn = (size_t)span * sizeof(float);
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH>), grid, dim3(64), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed, w,
-                       w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count);
+    hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed,
+                       w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count);
   });
   CVF_REQUIRE(launched, "cvf_ef_backward: no kernel instance for hidden width %d x %d layers", H, NH);
   return cvf_check_launch("ef_bwd_mfma_kernel");

@@ -49,7 +49,7 @@ __device__ __forceinline__ void align_lane(const cvf_pp_desc& pp, const Tables& 
     cy += (double)my[3 * a + 1];
     cz += (double)my[3 * a + 2];
   }
-  const double inv = 1.0 / (double)pp.n_align;
+  const double inv = fast_rcp((double)pp.n_align);
   c[0] = cx * inv;
   c[1] = cy * inv;
   c[2] = cz * inv;

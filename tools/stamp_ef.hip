@@ -1,0 +1,52 @@
+// Developer tool (not part of the library): phase timing of ef_fwd_mfma_kernel with s_memtime stamps.
+// Build+run on the GPU box:  hipcc -O3 --offload-arch=gfx950 -DCVF_STAMPS -Iinclude -Icolvars-finder_amd/csrc \
+//     tools/stamp_ef.hip colvars-finder_amd/csrc/stats.hip -o /tmp/stamp_ef && /tmp/stamp_ef
+#include "../colvars-finder_amd/csrc/ef_mfma.hip"
+#include <cstdio>
+#include <vector>
+#include <random>
+
+int main() {
+  const int k = 3, D = 66, H = 20, NHl = 3, B = 20000;
+  const int64_t T = (B + 63) / 64;
+  cvf_mlp_desc m = {};
+  m.n_nets = k; m.n_layers = NHl + 1;
+  int dims[5] = {D, H, H, H, 1};
+  for (int i = 0; i < 5; ++i) m.dims[i] = dims[i];
+  int pos = 0;
+  for (int n = 0; n < k; ++n)
+    for (int l = 0; l < 4; ++l) {
+      m.act[l] = l < 3;
+      m.w_off[n][l] = pos; pos += dims[l] * dims[l + 1];
+      m.b_off[n][l] = pos; pos += dims[l + 1];
+    }
+  m.n_params = pos;
+  std::mt19937 rng(1);
+  std::uniform_real_distribution<float> U(-0.2f, 0.2f);
+  std::vector<float> theta(pos), feat(T * D * 64);
+  for (auto& v : theta) v = U(rng);
+  for (auto& v : feat) v = 5 * U(rng);
+  float *dth, *dpk, *dfeat, *dy, *dg;
+  hipMalloc(&dth, pos * 4); hipMalloc(&dpk, cvf_ef_pack_floats(&m) * 4); hipMalloc(&dfeat, feat.size() * 4);
+  hipMalloc(&dy, T * k * 64 * 4); hipMalloc(&dg, T * k * D * 64 * 4);
+  hipMemcpy(dth, theta.data(), pos * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dfeat, feat.data(), feat.size() * 4, hipMemcpyHostToDevice);
+  cvf_ef_pack(&m, dth, dpk, nullptr);
+  for (int it = 0; it < 5; ++it) cvf_ef_mlp_fwd(&m, dth, dpk, dfeat, T, dy, dg, nullptr);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> st(64 * 4096);
+  hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+  const char* names[8] = {"start", "prefetch issued", "layer0 done", "tanh0 done", "chain done", "y done", "dchain done", "g done"};
+  double acc[8] = {0};
+  int n = 0;
+  for (int b = 0; b < 1252 && b < 4096; ++b) {
+    const unsigned long long* s = &st[b * 64];
+    if (s[7] == 0) continue;
+    for (int i = 1; i < 8; ++i) acc[i] += double(s[i] - s[i - 1]);
+    ++n;
+  }
+  double tot = 0;
+  for (int i = 1; i < 8; ++i) { printf("%-18s %9.0f cycles\n", names[i], acc[i] / n); tot += acc[i] / n; }
+  printf("total %9.0f cycles over %d waves\n", tot, n);
+  return 0;
+}
