@@ -26,7 +26,9 @@ LIB_PATH = os.path.join(_HERE, "libcvf_hip.so")
 class PPDesc(C.Structure):
     _fields_ = [("mode", C.c_int32), ("n_coord", C.c_int32), ("n_align", C.c_int32), ("n_rec", C.c_int32),
                 ("d_r", C.c_int32), ("use_angle_value", C.c_int32), ("has_position", C.c_int32), ("flags", C.c_int32),
-                ("align_idx", C.c_void_p), ("ref_c", C.c_void_p), ("rec", C.c_void_p)]
+                ("align_idx", C.c_void_p), ("ref_c", C.c_void_p), ("rec", C.c_void_p),
+                ("atom_align", C.c_void_p), ("atom_slot", C.c_void_p), ("rec_slot", C.c_void_p), ("n_slot", C.c_int32),
+                ("pad2_", C.c_int32)]
 
 
 class MLPDesc(C.Structure):
@@ -50,8 +52,9 @@ _SIGNATURES = {
     "cvf_version": (C.c_int, []),
     "cvf_last_error": (C.c_char_p, []),
     "cvf_ef_nstats": (C.c_int, [C.c_int, C.c_int]),
+    "cvf_align_feature_scratch_bytes": (C.c_int64, [C.POINTER(PPDesc), C.c_int64]),
     "cvf_align_feature_fwd": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p]),
+                                        C.c_void_p, C.c_void_p]),
     "cvf_metric_apply": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_pack_floats": (C.c_int64, [C.POINTER(MLPDesc)]),
@@ -113,6 +116,12 @@ def ptr(t):
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def align_scratch(desc, B, device):
+    """Scratch buffer cvf_align_feature_fwd needs for B frames (None for small molecules)."""
+    n = lib().cvf_align_feature_scratch_bytes(desc, B)
+    return torch.empty((n + 7) // 8, device=device, dtype=torch.float64) if n > 0 else None
 
 
 def ntiles(B):

@@ -285,6 +285,7 @@ class _EFWorkspace:
         self.stats = torch.empty(lib.cvf_ef_nstats(k, lag), **f64)
         self.loss_vec = torch.empty(3 + 2 * k, **f64)
         self.coef = torch.empty(4 * k + k * k, **f64)
+        self.k1_scratch, self.k1_scratch_checked = None, False   # large-molecule alignment scratch, sized on first use
         self.slab_rows = lib.cvf_ef_backward_slab_rows(Tt)
         self.slab = torch.empty(self.slab_rows * n_params, **f32)
 
@@ -379,10 +380,14 @@ class EigenFunctionTask(TrainingTask):
         ws = self._workspace(B)
         fl, k, d_r = self._flat, self.k, self._pp.d_r
         lag = self.lag_idx
-        self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X), B, P(ws.feat), None, P(ws.aux), s)
+        if ws.k1_scratch is None and not ws.k1_scratch_checked:
+            ws.k1_scratch, ws.k1_scratch_checked = _hip.align_scratch(self._pp, B, self.device), True
+        self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X), B, P(ws.feat), None, P(ws.aux),
+                   P(ws.k1_scratch), s)
         if lag > 0:
             feat_lag = ws.feat[ws.T * d_r * _hip.TILE:]
-            self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X_lag), B, P(feat_lag), None, None, s)
+            self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X_lag), B, P(feat_lag), None, None,
+                       P(ws.k1_scratch), s)
         self._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(ws.y),
                    P(ws.g) if lag == 0 else None, s)
         if lag == 0:
@@ -581,7 +586,8 @@ class AutoEncoderTask(TrainingTask):
         n = X.shape[0]
         self._feature_traj = torch.empty(n, pp.d_r, device=self.device, dtype=torch.float32)       # core.py:635
         _hip.check(_hip.lib().cvf_align_feature_fwd(pp, _hip.ptr(X), n, None, _hip.ptr(self._feature_traj), None,
-                                                    _hip.stream()), "cvf_align_feature_fwd")
+                                                    _hip.ptr(_hip.align_scratch(pp, n, self.device)), _hip.stream()),
+                   "cvf_align_feature_fwd")
         assert pp.d_r == self._flat.desc.dims[0] == self._flat.desc.dims[self._flat.desc.n_layers], \
             'autoencoder input/output width must equal the feature dimension'
         if self.verbose:

@@ -88,6 +88,22 @@ class AlignFeatureLayer(torch.nn.Module):
         if all(r[0] == _hip.FEAT_POSITION and r[1] == i and r[5] == 3 * i for i, r in enumerate(rec)):
             flags |= _hip.PP_PURE_POSITION
         self._flags = flags
+        # per-atom tables for the streaming kernel of large molecules (include/cvf.h): which ref row an atom aligns
+        # to, and the compact "slot" of every atom some feature reads
+        atom_align = np.full(n_atoms, -1, dtype=np.int32)
+        atom_align[align_idx] = np.arange(len(align_idx), dtype=np.int32)
+        used = sorted({int(a) for r in rec for a in (r[1:2] if r[0] == _hip.FEAT_POSITION else
+                                                      r[1:1 + _TYPE_NATOMS[{v: k_ for k_, v in _TYPE_ID.items()}[r[0]]]])})
+        atom_slot = np.full(n_atoms, -1, dtype=np.int32)
+        atom_slot[used] = np.arange(len(used), dtype=np.int32)
+        rec_slot = []
+        for r in rec:
+            na = 1 if r[0] == _hip.FEAT_POSITION else _TYPE_NATOMS[{v: k_ for k_, v in _TYPE_ID.items()}[r[0]]]
+            rec_slot.append([r[0]] + [int(atom_slot[a]) for a in r[1:1 + na]] + [0] * (4 - na) + [r[5]])
+        self._n_slot = len(used)
+        self.register_buffer("atom_align", torch.tensor(atom_align))
+        self.register_buffer("atom_slot", torch.tensor(atom_slot))
+        self.register_buffer("rec_slot", torch.tensor(rec_slot, dtype=torch.int32).reshape(-1, 6))
         self.register_buffer("align_idx", torch.tensor(align_idx, dtype=torch.int32))
         self.register_buffer("ref_c", torch.tensor(ref - ref.mean(axis=0, keepdims=True), dtype=torch.float32))
         self.register_buffer("rec", torch.tensor(rec, dtype=torch.int32).reshape(-1, 6))
@@ -100,6 +116,8 @@ class AlignFeatureLayer(torch.nn.Module):
         d.has_position = int(bool((self.rec[:, 0] == _hip.FEAT_POSITION).any().item()))
         d.flags = self._flags
         d.align_idx, d.ref_c, d.rec = self.align_idx.data_ptr(), self.ref_c.data_ptr(), self.rec.data_ptr()
+        d.atom_align, d.atom_slot, d.rec_slot = self.atom_align.data_ptr(), self.atom_slot.data_ptr(), self.rec_slot.data_ptr()
+        d.n_slot = self._n_slot
         return d
 
     def forward(self, x):
@@ -117,8 +135,9 @@ class AlignFeatureLayer(torch.nn.Module):
         if B == 0:
             return out
         desc = self.pp_desc()
-        _hip.check(_hip.lib().cvf_align_feature_fwd(desc, _hip.ptr(x), B, None, _hip.ptr(out), None, _hip.stream()),
-                   "cvf_align_feature_fwd")
+        scratch = _hip.align_scratch(desc, B, x.device)
+        _hip.check(_hip.lib().cvf_align_feature_fwd(desc, _hip.ptr(x), B, None, _hip.ptr(out), None, _hip.ptr(scratch),
+                                                    _hip.stream()), "cvf_align_feature_fwd")
         return out
 
 

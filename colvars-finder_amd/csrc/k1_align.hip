@@ -451,8 +451,20 @@ __global__ __launch_bounds__(64) void metric_identity_kernel(int d, const float*
 
 }  // namespace
 
+int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
+                        float* aux_tiled, double* sums, hipStream_t s);
+size_t cvf_k1_large_scratch_bytes(int64_t B);
+
+// frames larger than this use the streaming workgroup-per-frame kernel (k1_large.hip)
+static constexpr int kLanePerFrameMaxCoord = 192;
+
+extern "C" int64_t cvf_align_feature_scratch_bytes(const cvf_pp_desc* pp, int64_t B) {
+  if (!pp || pp->mode != CVF_PP_ALIGN || pp->n_coord <= kLanePerFrameMaxCoord) return 0;
+  return (int64_t)cvf_k1_large_scratch_bytes(B);
+}
+
 extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled,
-                                     float* feat_rows, float* aux_tiled, void* stream) {
+                                     float* feat_rows, float* aux_tiled, void* scratch, void* stream) {
   CVF_REQUIRE(pp && x && B > 0, "cvf_align_feature_fwd: null argument or empty batch (B=%lld)", (long long)B);
   CVF_REQUIRE(feat_tiled || feat_rows, "cvf_align_feature_fwd: no output buffer");
   const int64_t T = cvf_ntiles(B);
@@ -465,6 +477,12 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
   CVF_REQUIRE(pp->mode == CVF_PP_ALIGN, "unknown pp mode %d", pp->mode);
   CVF_REQUIRE(pp->n_coord % 3 == 0 && pp->n_align >= 3 && pp->align_idx && pp->ref_c && pp->rec,
               "cvf_align_feature_fwd: malformed descriptor (n_coord=%d n_align=%d)", pp->n_coord, pp->n_align);
+  if (pp->n_coord > kLanePerFrameMaxCoord) {
+    CVF_REQUIRE(scratch != nullptr || cvf_k1_large_scratch_bytes(B) == 0,
+                "cvf_align_feature_fwd: frames of %d coordinates need the scratch buffer (cvf_align_feature_scratch_bytes)",
+                pp->n_coord);
+    return cvf_k1_large_launch(pp, x, B, feat_tiled, feat_rows, aux_tiled, (double*)scratch, s);
+  }
   const size_t lds = ((size_t)CVF_TILE * x_tile_stride(pp->n_coord) + tables_dwords(*pp)) * sizeof(float);
   CVF_REQUIRE(lds <= 160 * 1024, "frames of %d coordinates do not fit the lane-per-frame kernel's LDS tile", pp->n_coord);
   if (lds > 48 * 1024) {

@@ -58,6 +58,13 @@ typedef struct cvf_pp_desc {
   const float* ref_c;       /* [n_align*3] reference positions minus their centroid */
   const int32_t* rec;       /* [n_rec*6]: type, a0, a1, a2, a3, out_offset (one record per
                                position ATOM: a0 = atom, 3 outputs) */
+  /* optional (large molecules): per-atom tables that let the streaming kernel copy the atoms the features
+   * use ("slots") to LDS while the frame goes by, instead of gathering them from HBM afterwards */
+  const int32_t* atom_align; /* [N]: index b of the atom in align_idx / ref_c, or -1 */
+  const int32_t* atom_slot;  /* [N] (16-byte aligned): slot of the atom, or -1 when no feature uses it */
+  const int32_t* rec_slot;   /* [n_rec*6]: rec with the atom fields replaced by slots */
+  int32_t n_slot;
+  int32_t pad2_;
 } cvf_pp_desc;
 
 /* k identical feed-forward nets (colvarsfinder.nn.EigenFunctions, nn.py:242-293) or one
@@ -112,9 +119,12 @@ const char* cvf_last_error(void);
 
 /* --- K1: alignment + features, forward.  Replaces pp_layer(X) at core.py:403,414,635.
  * x [B, n_coord] row-major fp32.  feat_tiled [T][d_r][64] and/or feat_rows [B][d_r]
- * (either may be NULL); aux_tiled [T][18][64] (may be NULL; identity mode ignores it). */
+ * (either may be NULL); aux_tiled [T][18][64] (may be NULL; identity mode ignores it).
+ * Frames of thousands of atoms take the streaming path (one wave per frame, 16 frames per workgroup).
+ * `scratch`: cvf_align_feature_scratch_bytes() bytes, 8-byte aligned (currently 0 for every path: may be NULL). */
+int64_t cvf_align_feature_scratch_bytes(const cvf_pp_desc* pp, int64_t B); /* 0 for small molecules */
 int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
-                          float* aux_tiled, void* stream);
+                          float* aux_tiled, void* scratch, void* stream);
 
 /* --- K2+K3: per frame and net, q = J A J^T g and E = g^T J A J^T g with J the Jacobian
  * of r at the frame and A = diag(a).  Replaces the k autograd.grad calls through

@@ -256,3 +256,46 @@ def test_fused_adam_matches_torch(dev):
     np.testing.assert_allclose(st["alone"]["theta"].cpu().numpy(), want, rtol=2e-6, atol=2e-7)
     np.testing.assert_allclose(st["fused"]["theta"].cpu().numpy(), want, rtol=2e-6, atol=2e-7)
     assert torch.equal(st["alone"]["theta"], st["fused"]["theta"])
+
+
+# ------------------------------------------------------------------------------------------------ large molecules
+def _large_spec(n_atoms, rs):
+    pos_atoms = tuple(int(i) for i in rs.choice(n_atoms, 12, replace=False))
+    feats = [("position", pos_atoms)]
+    for _ in range(20):
+        feats.append(("dihedral", tuple(int(i) for i in rs.choice(n_atoms, 4, replace=False))))
+    for _ in range(15):
+        feats.append(("bond", tuple(int(i) for i in rs.choice(n_atoms, 2, replace=False))))
+    for _ in range(5):
+        feats.append(("angle", tuple(int(i) for i in rs.choice(n_atoms, 3, replace=False))))
+    return feats
+
+
+@pytest.mark.parametrize("n_atoms,B,contig", [(257, 70, True), (257, 33, False), (1200, 130, True)])
+def test_k1_streaming_kernel_vs_oracle(dev, n_atoms, B, contig):
+    """frames too large for the lane-per-frame tile go through the workgroup-per-frame streaming kernel"""
+    traj, _, ref = make_molecule_traj(n_atoms, B, seed=900 + n_atoms, scale=8.0, sigma=0.4)
+    rs = np.random.RandomState(n_atoms + B)
+    align = list(range(n_atoms)) if contig else sorted(int(i) for i in rs.choice(n_atoms, n_atoms // 2, replace=False))
+    spec = dict(align_idx=align, ref_pos=ref[align], features=_large_spec(n_atoms, rs), use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    got = layer(torch.tensor(traj, device=dev)).cpu().numpy()
+    torch.set_default_dtype(torch.float64)
+    want = oracle_layer(spec)(torch.tensor(traj, dtype=torch.float64)).numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=3e-6 * np.abs(want).max())
+    # tiled output + aux through the C ABI: same numbers, every lane of the last tile finite
+    from colvarsfinder import _hip
+    T = _hip.ntiles(B)
+    x = torch.tensor(traj, device=dev).contiguous()
+    tiled = torch.full((T * layer.d_r * 64,), float("nan"), device=dev, dtype=torch.float32)
+    aux = torch.full((T * 18 * 64,), float("nan"), device=dev, dtype=torch.float32)
+    desc = layer.pp_desc()
+    scratch = _hip.align_scratch(desc, B, dev)   # None when the path needs none
+    _hip.check(_hip.lib().cvf_align_feature_fwd(desc, _hip.ptr(x), B, _hip.ptr(tiled), None, _hip.ptr(aux), _hip.ptr(scratch),
+                                                _hip.stream()), "k1")
+    assert torch.isfinite(tiled).all() and torch.isfinite(aux).all()
+    rows = tiled.view(T, layer.d_r, 64).permute(0, 2, 1).reshape(T * 64, layer.d_r)[:B].cpu().numpy()
+    np.testing.assert_allclose(rows, got, rtol=0, atol=0)
+    R = aux.view(T, 18, 64)[:, :9, :].permute(0, 2, 1).reshape(T * 64, 3, 3)[:B].cpu().numpy()
+    np.testing.assert_allclose(R @ R.transpose(0, 2, 1), np.broadcast_to(np.eye(3), (B, 3, 3)), atol=5e-6)
+    np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=5e-6)
