@@ -169,3 +169,41 @@ def test_molann_style_constructors_build_the_descriptor():
         pp.FeatureLayer([pp.Feature("b", "bond", _AtomGroup([1, 2]))], input_ag)   # atom 2 not in the input group
     with pytest.raises(RuntimeError):
         layer(torch.zeros(2, 10, 3))                                                # CPU tensor: no fallback
+
+
+def test_utils_match_reference_files(tmp_path):
+    """colvarsfinder.utils twin vs the files the reference's utils.py wrote (fixture utils_2d.npz):
+    same RNG consumption, byte-identical traj.txt / output.csv / weights.txt, same filtered trajectory."""
+    import contextlib
+    import io
+    from colvarsfinder import utils
+    g = np.load(goldens.GOLDEN + "/utils_2d.npz")
+
+    class Pot:
+        dim, beta = 2, 1.5
+
+        def V(self, x):
+            return (x[0] ** 2 - 1) ** 2 + 2.0 * x[1] ** 2
+
+        def gradV(self, x):
+            return np.array([4 * x[0] * (x[0] ** 2 - 1), 4.0 * x[1]])
+
+    tmp = str(tmp_path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        np.random.seed(77)
+        utils.integrate_sde_overdamped(Pot(), 3000, tmp, pre_steps=50, step_size=0.01, report_interval=10,
+                                       report_interval_stdout=1000)
+        assert np.random.rand() == float(g["rng_after"])
+        utils.calc_weights(os.path.join(tmp, "output.csv"), 1.5, 1.0, traj_weight_filename=os.path.join(tmp, "weights.txt"))
+        t = utils.WeightedTrajectory(traj_filename=os.path.join(tmp, "traj.txt"), weight_filename=os.path.join(tmp, "weights.txt"),
+                                     min_w=0.2, max_w=3.0, verbose=False)
+    assert open(os.path.join(tmp, "traj.txt")).read() == str(g["traj_txt"])
+    assert open(os.path.join(tmp, "output.csv")).read() == str(g["csv_txt"])
+    assert open(os.path.join(tmp, "weights.txt")).read() == str(g["w_txt"])
+    np.testing.assert_array_equal(t.trajectory, g["wt_traj"])
+    np.testing.assert_allclose(t.weights, g["wt_weights"], rtol=1e-15)
+    assert t.dt == float(g["wt_dt"]) and t.n_frames == int(g["wt_n_frames"])
+    with pytest.raises(FileNotFoundError):
+        utils.WeightedTrajectory(traj_filename=os.path.join(tmp, "nope.txt"))
+    with pytest.raises(NotImplementedError):
+        utils.integrate_md_langevin()

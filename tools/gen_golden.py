@@ -271,11 +271,47 @@ def run_nn_structure(rnn):
     print("  nn_structure: ef params", out["ef_nparams"], "ae params", out["ae_nparams"])
 
 
+def run_utils():
+    """G6: integrate_sde_overdamped / calc_weights / WeightedTrajectory(text) of the reference (utils.py:62-169,257-417)."""
+    import contextlib
+    import io
+    import colvarsfinder.utils as rutils
+    assert rutils.__file__.startswith(REF)
+
+    class Pot:
+        dim, beta = 2, 1.5
+
+        def V(self, x):
+            return (x[0] ** 2 - 1) ** 2 + 2.0 * x[1] ** 2
+
+        def gradV(self, x):
+            return np.array([4 * x[0] * (x[0] ** 2 - 1), 4.0 * x[1]])
+
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+        np.random.seed(77)
+        rutils.integrate_sde_overdamped(Pot(), 3000, tmp, pre_steps=50, step_size=0.01, report_interval=10,
+                                        report_interval_stdout=1000)
+        after = np.random.rand()
+        rutils.calc_weights(os.path.join(tmp, "output.csv"), 1.5, 1.0, traj_weight_filename=os.path.join(tmp, "weights.txt"))
+        traj_txt = open(os.path.join(tmp, "traj.txt")).read()
+        csv_txt = open(os.path.join(tmp, "output.csv")).read()
+        w_txt = open(os.path.join(tmp, "weights.txt")).read()
+        t = rutils.WeightedTrajectory(traj_filename=os.path.join(tmp, "traj.txt"),
+                                      weight_filename=os.path.join(tmp, "weights.txt"), min_w=0.2, max_w=3.0, verbose=False)
+    np.savez_compressed(os.path.join(OUT, "utils_2d.npz"), traj_txt=np.asarray(traj_txt), csv_txt=np.asarray(csv_txt),
+                        w_txt=np.asarray(w_txt), rng_after=after, wt_traj=t.trajectory, wt_weights=t.weights, wt_dt=t.dt,
+                        wt_n_frames=t.n_frames)
+    print("  utils_2d:", t.trajectory.shape, "kept of", t.n_frames)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     core, rnn = import_reference()
     print("reference imported from", core.__file__)
     run_nn_structure(rnn)
+    run_utils()
+    if "--utils-only" in sys.argv:
+        return
 
     t2, w2 = make_2d_traj(600, seed=11)
     id2 = dict(pp="identity", traj=t2, w=w2)
