@@ -27,7 +27,7 @@ class PPDesc(C.Structure):
     _fields_ = [("mode", C.c_int32), ("n_coord", C.c_int32), ("n_align", C.c_int32), ("n_rec", C.c_int32),
                 ("d_r", C.c_int32), ("use_angle_value", C.c_int32), ("has_position", C.c_int32), ("flags", C.c_int32),
                 ("align_idx", C.c_void_p), ("ref_c", C.c_void_p), ("rec", C.c_void_p),
-                ("atom_align", C.c_void_p), ("atom_slot", C.c_void_p), ("rec_slot", C.c_void_p), ("n_slot", C.c_int32),
+                ("atom_align", C.c_void_p), ("atom_slot", C.c_void_p), ("rec_slot", C.c_void_p), ("slot_atom", C.c_void_p), ("n_slot", C.c_int32),
                 ("pad2_", C.c_int32)]
 
 
@@ -56,7 +56,8 @@ _SIGNATURES = {
     "cvf_align_feature_fwd": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
     "cvf_metric_apply": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_metric_dense_tensors": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_pack_floats": (C.c_int64, [C.POINTER(MLPDesc)]),
     "cvf_ef_pack": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_mlp_fwd": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

@@ -345,6 +345,12 @@ class EigenFunctionTask(TrainingTask):
         for i in range(k):
             cfg.eig_w[i] = float(eig_weights[i])
         self._cfg = cfg
+        # large molecules (streaming alignment path): moments of (diag_coeff, reference) used by the derivative kernel
+        self._dense = None
+        if self.lag_idx == 0 and _hip.lib().cvf_align_feature_scratch_bytes(self._pp, 64) > 0:
+            self._dense = torch.zeros(42, device=self.device, dtype=torch.float64)
+            _hip.check(_hip.lib().cvf_metric_dense_tensors(self._pp, _hip.ptr(self._diag_coeff), _hip.ptr(self._dense),
+                                                           _hip.stream()), "cvf_metric_dense_tensors")
         self._ws = {}
         self._graphs = {}
         # whole-step hipGraph replay (single process; CVF_GRAPH=0 turns it off)
@@ -392,7 +398,7 @@ class EigenFunctionTask(TrainingTask):
                    P(ws.g) if lag == 0 else None, s)
         if lag == 0:
             self._call("cvf_metric_apply", lib.cvf_metric_apply, self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), k,
-                       P(ws.g), P(ws.q), P(ws.e), s)
+                       P(ws.g), P(ws.q), P(ws.e), P(ws.k1_scratch), P(self._dense), s)
         single = _dist.world() == 1   # no cross-rank reduction: the loss tail runs inside the stats launch
         lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
         if lag == 0:

@@ -104,6 +104,7 @@ class AlignFeatureLayer(torch.nn.Module):
         self.register_buffer("atom_align", torch.tensor(atom_align))
         self.register_buffer("atom_slot", torch.tensor(atom_slot))
         self.register_buffer("rec_slot", torch.tensor(rec_slot, dtype=torch.int32).reshape(-1, 6))
+        self.register_buffer("slot_atom", torch.tensor(used, dtype=torch.int32))
         self.register_buffer("align_idx", torch.tensor(align_idx, dtype=torch.int32))
         self.register_buffer("ref_c", torch.tensor(ref - ref.mean(axis=0, keepdims=True), dtype=torch.float32))
         self.register_buffer("rec", torch.tensor(rec, dtype=torch.int32).reshape(-1, 6))
@@ -117,7 +118,7 @@ class AlignFeatureLayer(torch.nn.Module):
         d.flags = self._flags
         d.align_idx, d.ref_c, d.rec = self.align_idx.data_ptr(), self.ref_c.data_ptr(), self.rec.data_ptr()
         d.atom_align, d.atom_slot, d.rec_slot = self.atom_align.data_ptr(), self.atom_slot.data_ptr(), self.rec_slot.data_ptr()
-        d.n_slot = self._n_slot
+        d.slot_atom, d.n_slot = self.slot_atom.data_ptr(), self._n_slot
         return d
 
     def forward(self, x):

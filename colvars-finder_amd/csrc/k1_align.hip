@@ -452,15 +452,19 @@ __global__ __launch_bounds__(64) void metric_identity_kernel(int d, const float*
 }  // namespace
 
 int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
-                        float* aux_tiled, double* sums, hipStream_t s);
-size_t cvf_k1_large_scratch_bytes(int64_t B);
+                        float* aux_tiled, float* slot_xyz, hipStream_t s);
+size_t cvf_k1_large_scratch_bytes(const cvf_pp_desc* pp, int64_t B);
+size_t cvf_metric_large_lds(const cvf_pp_desc* pp);
+int cvf_metric_large_launch(const cvf_pp_desc* pp, int64_t B, const float* aux_tiled, const float* a, int k,
+                            const float* slot_xyz, const double* dense, const float* g_tiled, float* q_tiled, float* e_tiled,
+                            hipStream_t s);
 
 // frames larger than this use the streaming workgroup-per-frame kernel (k1_large.hip)
 static constexpr int kLanePerFrameMaxCoord = 192;
 
 extern "C" int64_t cvf_align_feature_scratch_bytes(const cvf_pp_desc* pp, int64_t B) {
   if (!pp || pp->mode != CVF_PP_ALIGN || pp->n_coord <= kLanePerFrameMaxCoord) return 0;
-  return (int64_t)cvf_k1_large_scratch_bytes(B);
+  return (int64_t)cvf_k1_large_scratch_bytes(pp, B);
 }
 
 extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled,
@@ -478,10 +482,7 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
   CVF_REQUIRE(pp->n_coord % 3 == 0 && pp->n_align >= 3 && pp->align_idx && pp->ref_c && pp->rec,
               "cvf_align_feature_fwd: malformed descriptor (n_coord=%d n_align=%d)", pp->n_coord, pp->n_align);
   if (pp->n_coord > kLanePerFrameMaxCoord) {
-    CVF_REQUIRE(scratch != nullptr || cvf_k1_large_scratch_bytes(B) == 0,
-                "cvf_align_feature_fwd: frames of %d coordinates need the scratch buffer (cvf_align_feature_scratch_bytes)",
-                pp->n_coord);
-    return cvf_k1_large_launch(pp, x, B, feat_tiled, feat_rows, aux_tiled, (double*)scratch, s);
+    return cvf_k1_large_launch(pp, x, B, feat_tiled, feat_rows, aux_tiled, (float*)scratch, s);
   }
   const size_t lds = ((size_t)CVF_TILE * x_tile_stride(pp->n_coord) + tables_dwords(*pp)) * sizeof(float);
   CVF_REQUIRE(lds <= 160 * 1024, "frames of %d coordinates do not fit the lane-per-frame kernel's LDS tile", pp->n_coord);
@@ -502,7 +503,7 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
 
 extern "C" int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled,
                                 const float* a, int k, const float* g_tiled, float* q_tiled, float* e_tiled,
-                                void* stream) {
+                                const float* slot_xyz, const double* dense, void* stream) {
   CVF_REQUIRE(pp && a && g_tiled && q_tiled && e_tiled && B > 0 && k >= 1 && k <= CVF_MAX_NETS,
               "cvf_metric_apply: bad argument (B=%lld k=%d)", (long long)B, k);
   const int64_t T = cvf_ntiles(B);
@@ -512,7 +513,14 @@ extern "C" int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B
                        e_tiled);
     return cvf_check_launch("metric_identity_kernel");
   }
-  CVF_REQUIRE(x && aux_tiled, "cvf_metric_apply: align mode needs x and aux");
+  CVF_REQUIRE(aux_tiled, "cvf_metric_apply: align mode needs aux");
+  if (pp->n_coord > kLanePerFrameMaxCoord) {
+    CVF_REQUIRE(slot_xyz && dense && pp->rec_slot && pp->slot_atom && pp->atom_align && pp->n_slot > 0,
+                "cvf_metric_apply: large molecules need the slot tables, slot_xyz (cvf_align_feature_fwd scratch) and "
+                "dense (cvf_metric_dense_tensors)");
+    return cvf_metric_large_launch(pp, B, aux_tiled, a, k, slot_xyz, dense, g_tiled, q_tiled, e_tiled, s);
+  }
+  CVF_REQUIRE(x, "cvf_metric_apply: align mode needs x");
   const size_t lds = ((size_t)CVF_TILE * (x_tile_stride(pp->n_coord) + pp->n_coord) + tables_dwords(*pp) + pp->n_coord) * sizeof(float);
   CVF_REQUIRE(lds <= 160 * 1024, "frames of %d coordinates do not fit the lane-per-frame metric kernel's LDS", pp->n_coord);
   if (lds > 48 * 1024)

@@ -157,7 +157,8 @@ template <bool VEC4>
 __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
                                                                        float* __restrict__ feat_tiled,
                                                                        float* __restrict__ feat_rows,
-                                                                       float* __restrict__ aux_tiled) {
+                                                                       float* __restrict__ aux_tiled,
+                                                                       float* __restrict__ slot_xyz) {
   extern __shared__ float dyn[];                  // [kGroup][n_slot][3] captured atoms, then [d_r][kGroup] features
   __shared__ float bc[kGroup][CVF_AUX_ROWS + 2];
   __shared__ double cD[kGroup][3];
@@ -235,6 +236,10 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
   const int64_t tile = f0 / CVF_TILE;
   const int l0 = (int)(f0 % CVF_TILE);
   if (aux_tiled != nullptr && lane < CVF_AUX_ROWS) aux_tiled[(tile * CVF_AUX_ROWS + lane) * CVF_TILE + l0 + fi] = bc[fi][lane];
+  if (slot_xyz != nullptr) {  // compact copy of the feature atoms for the derivative kernels (padded frame index)
+    float* dst = slot_xyz + (f0 + fi) * (int64_t)nslot * 3;
+    for (int i = lane; i < nslot * 3; i += 64) dst[i] = capL[i];
+  }
   float R[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = bc[fi][i];
@@ -281,16 +286,24 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
 
 }  // namespace
 
-size_t cvf_k1_large_scratch_bytes(int64_t) { return 0; }
+static bool capture_ok(const cvf_pp_desc* pp, bool tiled) {
+  if (!(pp->atom_slot && pp->rec_slot && pp->atom_align && pp->n_slot > 0)) return false;
+  const size_t ldsc = ((size_t)kGroup * pp->n_slot * 3 + (tiled ? (size_t)pp->d_r * kGroup : 0)) * sizeof(float);
+  return ldsc <= 150 * 1024;
+}
+// bytes of the compact feature-atom copy [padded frames][n_slot][3] written when `scratch` is given
+size_t cvf_k1_large_scratch_bytes(const cvf_pp_desc* pp, int64_t B) {
+  return capture_ok(pp, true) ? (size_t)cvf_ntiles(B) * CVF_TILE * pp->n_slot * 3 * sizeof(float) : 0;
+}
 
 // called from cvf_align_feature_fwd (k1_align.hip) when the frame does not fit the lane-per-frame tile
 int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
-                        float* aux_tiled, double* /*unused*/, hipStream_t s) {
+                        float* aux_tiled, float* slot_xyz, hipStream_t s) {
   const bool contig = (pp->flags & CVF_PP_ALIGN_CONTIG) != 0;
-  const int64_t groups = feat_tiled || aux_tiled ? cvf_ntiles(B) * (CVF_TILE / kGroup) : (B + kGroup - 1) / kGroup;
-  if (pp->atom_slot && pp->rec_slot && pp->atom_align && pp->n_slot > 0) {
+  const int64_t groups = feat_tiled || aux_tiled || slot_xyz ? cvf_ntiles(B) * (CVF_TILE / kGroup) : (B + kGroup - 1) / kGroup;
+  if (capture_ok(pp, feat_tiled != nullptr)) {
     const size_t ldsc = ((size_t)kGroup * pp->n_slot * 3 + (feat_tiled ? (size_t)pp->d_r * kGroup : 0)) * sizeof(float);
-    if (ldsc <= 150 * 1024) {
+    {
       const int N = pp->n_coord / 3;
       const bool vec4 = contig && (N % 4 == 0) && (pp->n_align % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
                         (((uintptr_t)pp->ref_c & 15) == 0) && (((uintptr_t)pp->atom_slot & 15) == 0);
@@ -300,10 +313,10 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
       }
       if (vec4)
         hipLaunchKernelGGL(k1_large_capture_kernel<true>, dim3((unsigned)groups), dim3(64 * kGroup), ldsc, s, *pp, x, B,
-                           feat_tiled, feat_rows, aux_tiled);
+                           feat_tiled, feat_rows, aux_tiled, slot_xyz);
       else
         hipLaunchKernelGGL(k1_large_capture_kernel<false>, dim3((unsigned)groups), dim3(64 * kGroup), ldsc, s, *pp, x, B,
-                           feat_tiled, feat_rows, aux_tiled);
+                           feat_tiled, feat_rows, aux_tiled, slot_xyz);
       return cvf_check_launch("k1_large_capture_kernel");
     }
   }

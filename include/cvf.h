@@ -63,6 +63,7 @@ typedef struct cvf_pp_desc {
   const int32_t* atom_align; /* [N]: index b of the atom in align_idx / ref_c, or -1 */
   const int32_t* atom_slot;  /* [N] (16-byte aligned): slot of the atom, or -1 when no feature uses it */
   const int32_t* rec_slot;   /* [n_rec*6]: rec with the atom fields replaced by slots */
+  const int32_t* slot_atom;  /* [n_slot]: atom of each slot */
   int32_t n_slot;
   int32_t pad2_;
 } cvf_pp_desc;
@@ -120,8 +121,9 @@ const char* cvf_last_error(void);
 /* --- K1: alignment + features, forward.  Replaces pp_layer(X) at core.py:403,414,635.
  * x [B, n_coord] row-major fp32.  feat_tiled [T][d_r][64] and/or feat_rows [B][d_r]
  * (either may be NULL); aux_tiled [T][18][64] (may be NULL; identity mode ignores it).
- * Frames of thousands of atoms take the streaming path (one wave per frame, 16 frames per workgroup).
- * `scratch`: cvf_align_feature_scratch_bytes() bytes, 8-byte aligned (currently 0 for every path: may be NULL). */
+ * Frames of thousands of atoms take the streaming path (one wave per frame, 8 frames per workgroup).
+ * `scratch` (may be NULL; cvf_align_feature_scratch_bytes() bytes): on the streaming path it receives the compact
+ * copy [padded frames][n_slot][3] of the atoms the features use, which cvf_metric_apply consumes as `slot_xyz`. */
 int64_t cvf_align_feature_scratch_bytes(const cvf_pp_desc* pp, int64_t B); /* 0 for small molecules */
 int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
                           float* aux_tiled, void* scratch, void* stream);
@@ -132,7 +134,11 @@ int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, floa
  * [B,3N,k] gradient tensor is never materialised.
  * g_tiled, q_tiled [T][k][d_r][64]; e_tiled [T][k][64]; a [n_coord]. */
 int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled, const float* a,
-                     int k, const float* g_tiled, float* q_tiled, float* e_tiled, void* stream);
+                     int k, const float* g_tiled, float* q_tiled, float* e_tiled, const float* slot_xyz,
+                     const double* dense, void* stream);
+/* large molecules only (slot_xyz / dense may be NULL otherwise): dense[42] = moments of (a, ref) over the align atoms,
+ * T0[c] = sum a_bc, T1[c][j] = sum a_bc ref_bj, T2[c][j][k] = sum a_bc ref_bj ref_bk, R1[j] = sum ref_bj (fp64). */
+int cvf_metric_dense_tensors(const cvf_pp_desc* pp, const float* a, double* dense, void* stream);
 
 /* --- packed MFMA weight fragments of the nets (a second copy of the weights in the order the
  * matrix-core kernels consume them; see csrc/cvf_pack.hpp).  cvf_ef_pack rebuilds it from theta;

@@ -299,3 +299,41 @@ def test_k1_streaming_kernel_vs_oracle(dev, n_atoms, B, contig):
     R = aux.view(T, 18, 64)[:, :9, :].permute(0, 2, 1).reshape(T * 64, 3, 3)[:B].cpu().numpy()
     np.testing.assert_allclose(R @ R.transpose(0, 2, 1), np.broadcast_to(np.eye(3), (B, 3, 3)), atol=5e-6)
     np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=5e-6)
+
+
+@pytest.mark.parametrize("n_atoms,B,contig,k", [(257, 96, True, 2), (300, 70, False, 3)])
+def test_large_molecule_generator_step_vs_oracle(dev, n_atoms, B, contig, k):
+    """EigenFunctionTask in generator mode on frames that take the streaming alignment path: loss, eigenvalues and
+    parameter gradient against the fp64 oracle (autograd through linalg.svd over all atoms)."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    traj, w, ref = make_molecule_traj(n_atoms, B, seed=500 + n_atoms, scale=6.0, sigma=0.4)
+    rs = np.random.RandomState(n_atoms)
+    align = list(range(n_atoms)) if contig else sorted(int(i) for i in rs.choice(n_atoms, 2 * n_atoms // 3, replace=False))
+    spec = dict(align_idx=align, ref_pos=ref[align], features=_large_spec(n_atoms, rs), use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    dims = [layer.d_r, 16, 16, 1]
+    gen = torch.Generator().manual_seed(7)
+    sd0 = nnref.init_eigenfunctions(dims, k, gen)
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    a = torch.tensor(diag_coeff_for(n_atoms, 3), dtype=torch.float32)
+    eig_w = [1.0, 0.6, 0.3][:k]
+    task = core.EigenFunctionTask(Traj(traj, w, 1.0), layer, model, "/tmp/cvf_test", 15.0, eig_w, diag_coeff=a, beta=1.5, lag_tau=0,
+                                  k=k, device=dev, verbose=False, save_model_every_step=0)
+    assert task._dense is not None    # the streaming path is really the one in use
+    loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+    X = torch.tensor(traj, dtype=torch.float64, requires_grad=True)
+    lo, eo, no, po, co = losses.ef_loss(sd, k, oracle_layer(spec), X, torch.tensor(w), alpha=15.0, eig_w=eig_w,
+                                        diag_coeff=a.double(), beta=1.5)
+    lo.backward()
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(float(npl), float(no.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=RTOL64)
+    assert list(cvec) == list(co)
+    want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())

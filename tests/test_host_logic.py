@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 def test_struct_layouts_match_the_header(built_lib):
     # sizes computed from include/cvf.h by hand: any drift between the C structs and ctypes breaks every call
-    assert ctypes.sizeof(built_lib.PPDesc) == 8 * 4 + 6 * 8 + 2 * 4
+    assert ctypes.sizeof(built_lib.PPDesc) == 8 * 4 + 7 * 8 + 2 * 4
     assert ctypes.sizeof(built_lib.MLPDesc) == 4 * (2 + 13 + 12 + 2 * 8 * 12 + 1)
     assert ctypes.sizeof(built_lib.EFCfg) == 4 * 4 + 8 * 3 + 8 * 8
 
