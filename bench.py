@@ -30,6 +30,8 @@ import torch  # noqa: E402
 
 N_ATOMS, K_NETS, LAYERS = 22, 3, [66, 20, 20, 20, 1]
 ALPHA, EIG_W, BETA, LR = 20.0, [1.0, 0.75, 0.5], 1.0, 1e-3
+# --workload c5: BASELINE config 5 shape (not the default line): 5000 atoms, 32 positions + 96 dihedrals + 96 distances
+C5 = dict(n_atoms=5000, k=6, layers=[384, 20, 20, 20, 1], eig_w=[1.0, 0.9, 0.8, 0.7, 0.6, 0.5], batch=2000, frames=16000)
 SEED = 20260103
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
@@ -41,15 +43,25 @@ FLOP_FWD = 2 * K_NETS * (P_W + (P_W - 66 * 20) + 66 * 20)            # forward +
 FLOP_BWD = 2 * K_NETS * (P_W + (P_W - 66 * 20) + P_W + 800 + 2 * P_W)  # fwd, d-chain, tangent, zbar-chain, outer products
 
 
-def make_shard(n_frames, rank):
+def make_shard(n_frames, rank, n_atoms=N_ATOMS, scale=2.0, sigma=0.3):
     from tests.synth import make_weights, random_rotations
-    ref = np.random.RandomState(SEED).normal(scale=2.0, size=(N_ATOMS, 3))
+    ref = np.random.RandomState(SEED).normal(scale=scale, size=(n_atoms, 3))
     rs = np.random.RandomState(SEED + 1 + rank)
-    xi = rs.normal(scale=0.3, size=(n_frames, N_ATOMS, 3))
-    Q = random_rotations(rs, n_frames)
-    t = rs.normal(size=(n_frames, 1, 3))
-    x = (np.einsum("bij,baj->bai", Q, ref[None] + xi) + t).astype(np.float32)
+    Q = random_rotations(rs, n_frames).astype(np.float32)
+    t = rs.normal(size=(n_frames, 1, 3)).astype(np.float32)
+    x = np.empty((n_frames, n_atoms, 3), dtype=np.float32)
+    for s0 in range(0, n_frames, 2000):   # chunked: the config-5 shard is ~1 GB
+        xi = rs.normal(scale=sigma, size=(min(2000, n_frames - s0), n_atoms, 3)).astype(np.float32)
+        x[s0:s0 + len(xi)] = np.einsum("bij,baj->bai", Q[s0:s0 + len(xi)], ref[None].astype(np.float32) + xi) + t[s0:s0 + len(xi)]
     return x, make_weights(rs, n_frames), ref
+
+
+def c5_features(n_atoms):
+    rs = np.random.RandomState(SEED + 5)
+    feats = [("position", tuple(int(i) for i in rs.choice(n_atoms, 32, replace=False)))]
+    feats += [("dihedral", tuple(int(i) for i in rs.choice(n_atoms, 4, replace=False))) for _ in range(96)]
+    feats += [("bond", tuple(int(i) for i in rs.choice(n_atoms, 2, replace=False))) for _ in range(96)]
+    return feats
 
 
 def cpu_baseline(x, w, ref, a, sd0, batch, budget_s):
@@ -93,7 +105,10 @@ def main():
     ap.add_argument("--batch", type=int, default=20000, help="frames per GPU per step (reference notebook: 20000)")
     ap.add_argument("--frames", type=int, default=100000, help="frames per GPU shard (config 3: 100k)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 disables it)")
+    ap.add_argument("--workload", choices=["c3", "c5"], default="c3", help="c3 = the benchmark line; c5 = config-5 shape (extra)")
     args = ap.parse_args()
+    if args.workload == "c5":
+        return main_c5(args)
 
     from colvarsfinder import _dist, core, nn, pp
     from tests.synth import Traj, diag_coeff_for
@@ -205,6 +220,57 @@ def main():
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(x, w, ref, a, sd0, B, args.cpu_seconds)
     print(json.dumps(out))
+
+
+def main_c5(args):
+    """Config-5 shape on the GPUs at hand (5000 atoms, k = 6, d_r = 384): exercises the streaming alignment kernel and the
+    large-molecule derivative kernel inside the full train step.  Extra measurement, not the benchmark line."""
+    from colvarsfinder import _dist, core, nn, pp
+    from tests.synth import Traj, diag_coeff_for
+    _dist.init_from_env("nccl")
+    world, rank = _dist.world(), _dist.rank()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    n_atoms, k = C5["n_atoms"], C5["k"]
+    frames = C5["frames"] if args.frames == 100000 else args.frames
+    B = C5["batch"] if args.batch == 20000 else args.batch
+    x, w, ref = make_shard(frames, rank, n_atoms, scale=2.0, sigma=0.05)   # nm-like units: 20 A / 0.5 A of SURVEY 8d (in A the tanh nets saturate at init)
+    a = torch.tensor(diag_coeff_for(n_atoms, SEED), dtype=torch.float32)
+    torch.manual_seed(SEED)
+    model = nn.EigenFunctions(C5["layers"], k)
+    layer = pp.AlignFeatureLayer(n_atoms, list(range(n_atoms)), ref, c5_features(n_atoms))
+    task = core.EigenFunctionTask(Traj(x, w, 1.0), layer, model, "/tmp/cvf_bench", ALPHA, C5["eig_w"], diag_coeff=a, beta=BETA,
+                                  lag_tau=0, learning_rate=LR, k=k, batch_size=B, device=dev, verbose=False, save_model_every_step=0)
+    n_batches = frames // B
+    X, Wt = task._traj, task._weights
+    log = torch.zeros(n_batches, 3 + 2 * k, device=dev, dtype=torch.float64)
+
+    def step(i):
+        b = i % n_batches
+        task._graph_step(("bench", b), lambda: task.train_step(X[b * B:(b + 1) * B], Wt[b * B:(b + 1) * B]), log[b])
+        return log[b]
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        lv = step(args.warmup + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    task._use_graphs, task._events = False, {}
+    for i in range(min(args.steps, 20)):
+        step(args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    kern = {n: float(np.mean([s_.elapsed_time(e_) for s_, e_ in ev])) * 1e3 for n, ev in task._events.items()}
+    if rank == 0:
+        k1 = kern["cvf_align_feature_fwd"]
+        bpf = 12 * n_atoms + 4 + 4 * layer.d_r
+        print(json.dumps({"workload": "config-5 shape: 5000 atoms, d_r=384, k=6, EigenFunctionTask generator step", "n_gpus": world,
+                          "batch_per_gpu": B, "frames_per_gpu": frames, "value": world * B * args.steps / elapsed, "unit": "frames/s",
+                          "ms_per_step": elapsed / args.steps * 1e3, "final_loss": float(lv[0]),
+                          "kernel_avg_us": dict(sorted(kern.items(), key=lambda kv: -kv[1])),
+                          "align_feature_GBps": bpf * B / (k1 * 1e-6) / 1e9, "align_feature_frac_of_8TBps": bpf * B / (k1 * 1e-6) / 8e12}))
 
 
 if __name__ == "__main__":

@@ -33,20 +33,13 @@ __device__ __forceinline__ float wave_sumf(float v) {
   return v;
 }
 
-// tanh, branch-free, ~1e-7 absolute error: the odd minimax polynomial of libm below 0.625,
-// 1 - 2/(exp(2|x|)+1) above (v_exp_f32 / v_rcp_f32 are ~1 ulp).  The libm tanhf is two divergent
-// branches of ~35 instructions; the 1e-5 parity bar on the loss needs ~1e-6 here.
+// tanh in 7 instructions, absolute error ~6e-8 (fp32 rounding of t):  t = exp(-2|x|) in (0,1],
+// tanh|x| = (1 - t) / (1 + t).  (libm's tanhf is two divergent branches of ~35 instructions, and a 20-wide net
+// evaluates 60 of them per frame; v_exp_f32 / v_rcp_f32 are ~1 ulp.)  The parity bar on the loss is 1e-5 relative.
 __device__ __forceinline__ float cvf_tanh(float x) {
-  const float ax = fabsf(x);
-  const float x2 = x * x;
-  float p = fmaf(x2, -5.70498872745e-3f, 2.06390887954e-2f);
-  p = fmaf(x2, p, -5.37397155531e-2f);
-  p = fmaf(x2, p, 1.33314422036e-1f);
-  p = fmaf(x2, p, -3.33332819422e-1f);
-  const float small = fmaf(x * x2, p, x);
-  const float e = __expf(2.0f * ax);
-  const float big = copysignf(fmaf(-2.0f, __frcp_rn(e + 1.0f), 1.0f), x);
-  return ax < 0.625f ? small : big;
+  const float t = __builtin_amdgcn_exp2f(-2.8853900817779268f * fabsf(x));   // exp(-2|x|) = 2^(-2 log2(e) |x|)
+  const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+  return copysignf(r, x);
 }
 
 // ------------------------------------------------------------------------------------

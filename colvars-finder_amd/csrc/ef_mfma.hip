@@ -406,6 +406,273 @@ __global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const
   CVF_STAMP(7);
 }
 
+template <int H, int FT>
+__device__ __forceinline__ void tangent_of(Vec<H, FT>& td, const Vec<H, FT>& h, const Vec<H, FT>& t);
+
+// K4a for small feature dimensions (d0 <= 72: 18 k-steps, 5 output row tiles - the dipeptide-sized layers): EVERY
+// global load of the kernel (all weight fragments, biases, the wave's slice of the feature tile) is issued before
+// the first MFMA.  At small batch sizes the whole launch is one wave per SIMD slot, nothing else is resident to hide a
+// dependent round trip (2-5k cycles under the start-up burst), and the phased version paid five of them in sequence.
+template <int H, int NH, int FT>
+__global__ __launch_bounds__(64) void ef_fwd_pre_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
+                                                         const float* __restrict__ packed,
+                                                         const float* __restrict__ feat, float* __restrict__ y_tiled,
+                                                         float* __restrict__ g_tiled) {
+  constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG;
+  constexpr int SUB = 4 / FT, CH = 6, CTMAX = 5;
+  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
+  const int64_t tile = blockIdx.x / SUB;
+  const int ft0 = (blockIdx.x % SUB) * FT;
+  const int net = blockIdx.y;
+  const int k = mlp.n_nets, D = mlp.dims[0];
+  const int S = (D + 3) >> 2, CT = (D + 15) >> 4;
+  const PackLayout L = pack_layout(H, NH, D);
+  const float* pk = packed + (int64_t)net * L.per_net;
+  const int fo = 4 * col + ft0;
+  const float* in_lane = feat + tile * (int64_t)D * CVF_TILE + fo;
+  const bool want_g = g_tiled != nullptr;
+
+  CVF_STAMP(0);
+  // ---- all loads
+  L0Chunk<H, FT, CH> c0, c1, c2;
+  load_l0chunk<H, FT, CH>(c0, pk + L.f0(), D, S, in_lane, 0, lane);
+  load_l0chunk<H, FT, CH>(c1, pk + L.f0(), D, S, in_lane, CH, lane);
+  load_l0chunk<H, FT, CH>(c2, pk + L.f0(), D, S, in_lane, 2 * CH, lane);
+  HConst<H> bias[NH];
+#pragma unroll
+  for (int l = 0; l < NH; ++l) load_hconst<H>(bias[l], theta + mlp.b_off[net][l], q);
+  HFrag<H> hf[NH > 1 ? NH - 1 : 1];
+#pragma unroll
+  for (int l = 1; l < NH; ++l) load_hfrag<H>(hf[l - 1], pk + L.fh(l), lane);
+  float wl[RT][4];
+  load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
+  const float bL = theta[mlp.b_off[net][NH]];
+  HFrag<H> tf[NH > 1 ? NH - 1 : 1];
+  float t0[CTMAX][NG];
+  if (want_g) {
+#pragma unroll
+    for (int l = 1; l < NH; ++l) load_hfrag<H>(tf[l - 1], pk + L.th(l), lane);
+    const float* pT0 = pk + L.t0();
+#pragma unroll
+    for (int rt = 0; rt < CTMAX; ++rt) {
+      const int rte = rt < CT ? rt : CT - 1;
+#pragma unroll
+      for (int s = 0; s < NG; ++s) {
+        const float v = pT0[(rte * NG + s) * 64 + lane];
+        t0[rt][s] = rt < CT ? v : 0.0f;
+      }
+    }
+  }
+
+  CVF_STAMP(1);
+  // ---- compute
+  Vec<H, FT> h[NH];
+  set_const<H, FT>(h[0], bias[0]);
+  mul_l0chunk<H, FT, CH>(h[0], c0);
+  CVF_STAMP(2);
+  mul_l0chunk<H, FT, CH>(h[0], c1);
+  mul_l0chunk<H, FT, CH>(h[0], c2);
+  CVF_STAMP(3);
+  tanh_inplace<H, FT>(h[0]);
+#pragma unroll
+  for (int l = 1; l < NH; ++l) {
+    set_const<H, FT>(h[l], bias[l]);
+    hidden_mul<H, FT>(h[l], hf[l - 1], h[l - 1]);
+    tanh_inplace<H, FT>(h[l]);
+  }
+  {
+    float yv[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      float part = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(wl[rt][r], h[NH - 1].v[rt][ft][r], part);
+      yv[ft] = sum_over_q(part) + bL;
+    }
+    if (q == 0) store_frames<FT>(y_tiled + (tile * k + net) * CVF_TILE + fo, yv);
+  }
+  CVF_STAMP(4);
+  if (!want_g) return;
+  Vec<H, FT> d;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = h[NH - 1].v[rt][ft][r];
+        d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
+      }
+#pragma unroll
+  for (int l = NH - 1; l >= 1; --l) {
+    Vec<H, FT> e;
+    init_bias<H, FT>(e, nullptr, q);
+    hidden_mul<H, FT>(e, tf[l - 1], d);
+    tangent_of<H, FT>(d, h[l - 1], e);
+  }
+  CVF_STAMP(5);
+  float* gout = g_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + fo;
+#pragma unroll
+  for (int rt = 0; rt < CTMAX; ++rt) {
+    if (rt < CT) {  // wave-uniform
+      f32x4 acc[FT];
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) acc[ft] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int s = 0; s < NG; ++s)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) acc[ft] = mfma4(t0[rt][s], d.v[s >> 2][ft][s & 3], acc[ft]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * rt + 4 * q + r;
+        if (i < D) {
+          float gv[FT];
+#pragma unroll
+          for (int ft = 0; ft < FT; ++ft) gv[ft] = acc[ft][r];
+          store_frames<FT>(gout + (int64_t)i * CVF_TILE, gv);
+        }
+      }
+    }
+  }
+  CVF_STAMP(6);
+  CVF_STAMP(7);
+}
+
+// K4a, workgroup form: four waves = four consecutive 64-frame tiles of ONE net.  The net's weight fragments
+// (F0, Fh, Th, T0: ~25 KB for 66 -> 20 -> 20 -> 20 -> 1) are fetched ONCE per workgroup with 16-byte loads into
+// LDS and read from there by all four waves; per-wave global traffic is then only its feature tile.  (The per-CU
+// vector-memory path, not latency, bounded the wave-per-block kernels: every wave re-fetched the same 25 KB.)
+template <int H, int NH>
+__global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
+                                                         const float* __restrict__ packed,
+                                                         const float* __restrict__ feat, int64_t n_tiles,
+                                                         float* __restrict__ y_tiled, float* __restrict__ g_tiled) {
+  constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG, FT = 4, CH = 6;
+  extern __shared__ float wL[];   // this net's packed fragments
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q = lane >> 4;
+  const int net = blockIdx.y;
+  const int k = mlp.n_nets, D = mlp.dims[0];
+  const int S = (D + 3) >> 2, CT = (D + 15) >> 4;
+  const PackLayout L = pack_layout(H, NH, D);
+  {
+    const float4* src = reinterpret_cast<const float4*>(packed + (int64_t)net * L.per_net);
+    float4* dst = reinterpret_cast<float4*>(wL);
+    for (int i = tid; i < L.per_net / 4; i += 256) dst[i] = src[i];
+  }
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const bool live = tile < n_tiles;
+  if (!live) tile = n_tiles - 1;   // keep the wave in step with the barriers; its stores are masked
+  const int fo = 4 * col;
+  const float* in_lane = feat + tile * (int64_t)D * CVF_TILE + fo;
+  const bool want_g = g_tiled != nullptr;
+  // this wave's global loads: feature tile slice (all k-steps), biases, last-layer weights
+  float bfr[18][FT];
+  const bool smallD = S <= 18;
+#pragma unroll
+  for (int s = 0; s < 18; ++s) {
+    const int se = s < S ? s : S - 1;
+    const int kf = 4 * se + q;
+    load_frames<FT>(in_lane + (int64_t)(kf < D ? kf : 0) * CVF_TILE, bfr[s]);
+  }
+  HConst<H> bias[NH];
+#pragma unroll
+  for (int l = 0; l < NH; ++l) load_hconst<H>(bias[l], theta + mlp.b_off[net][l], q);
+  float wl[RT][4];
+  load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
+  const float bL = theta[mlp.b_off[net][NH]];
+  __syncthreads();
+
+  Vec<H, FT> h[NH];
+  set_const<H, FT>(h[0], bias[0]);
+  {
+    const float* f0 = wL + L.f0();
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+      if (s < S) {  // wave-uniform
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) h[0].v[rt][ft] = mfma4(f0[(s * RT + rt) * 64 + lane], bfr[s][ft], h[0].v[rt][ft]);
+      }
+    }
+    for (int s = 18; s < S; ++s) {  // wider first layers: remaining k-steps straight from global
+      const int kf = 4 * s + q;
+      float b[FT];
+      load_frames<FT>(in_lane + (int64_t)(kf < D ? kf : 0) * CVF_TILE, b);
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) h[0].v[rt][ft] = mfma4(f0[(s * RT + rt) * 64 + lane], b[ft], h[0].v[rt][ft]);
+    }
+  }
+  (void)smallD;
+  tanh_inplace<H, FT>(h[0]);
+#pragma unroll
+  for (int l = 1; l < NH; ++l) {
+    set_const<H, FT>(h[l], bias[l]);
+    hidden_apply<H, FT>(h[l], wL + L.fh(l), h[l - 1], lane);
+    tanh_inplace<H, FT>(h[l]);
+  }
+  {
+    float yv[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      float part = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(wl[rt][r], h[NH - 1].v[rt][ft][r], part);
+      yv[ft] = sum_over_q(part) + bL;
+    }
+    if (q == 0 && live) store_frames<FT>(y_tiled + (tile * k + net) * CVF_TILE + fo, yv);
+  }
+  if (!want_g) return;
+  Vec<H, FT> d;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = h[NH - 1].v[rt][ft][r];
+        d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
+      }
+#pragma unroll
+  for (int l = NH - 1; l >= 1; --l) {
+    Vec<H, FT> e;
+    init_bias<H, FT>(e, nullptr, q);
+    hidden_apply<H, FT>(e, wL + L.th(l), d, lane);
+    tangent_of<H, FT>(d, h[l - 1], e);
+  }
+  const float* pT0 = wL + L.t0();
+  float* gout = g_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + fo;
+  for (int rt = 0; rt < CT; ++rt) {
+    f32x4 acc[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) acc[ft] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < NG; ++s) {
+      const float a = pT0[(rt * NG + s) * 64 + lane];
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) acc[ft] = mfma4(a, d.v[s >> 2][ft][s & 3], acc[ft]);
+    }
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * rt + 4 * q + r;
+        if (i < D) {
+          float gv[FT];
+#pragma unroll
+          for (int ft = 0; ft < FT; ++ft) gv[ft] = acc[ft][r];
+          store_frames<FT>(gout + (int64_t)i * CVF_TILE, gv);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4b
 // ------------------------------------------------------------------------------------------------
@@ -523,11 +790,12 @@ __global__ __launch_bounds__(64 * WPB, 2) void ef_bwd_mfma_kernel(EfBwdArgs args
   __syncthreads();
   if (tid < 64) SB1[H * kPitch + tid] = 1.0f;  // bias column of [h ; 1]  (row H of SB2 stays 0)
 
-  const double* gS1 = coef;
-  const double* gS2 = coef + k;
-  const double* gEt = coef + k + k * k;
-  const double* gS1l = coef + 2 * k + k * k;
-  const double* gS2l = coef + 3 * k + k * k;
+  // this net's coefficients d loss / d sums (wave-uniform, loaded once)
+  const double cS1 = coef[net], cEt = coef[k + k * k + net];
+  const double cS1l = coef[2 * k + k * k + net], cS2l = coef[3 * k + k * k + net];
+  double cS2[CVF_MAX_NETS];
+#pragma unroll
+  for (int j = 0; j < CVF_MAX_NETS; ++j) cS2[j] = j < k ? (j == net ? 2.0 : 1.0) * coef[k + net * k + j] : 0.0;
 
   float wl[RT][4];
   load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
@@ -554,6 +822,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void ef_bwd_mfma_kernel(EfBwdArgs args
   for (int64_t tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x) {
     const int pass = tile >= args.T ? 1 : 0;
     const int64_t t0 = pass ? tile - args.T : tile;
+    CVF_STAMP(8);
     // ---- per-frame coefficients for the FT frames this lane owns
     float alpha[FT], gamma[FT];
 #pragma unroll
@@ -565,32 +834,34 @@ __global__ __launch_bounds__(64 * WPB, 2) void ef_bwd_mfma_kernel(EfBwdArgs args
       const float wb = valid ? wraw : 0.0f;
       const float* yb = y_tiled + t0 * k * CVF_TILE + fo + ft;
       gamma[ft] = 0.0f;
+      double a = cS1;
+#pragma unroll
+      for (int j = 0; j < CVF_MAX_NETS; ++j)
+        if (j < k) a = fma(cS2[j], (double)yb[j * CVF_TILE], a);
       if (args.lag_idx == 0) {
-        double a = gS1[net];
-        for (int j = 0; j < k; ++j) a += (j == net ? 2.0 : 1.0) * gS2[net * k + j] * (double)yb[j * CVF_TILE];
         alpha[ft] = (float)((double)wb * a);
-        gamma[ft] = (float)(2.0 * (double)wb * gEt[net]);
+        gamma[ft] = (float)(2.0 * (double)wb * cEt);
       } else {
         const float* yl = y_tiled + (args.T + t0) * k * CVF_TILE + fo + ft;
         const double diff = (double)yl[net * CVF_TILE] - (double)yb[net * CVF_TILE];
-        const double tterm = 2.0 * (double)wb * gEt[net] * diff;
+        const double tterm = 2.0 * (double)wb * cEt * diff;
         if (pass == 0) {
-          double a = gS1[net];
-          for (int j = 0; j < k; ++j) a += (j == net ? 2.0 : 1.0) * gS2[net * k + j] * (double)yb[j * CVF_TILE];
           alpha[ft] = (float)((double)wb * a - tterm);
         } else {
           const float wlraw = w_lag[fc];
           const float wlg = valid ? wlraw : 0.0f;
-          alpha[ft] = (float)((double)wlg * (gS1l[net] + 2.0 * gS2l[net] * (double)yl[net * CVF_TILE]) + tterm);
+          alpha[ft] = (float)((double)wlg * (cS1l + cS2l * 2.0 * (double)yl[net * CVF_TILE]) + tterm);
         }
       }
     }
     const float* f_tile = feat + tile * (int64_t)D * CVF_TILE;
     const float* q_tile = tangent ? q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE : nullptr;
 
+    CVF_STAMP(9);
     // ---- chains (registers, MFMA) for this wave's frames
     Vec<H, FT> h[NH];
     chain_forward<H, NH, FT, true>(mlp, theta, pk, L, net, f_tile + fo, lane, h);
+    CVF_STAMP(10);
     Vec<H, FT> e[NH > 1 ? NH - 1 : 1];  // e[l] = W_{l+1}^T d_{l+1}, l = 0..NH-2  (e_{NH-1} = W_L is the constant wl)
     Vec<H, FT> t[NH];                   // t[l] = W_l tdot_{l-1}
     if (tangent) {
@@ -629,6 +900,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void ef_bwd_mfma_kernel(EfBwdArgs args
       }
     }
 
+    CVF_STAMP(11);
     // ---- last layer (1 x H):  W_L += sum alpha h_{NH-1} + tdot_{NH-1} ; b_L += sum alpha
     {
       if (q == 0) {
@@ -657,6 +929,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void ef_bwd_mfma_kernel(EfBwdArgs args
       __syncthreads();
     }
 
+    CVF_STAMP(12);
     // ---- reverse sweep
     Vec<H, FT> hbar;
 #pragma unroll
@@ -667,6 +940,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void ef_bwd_mfma_kernel(EfBwdArgs args
         for (int r = 0; r < 4; ++r) hbar.v[rt][ft][r] = alpha[ft] * wl[rt][r];
 #pragma unroll
     for (int l = NH - 1; l >= 0; --l) {
+      CVF_STAMP(13 + (NH - 1 - l));
       Vec<H, FT> zbar, dl;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -707,30 +981,43 @@ __global__ __launch_bounds__(64 * WPB, 2) void ef_bwd_mfma_kernel(EfBwdArgs args
         __syncthreads();
       } else {
         __syncthreads();
-        // first layer: the B operands are the feature tile (+ ones row) and q, read straight from global
-        // memory in operand order (the tile was just streamed by the chains: L2 hits), 16 loads in flight
+        // first layer: the B operands are the feature tile (+ ones row) and q, read straight from global memory.
+        // The order in which the 64 frames are summed is free as long as A and B agree, so k-slot q of k-step
+        // (j, c) is frame 16 j + 4 q + c: a lane's sixteen B values are then four 16-byte loads, and one load
+        // instruction covers 64 contiguous bytes of each of its 16 feature rows (with the natural order 4 s + q
+        // every 4-byte load touched 16 different sectors: 12k cycles per tile pair, half of this kernel).
         for (int pr = wave; pr < RTO * CT1; pr += WPB) {
           const int rt = pr / CT1, ct = pr - rt * CT1;
           const int i = 16 * ct + row16;
-          const float* a1 = SA1 + (16 * rt + row16) * kPitch + q;
-          const float* a2 = SA2 + (16 * rt + row16) * kPitch + q;
+          const float* a1 = SA1 + (16 * rt + row16) * kPitch + 4 * q;
+          const float* a2 = SA2 + (16 * rt + row16) * kPitch + 4 * q;
           // (no MFMA under lane-divergent control flow: operand values are selected per lane, the MFMAs are uniform)
           const int ic = i < D ? i : D - 1;
-          const float* fb = f_tile + (int64_t)ic * CVF_TILE + q;
           const float pad1 = i == D ? 1.0f : 0.0f;   // bias column; columns past it stay 0
-          float b1[16];
+          const float4* fb = reinterpret_cast<const float4*>(f_tile + (int64_t)ic * CVF_TILE + 4 * q);
+          float4 b1[4];
 #pragma unroll
-          for (int s = 0; s < 16; ++s) b1[s] = fb[4 * s];
+          for (int j = 0; j < 4; ++j) b1[j] = fb[4 * j];
           f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int s = 0; s < 16; ++s) acc = mfma4(a1[4 * s], i < D ? b1[s] : pad1, acc);
+          for (int j = 0; j < 4; ++j) {
+            acc = mfma4(a1[16 * j + 0], i < D ? b1[j].x : pad1, acc);
+            acc = mfma4(a1[16 * j + 1], i < D ? b1[j].y : pad1, acc);
+            acc = mfma4(a1[16 * j + 2], i < D ? b1[j].z : pad1, acc);
+            acc = mfma4(a1[16 * j + 3], i < D ? b1[j].w : pad1, acc);
+          }
           if (tangent) {
-            const float* qb = q_tile + (int64_t)ic * CVF_TILE + q;
-            float b2[16];
+            const float4* qb = reinterpret_cast<const float4*>(q_tile + (int64_t)ic * CVF_TILE + 4 * q);
+            float4 b2[4];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) b2[s] = qb[4 * s];
+            for (int j = 0; j < 4; ++j) b2[j] = qb[4 * j];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc = mfma4(a2[4 * s], i < D ? b2[s] : 0.0f, acc);
+            for (int j = 0; j < 4; ++j) {
+              acc = mfma4(a2[16 * j + 0], i < D ? b2[j].x : 0.0f, acc);
+              acc = mfma4(a2[16 * j + 1], i < D ? b2[j].y : 0.0f, acc);
+              acc = mfma4(a2[16 * j + 2], i < D ? b2[j].z : 0.0f, acc);
+              acc = mfma4(a2[16 * j + 3], i < D ? b2[j].w : 0.0f, acc);
+            }
           }
           add_tile(0, H, D, rt, ct, acc);
         }
@@ -739,12 +1026,14 @@ __global__ __launch_bounds__(64 * WPB, 2) void ef_bwd_mfma_kernel(EfBwdArgs args
     }
   }
 
+  CVF_STAMP(17);
   // ---- flush this block's partial gradient of `net` into its slab row
   __syncthreads();
   float* out = slab + (int64_t)blockIdx.x * mlp.n_params + gbase;
   for (int i = tid; i < gspan; i += NT) out[i] = GI[i];
   // one gradient per optimiser step: advance the step counter read by the Adam that follows
   if (step != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *step += 1;
+  CVF_STAMP(18);
 }
 
 // grad[p] = sum over slab rows, fixed order: 16 row groups (strided) per parameter, then the 16
@@ -838,9 +1127,24 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
   // few tiles: split each 64-frame tile over two waves so that the launch still fills the 1024 SIMDs
   bool split = n_tiles * mlp->n_nets < 2048;
   if (getenv("CVF_FWD_SPLIT")) split = atoi(getenv("CVF_FWD_SPLIT")) != 0;   // developer override
+  const bool pre = mlp->dims[0] <= 72;   // every load up front (see ef_fwd_pre_kernel)
+  const size_t wlds = (size_t)pack_layout(H, NH, mlp->dims[0]).per_net * sizeof(float);
+  bool wg = wlds <= 64 * 1024;            // one fetch of the weights per four tiles (see ef_fwd_wg_kernel)
+  if (getenv("CVF_FWD_WG")) wg = wg && atoi(getenv("CVF_FWD_WG")) != 0;   // developer override
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    if (split)
+    if (wg) {
+      if (wlds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)ef_fwd_wg_kernel<kH, kNH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
+      hipLaunchKernelGGL((ef_fwd_wg_kernel<kH, kNH>), dim3((unsigned)((n_tiles + 3) / 4), mlp->n_nets), dim3(256), wlds,
+                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, n_tiles, y_tiled, g_tiled);
+    } else if (pre && split)
+      hipLaunchKernelGGL((ef_fwd_pre_kernel<kH, kNH, 2>), dim3((unsigned)(2 * n_tiles), mlp->n_nets), dim3(64), 0,
+                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
+    else if (pre)
+      hipLaunchKernelGGL((ef_fwd_pre_kernel<kH, kNH, 4>), dim3((unsigned)n_tiles, mlp->n_nets), dim3(64), 0,
+                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
+    else if (split)
       hipLaunchKernelGGL((ef_fwd_mfma_kernel<kH, kNH, 2>), dim3((unsigned)(2 * n_tiles), mlp->n_nets), dim3(64), 0,
                          (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
     else

@@ -36,10 +36,11 @@ int main() {
   hipDeviceSynchronize();
   std::vector<unsigned long long> st(64 * 4096);
   hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
-  const char* names[8] = {"start", "prefetch issued", "layer0 done", "tanh0 done", "chain done", "y done", "dchain done", "g done"};
+  const char* names[8] = {"start", "loads issued", "chunk0 done", "layer0 done", "chain+y done", "dchain done", "g done", "-"};
   double acc[8] = {0};
   int n = 0;
   for (int b = 0; b < 1252 && b < 4096; ++b) {
+    if (b & 1) continue;
     const unsigned long long* s = &st[b * 64];
     if (s[7] == 0) continue;
     for (int i = 1; i < 8; ++i) acc[i] += double(s[i] - s[i - 1]);
@@ -48,5 +49,44 @@ int main() {
   double tot = 0;
   for (int i = 1; i < 8; ++i) { printf("%-18s %9.0f cycles\n", names[i], acc[i] / n); tot += acc[i] / n; }
   printf("total %9.0f cycles over %d waves\n", tot, n);
+  // ---- backward kernel phases
+  {
+    std::vector<float> hw(B), hy(T * k * 64), hq(T * k * D * 64);
+    for (auto& v : hw) v = 1.0f + U(rng);
+    for (auto& v : hy) v = U(rng);
+    for (auto& v : hq) v = 0.01f * U(rng);
+    std::vector<double> hc(4 * k + k * k);
+    for (auto& v : hc) v = 0.01 * U(rng);
+    float *dw, *dq, *dslab; double* dcoef;
+    hipMalloc(&dw, B * 4); hipMalloc(&dq, hq.size() * 4); hipMalloc(&dcoef, hc.size() * 8);
+    hipMalloc(&dslab, cvf_ef_backward_slab_rows(T) * (size_t)pos * 4);
+    hipMemcpy(dw, hw.data(), B * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dy, hy.data(), hy.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dq, hq.data(), hq.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dcoef, hc.data(), hc.size() * 8, hipMemcpyHostToDevice);
+    cvf_ef_cfg cfg = {};
+    cfg.k = k; cfg.lag_idx = 0;
+    hipMemset(HIP_SYMBOL(g_stamps), 0, 0);
+    for (int it = 0; it < 5; ++it) {
+      int rc = cvf_ef_backward(&cfg, &m, dth, dpk, B, dw, nullptr, dfeat, dy, dq, dcoef, dslab, nullptr, nullptr);
+      if (rc) { printf("bwd failed: %s\n", cvf_last_error()); return 1; }
+    }
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+    const char* bn[11] = {"alpha", "fwd chain", "d+tangent", "last layer", "hbar init", "reverse l=2", "reverse l=1", "reverse l=0", "-", "flush", "end"};
+    double ab[11] = {0};
+    int nb = 0;
+    for (int b = 0; b < 626; ++b) {
+      const unsigned long long* s = &st[b * 64];
+      if (s[18] == 0 || s[8] == 0) continue;
+      ab[0] += double(s[9] - s[8]); ab[1] += double(s[10] - s[9]); ab[2] += double(s[11] - s[10]); ab[3] += double(s[12] - s[11]);
+      ab[4] += double(s[13] - s[12]); ab[5] += double(s[14] - s[13]); ab[6] += double(s[15] - s[14]); ab[7] += double(s[17] - s[15]);
+      ab[9] += double(s[18] - s[17]);
+      ++nb;
+    }
+    double tb = 0;
+    for (int i = 0; i < 11; ++i) { if (ab[i] > 0) printf("bwd %-14s %9.0f cycles\n", bn[i], ab[i] / nb); tb += ab[i] / nb; }
+    printf("bwd total %9.0f cycles over %d waves\n", tb, nb);
+  }
   return 0;
 }
