@@ -42,6 +42,19 @@ __device__ __forceinline__ float cvf_tanh(float x) {
   return copysignf(r, x);
 }
 
+// Developer aid: the tools/*.hip probes compile a kernel file with -DCVF_STAMPS to read s_memtime at phase
+// boundaries of one wave per block; in the shipped library the macro is empty.
+#ifdef CVF_STAMPS
+static __device__ unsigned long long g_stamps[64 * 4096];
+#define CVF_STAMP(i)                                                                              \
+  do {                                                                                            \
+    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 4096)                          \
+      g_stamps[(blockIdx.x * 2 + (threadIdx.x >> 6)) % 4096 * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define CVF_STAMP(i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------
 // Stage one tile (64 frames) of a row-major [B][nc] fp32 array into LDS as
 // lds[frame * stride + j], stride odd so that per-lane reads (lane = frame) are
@@ -63,19 +76,34 @@ __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int64_t
     int fr = e / nc;
     int j = e - fr * nc;
     const int dfr = 256 / nc, dj = 256 - dfr * nc;
-    for (int v = lane; v < nvec; v += CVF_WAVE) {
-      float4 val = src[v];
-      int f = fr, jj = j;
-      lds[f * stride + jj] = val.x;
-      if (++jj == nc) { jj = 0; ++f; }
-      lds[f * stride + jj] = val.y;
-      if (++jj == nc) { jj = 0; ++f; }
-      lds[f * stride + jj] = val.z;
-      if (++jj == nc) { jj = 0; ++f; }
-      lds[f * stride + jj] = val.w;
-      fr += dfr;
-      j += dj;
-      if (j >= nc) { j -= nc; ++fr; }
+    // Batches of kBatch 16-byte loads are issued back to back before the first LDS write: this wave is usually
+    // alone on its SIMD, and a load -> wait -> write loop paid one full memory round trip per 1 KiB of the tile
+    // (17 of them for 22 atoms).  Indices are clamped instead of
+    // predicated so the loads stay unconditional (counted waits).
+    constexpr int kBatch = 18;
+    for (int v0 = lane; v0 < nvec; v0 += CVF_WAVE * kBatch) {
+      float4 val[kBatch];
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i) {
+        const int v = v0 + CVF_WAVE * i;
+        val[i] = src[v < nvec ? v : nvec - 1];
+      }
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i) {
+        if (v0 + CVF_WAVE * i < nvec) {
+          int f = fr, jj = j;
+          lds[f * stride + jj] = val[i].x;
+          if (++jj == nc) { jj = 0; ++f; }
+          lds[f * stride + jj] = val[i].y;
+          if (++jj == nc) { jj = 0; ++f; }
+          lds[f * stride + jj] = val[i].z;
+          if (++jj == nc) { jj = 0; ++f; }
+          lds[f * stride + jj] = val[i].w;
+        }
+        fr += dfr;
+        j += dj;
+        if (j >= nc) { j -= nc; ++fr; }
+      }
     }
   } else {
     for (int e = lane; e < total; e += CVF_WAVE) {

@@ -25,19 +25,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Developer aid: tools/stamp_ef.hip compiles this file with -DCVF_STAMPS to read s_memtime at phase
-// boundaries of one wave per block; in the shipped library the macro is empty.
-#ifdef CVF_STAMPS
-__device__ unsigned long long g_stamps[64 * 4096];
-#define CVF_STAMP(i)                                                                              \
-  do {                                                                                            \
-    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 4096)                          \
-      g_stamps[(blockIdx.x * 2 + (threadIdx.x >> 6)) % 4096 * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define CVF_STAMP(i) do {} while (0)
-#endif
-
 namespace {
 
 constexpr int kPitch = 66;
@@ -750,7 +737,7 @@ __device__ __forceinline__ void tangent_of(Vec<H, FT>& td, const Vec<H, FT>& h, 
 // each weight-gradient product.  Splitting the tile over waves shortens each wave's dependent chain and
 // puts two waves on every SIMD, which is what hides the LDS / L2 latencies at small batch sizes.
 template <int H, int NH, int WPB>
-__global__ __launch_bounds__(64 * WPB, 2) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp_desc mlp,
+__global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp_desc mlp,
                                                                const float* __restrict__ theta,
                                                                const float* __restrict__ packed,
                                                                const float* __restrict__ w, const float* __restrict__ w_lag,
@@ -1157,6 +1144,12 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
 
 extern "C" int64_t cvf_ef_backward_slab_rows(int64_t n_tiles) { return bwd_grid(n_tiles); }
 
+// developer switch while tuning: CVF_BWD_WPB=4 runs four waves per tile (one 16-frame group each)
+static bool bwd_wpb4() {
+  static const int v = [] { const char* e = getenv("CVF_BWD_WPB"); return e ? atoi(e) : 2; }();
+  return v == 4;
+}
+
 extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
                                int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
                                const float* y_tiled, const float* q_tiled, const double* coef, float* slab,
@@ -1189,8 +1182,12 @@ extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, c
   const size_t lds_dyn = (size_t)span * sizeof(float);
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed,
-                       w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count);
+    if (bwd_wpb4())
+      hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 4>), grid, dim3(256), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed,
+                         w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count);
+    else
+      hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed,
+                         w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count);
   });
   CVF_REQUIRE(launched, "cvf_ef_backward: no kernel instance for hidden width %d x %d layers", H, NH);
   return cvf_check_launch("ef_bwd_mfma_kernel");

@@ -24,14 +24,40 @@ struct Tables {
   const float* ref_c;
 };
 __host__ __device__ inline int tables_dwords(const cvf_pp_desc& pp) { return 6 * pp.n_rec + 4 * pp.n_align; }
-__device__ __forceinline__ Tables stage_tables(const cvf_pp_desc& pp, float* lds, int lane) {
-  int32_t* recL = reinterpret_cast<int32_t*>(lds);
-  int32_t* alL = recL + 6 * pp.n_rec;
-  float* refL = reinterpret_cast<float*>(alL + pp.n_align);
-  for (int i = lane; i < 6 * pp.n_rec; i += CVF_WAVE) recL[i] = pp.rec[i];
-  for (int i = lane; i < pp.n_align; i += CVF_WAVE) alL[i] = pp.align_idx[i];
-  for (int i = lane; i < 3 * pp.n_align; i += CVF_WAVE) refL[i] = pp.ref_c[i];
-  return Tables{recL, alL, refL};
+// Word i of the concatenated tables [rec | align_idx | ref_c], read from global memory by one unconditional load.
+__device__ __forceinline__ int32_t table_word(const cvf_pp_desc& pp, int i) {
+  const int n1 = 6 * pp.n_rec, n2 = n1 + pp.n_align;
+  const int32_t* p = i < n1 ? pp.rec + i
+                            : (i < n2 ? pp.align_idx + (i - n1) : reinterpret_cast<const int32_t*>(pp.ref_c) + (i - n2));
+  return *p;
+}
+// The first kTablePre words per lane are fetched into registers *before* the coordinate tile is staged, so their
+// round trip overlaps the tile's instead of following it; tables_commit writes them (and any remainder) to LDS.
+constexpr int kTablePre = 4;
+struct TablePrefetch {
+  int32_t w[kTablePre];
+};
+__device__ __forceinline__ TablePrefetch tables_prefetch(const cvf_pp_desc& pp, int lane) {
+  const int n = tables_dwords(pp);
+  TablePrefetch tp;
+#pragma unroll
+  for (int i = 0; i < kTablePre; ++i) {
+    const int j = lane + CVF_WAVE * i;
+    tp.w[i] = table_word(pp, j < n ? j : n - 1);
+  }
+  return tp;
+}
+__device__ __forceinline__ Tables tables_commit(const cvf_pp_desc& pp, const TablePrefetch& tp, float* lds, int lane) {
+  const int n = tables_dwords(pp);
+  int32_t* L = reinterpret_cast<int32_t*>(lds);
+#pragma unroll
+  for (int i = 0; i < kTablePre; ++i) {
+    const int j = lane + CVF_WAVE * i;
+    if (j < n) L[j] = tp.w[i];
+  }
+  for (int j = lane + CVF_WAVE * kTablePre; j < n; j += CVF_WAVE) L[j] = table_word(pp, j);
+  int32_t* alL = L + 6 * pp.n_rec;
+  return Tables{L, alL, reinterpret_cast<const float*>(alL + pp.n_align)};
 }
 __device__ __forceinline__ V3 atom(const float* my, int a) { return V3{my[3 * a], my[3 * a + 1], my[3 * a + 2]}; }
 
@@ -41,37 +67,57 @@ __device__ __forceinline__ V3 atom(const float* my, int a) { return V3{my[3 * a]
 template <bool CONTIG>
 __device__ __forceinline__ void align_lane(const cvf_pp_desc& pp, const Tables& tb, const float* my, double (&c)[3],
                                            KabschOut& ko) {
-  double cx = 0, cy = 0, cz = 0;
-#pragma unroll 4
+  // One pass: H = sum_b (x_b - c) r_b^T = sum_b x_b r_b^T - c (sum_b r_b)^T, and the reference is stored centred,
+  // so the second term is n_align * c * (fp32 rounding residue of the reference's mean)^T - kept, it costs nothing.
+  double cx = 0, cy = 0, cz = 0, rs0 = 0, rs1 = 0, rs2 = 0;
+  double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll 2
   for (int b = 0; b < pp.n_align; ++b) {
     const int a = CONTIG ? b : tb.align_idx[b];
-    cx += (double)my[3 * a];
-    cy += (double)my[3 * a + 1];
-    cz += (double)my[3 * a + 2];
+    const double x0 = (double)my[3 * a], x1 = (double)my[3 * a + 1], x2 = (double)my[3 * a + 2];
+    const double r0 = (double)tb.ref_c[3 * b], r1 = (double)tb.ref_c[3 * b + 1], r2 = (double)tb.ref_c[3 * b + 2];
+    cx += x0; cy += x1; cz += x2;
+    rs0 += r0; rs1 += r1; rs2 += r2;
+    H[0][0] = fma(x0, r0, H[0][0]); H[0][1] = fma(x0, r1, H[0][1]); H[0][2] = fma(x0, r2, H[0][2]);
+    H[1][0] = fma(x1, r0, H[1][0]); H[1][1] = fma(x1, r1, H[1][1]); H[1][2] = fma(x1, r2, H[1][2]);
+    H[2][0] = fma(x2, r0, H[2][0]); H[2][1] = fma(x2, r1, H[2][1]); H[2][2] = fma(x2, r2, H[2][2]);
   }
   const double inv = fast_rcp((double)pp.n_align);
   c[0] = cx * inv;
   c[1] = cy * inv;
   c[2] = cz * inv;
-  double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll 2
-  for (int b = 0; b < pp.n_align; ++b) {
-    const int a = CONTIG ? b : tb.align_idx[b];
-    const double xc0 = (double)my[3 * a] - c[0], xc1 = (double)my[3 * a + 1] - c[1], xc2 = (double)my[3 * a + 2] - c[2];
-    const double r0 = (double)tb.ref_c[3 * b], r1 = (double)tb.ref_c[3 * b + 1], r2 = (double)tb.ref_c[3 * b + 2];
-    H[0][0] += xc0 * r0; H[0][1] += xc0 * r1; H[0][2] += xc0 * r2;
-    H[1][0] += xc1 * r0; H[1][1] += xc1 * r1; H[1][2] += xc1 * r2;
-    H[2][0] += xc2 * r0; H[2][1] += xc2 * r1; H[2][2] += xc2 * r2;
-  }
+  const double rs[3] = {rs0, rs1, rs2};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) H[i][j] = fma(-c[i], rs[j], H[i][j]);
+  CVF_STAMP(3);
   kabsch_from_H(H, ko);
+  CVF_STAMP(4);
 }
 
-__device__ __forceinline__ V3 centred(const float* my, int a, const double (&c)[3]) {
-  return V3{(float)((double)my[3 * a] - c[0]), (float)((double)my[3 * a + 1] - c[1]),
-            (float)((double)my[3 * a + 2] - c[2])};
+// x - c in fp32 with the centroid as a (hi, lo) pair of floats: two roundings of the result's own ulp, no
+// fp64 conversions in the per-atom loops (v_cvt_f64_f32 / v_cvt_f32_f64 are quarter-rate).
+struct Centre {
+  float hi[3], lo[3];
+};
+__device__ __forceinline__ Centre centre_of(const double (&c)[3]) {
+  Centre ce;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    ce.hi[i] = (float)c[i];
+    ce.lo[i] = (float)(c[i] - (double)ce.hi[i]);
+  }
+  return ce;
+}
+__device__ __forceinline__ Centre centre_of(float c0, float c1, float c2) { return Centre{{c0, c1, c2}, {0.0f, 0.0f, 0.0f}}; }
+__device__ __forceinline__ V3 centred(const float* my, int a, const Centre& c) {
+  return V3{(my[3 * a] - c.hi[0]) - c.lo[0], (my[3 * a + 1] - c.hi[1]) - c.lo[1], (my[3 * a + 2] - c.hi[2]) - c.lo[2]};
 }
 
-template <bool FAST>
+// TILED / ROWS: which of the two output layouts is written - compile-time, because a run-time `if (ft)` around
+// each of the d_r stores became an exec-mask branch per store (2/3 of the feature loop's time).
+template <bool FAST, bool TILED, bool ROWS>
 __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
                                                        float* __restrict__ feat_tiled, float* __restrict__ feat_rows,
                                                        float* __restrict__ aux_tiled) {
@@ -79,28 +125,35 @@ __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const floa
   const int lane = threadIdx.x;
   const int64_t tile = blockIdx.x;
   const int nc = pp.n_coord;
+  CVF_STAMP(0);
+  const TablePrefetch tp = tables_prefetch(pp, lane);
   load_x_tile(x, B, nc, tile, lds, lane);
-  const Tables tb = stage_tables(pp, lds + CVF_TILE * x_tile_stride(nc), lane);
+  CVF_STAMP(1);
+  const Tables tb = tables_commit(pp, tp, lds + CVF_TILE * x_tile_stride(nc), lane);
   __syncthreads();
+  CVF_STAMP(2);
   const float* my = lds + lane * x_tile_stride(nc);
-  double c[3];
+  double cd[3];
   KabschOut ko;
-  align_lane<FAST>(pp, tb, my, c, ko);
+  align_lane<FAST>(pp, tb, my, cd, ko);
+  const Centre c = centre_of(cd);
+  CVF_STAMP(5);
   if (aux_tiled) {
     float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
 #pragma unroll
     for (int i = 0; i < 9; ++i) ax[i * CVF_TILE] = ko.R[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ax[(9 + i) * CVF_TILE] = (float)c[i];
+    for (int i = 0; i < 3; ++i) ax[(9 + i) * CVF_TILE] = c.hi[i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) ax[(12 + i) * CVF_TILE] = ko.Kinv[i];
   }
   const int64_t frame = tile * CVF_TILE + lane;
-  float* ft = feat_tiled ? feat_tiled + tile * pp.d_r * CVF_TILE + lane : nullptr;
-  float* fr = (feat_rows && frame < B) ? feat_rows + frame * pp.d_r : nullptr;
+  float* ft = TILED ? feat_tiled + tile * pp.d_r * CVF_TILE + lane : nullptr;
+  // frames past B (tail tile) write their row into the last valid frame's slot: same value, no predicate
+  float* fr = ROWS ? feat_rows + (frame < B ? frame : B - 1) * pp.d_r : nullptr;
   auto emit = [&](int o, float v) {
-    if (ft) ft[o * CVF_TILE] = v;
-    if (fr) fr[o] = v;
+    if (TILED) ft[o * CVF_TILE] = v;
+    if (ROWS) fr[o] = v;
   };
   if (FAST) {  // CVF_PP_PURE_POSITION: record r = position of atom r -> outputs 3r..3r+2
 #pragma unroll 4
@@ -110,6 +163,7 @@ __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const floa
       emit(3 * a + 1, al.y);
       emit(3 * a + 2, al.z);
     }
+    CVF_STAMP(6);
     return;
   }
 #pragma unroll 2
@@ -166,21 +220,20 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
   const int net = blockIdx.y;
   const int nc = pp.n_coord;
   const int stride = x_tile_stride(nc);
+  const TablePrefetch tp = tables_prefetch(pp, lane);
   load_x_tile(x, B, nc, tile, lds, lane);
   float* Gl = lds + CVF_TILE * stride + lane;  // G(j) = Gl[j*64]
   for (int j = 0; j < nc; ++j) Gl[j * CVF_TILE] = 0.0f;
-  const Tables tb = stage_tables(pp, lds + CVF_TILE * (stride + nc), lane);
+  const Tables tb = tables_commit(pp, tp, lds + CVF_TILE * (stride + nc), lane);
   float* aL = lds + CVF_TILE * (stride + nc) + tables_dwords(pp);   // diag_coeff, staged like the tables
   for (int i = lane; i < nc; i += CVF_WAVE) aL[i] = a[i];
   __syncthreads();
   const float* my = lds + lane * stride;
   const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
   float R[9], Kinv[6];
-  double c[3];
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = ax[i * CVF_TILE];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) c[i] = (double)ax[(9 + i) * CVF_TILE];
+  const Centre c = centre_of(ax[9 * CVF_TILE], ax[10 * CVF_TILE], ax[11 * CVF_TILE]);
 #pragma unroll
   for (int i = 0; i < 6; ++i) Kinv[i] = ax[(12 + i) * CVF_TILE];
   const int64_t base = (tile * k + net) * (int64_t)pp.d_r * CVF_TILE + lane;
@@ -343,11 +396,9 @@ __global__ __launch_bounds__(64) void metric_pure_kernel(cvf_pp_desc pp, const f
   const float* my = lds + lane * stride;
   const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
   float R[9], Kinv[6];
-  double c[3];
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = ax[i * CVF_TILE];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) c[i] = (double)ax[(9 + i) * CVF_TILE];
+  const Centre c = centre_of(ax[9 * CVF_TILE], ax[10 * CVF_TILE], ax[11 * CVF_TILE]);
 #pragma unroll
   for (int i = 0; i < 6; ++i) Kinv[i] = ax[(12 + i) * CVF_TILE];
   const int64_t base = (tile * k + net) * (int64_t)pp.d_r * CVF_TILE + lane;
@@ -486,17 +537,22 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
   }
   const size_t lds = ((size_t)CVF_TILE * x_tile_stride(pp->n_coord) + tables_dwords(*pp)) * sizeof(float);
   CVF_REQUIRE(lds <= 160 * 1024, "frames of %d coordinates do not fit the lane-per-frame kernel's LDS tile", pp->n_coord);
-  if (lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)k1_align_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)k1_align_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
   const bool fast = (pp->flags & (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION)) == (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION);
-  if (fast) {
+  if (fast)
     CVF_REQUIRE(pp->d_r == 3 * pp->n_rec && 3 * pp->n_rec <= pp->n_coord && pp->n_align * 3 <= pp->n_coord,
                 "cvf_align_feature_fwd: flags do not match the descriptor");
-    hipLaunchKernelGGL(k1_align_kernel<true>, dim3((unsigned)T), dim3(64), lds, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled);
-  } else {
-    hipLaunchKernelGGL(k1_align_kernel<false>, dim3((unsigned)T), dim3(64), lds, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled);
+  auto launch = [&](auto kernel) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)T), dim3(64), lds, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled);
+  };
+  const int variant = (fast ? 4 : 0) | (feat_tiled ? 2 : 0) | (feat_rows ? 1 : 0);
+  switch (variant) {
+    case 1: launch(k1_align_kernel<false, false, true>); break;
+    case 2: launch(k1_align_kernel<false, true, false>); break;
+    case 3: launch(k1_align_kernel<false, true, true>); break;
+    case 5: launch(k1_align_kernel<true, false, true>); break;
+    case 6: launch(k1_align_kernel<true, true, false>); break;
+    default: launch(k1_align_kernel<true, true, true>); break;
   }
   return cvf_check_launch("k1_align_kernel");
 }
