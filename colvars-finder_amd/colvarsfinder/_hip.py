@@ -57,6 +57,10 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     "cvf_metric_apply": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_metric_stats_scratch_doubles": (C.c_int64, [C.c_int64, C.c_int]),
+    "cvf_metric_apply_stats": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(EFCfg), C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_metric_dense_tensors": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_pack_floats": (C.c_int64, [C.POINTER(MLPDesc)]),
     "cvf_ef_pack": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -281,7 +281,8 @@ class _EFWorkspace:
             self.e = torch.empty(T * k * _hip.TILE, **f32)
         else:
             self.g = self.q = self.e = None
-        self.scratch = torch.empty(lib.cvf_ef_stats_scratch_doubles(k, lag), **f64)
+        self.scratch = torch.zeros(lib.cvf_metric_stats_scratch_doubles(B, k) if lag == 0 else
+                                   lib.cvf_ef_stats_scratch_doubles(k, lag), **f64)
         self.stats = torch.empty(lib.cvf_ef_nstats(k, lag), **f64)
         self.loss_vec = torch.empty(3 + 2 * k, **f64)
         self.coef = torch.empty(4 * k + k * k, **f64)
@@ -396,14 +397,12 @@ class EigenFunctionTask(TrainingTask):
                        P(ws.k1_scratch), s)
         self._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(ws.y),
                    P(ws.g) if lag == 0 else None, s)
-        if lag == 0:
-            self._call("cvf_metric_apply", lib.cvf_metric_apply, self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), k,
-                       P(ws.g), P(ws.q), P(ws.e), P(ws.k1_scratch), P(self._dense), s)
         single = _dist.world() == 1   # no cross-rank reduction: the loss tail runs inside the stats launch
         lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
-        if lag == 0:
-            self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), P(ws.e), None, None, P(ws.scratch),
-                       P(ws.stats), lv, cf, s)
+        if lag == 0:   # q = J A J^T g, E, and the batch sums (K2/K3 + K5) in one launch
+            self._call("cvf_metric_apply", lib.cvf_metric_apply_stats, self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), k,
+                       P(ws.g), P(ws.q), P(ws.e), P(ws.k1_scratch), P(self._dense), self._cfg, P(w), P(ws.y),
+                       P(ws.scratch), P(ws.stats), lv, cf, s)
         else:
             y_lag = ws.y[ws.T * k * _hip.TILE:]
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), None, P(w_lag), P(y_lag),

@@ -22,15 +22,42 @@ static inline int64_t cvf_ntiles(int64_t B) { return (B + CVF_TILE - 1) / CVF_TI
 // ------------------------------------------------------------------------------------
 // wave helpers
 // ------------------------------------------------------------------------------------
+// Wave-wide sums on the DPP cross-lane path (no LDS crossbar round trips): an inclusive scan inside each row of 16
+// lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then row_bcast:15 / row_bcast:31 carry
+// the row totals into lane 63, whose value is broadcast through an SGPR.  The order of the additions is fixed, so the
+// result is reproducible run to run; every lane receives the total.  (__shfl_xor compiles to ds_bpermute_b32: six
+// dependent ~100-cycle hops per sum, twice that for a double.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_movf(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_movd(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_movd<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_movd<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_movd<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_movd<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row holds the row's sum
+  v += dpp_movd<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_movd<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ float wave_sumf(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_movf<0x111, 0xf>(v);
+  v += dpp_movf<0x112, 0xf>(v);
+  v += dpp_movf<0x114, 0xf>(v);
+  v += dpp_movf<0x118, 0xf>(v);
+  v += dpp_movf<0x142, 0xa>(v);
+  v += dpp_movf<0x143, 0xc>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // tanh in 7 instructions, absolute error ~6e-8 (fp32 rounding of t):  t = exp(-2|x|) in (0,1],
@@ -63,34 +90,36 @@ static __device__ unsigned long long g_stamps[64 * 4096];
 // ------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ int x_tile_stride(int nc) { return nc | 1; }
 
+// `tid` of `nthreads` (a multiple of 64) threads share the work; callers follow with a barrier.
 __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int64_t B, int nc, int64_t tile, float* lds,
-                                            int lane) {
+                                            int tid, int nthreads = CVF_WAVE) {
   const int stride = x_tile_stride(nc);
   const int64_t f0 = tile * CVF_TILE;
   const int total = CVF_TILE * nc;
   if (f0 + CVF_TILE <= B) {
     const float4* src = reinterpret_cast<const float4*>(x + f0 * nc);  // 64*nc*4 B tiles are 16-B aligned
     const int nvec = total >> 2;                                       // total is a multiple of 64
-    // (frame, j) of element 4*v advance incrementally: +256 elements per iteration
-    int e = lane * 4;
+    // (frame, j) of element 4*v advance incrementally: +4*nthreads elements per iteration
+    int e = tid * 4;
     int fr = e / nc;
     int j = e - fr * nc;
-    const int dfr = 256 / nc, dj = 256 - dfr * nc;
+    const int step = 4 * nthreads;
+    const int dfr = step / nc, dj = step - dfr * nc;
     // Batches of kBatch 16-byte loads are issued back to back before the first LDS write: this wave is usually
     // alone on its SIMD, and a load -> wait -> write loop paid one full memory round trip per 1 KiB of the tile
     // (17 of them for 22 atoms).  Indices are clamped instead of
     // predicated so the loads stay unconditional (counted waits).
     constexpr int kBatch = 18;
-    for (int v0 = lane; v0 < nvec; v0 += CVF_WAVE * kBatch) {
+    for (int v0 = tid; v0 < nvec; v0 += nthreads * kBatch) {
       float4 val[kBatch];
 #pragma unroll
       for (int i = 0; i < kBatch; ++i) {
-        const int v = v0 + CVF_WAVE * i;
+        const int v = v0 + nthreads * i;
         val[i] = src[v < nvec ? v : nvec - 1];
       }
 #pragma unroll
       for (int i = 0; i < kBatch; ++i) {
-        if (v0 + CVF_WAVE * i < nvec) {
+        if (v0 + nthreads * i < nvec) {
           int f = fr, jj = j;
           lds[f * stride + jj] = val[i].x;
           if (++jj == nc) { jj = 0; ++f; }
@@ -106,7 +135,7 @@ __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int64_t
       }
     }
   } else {
-    for (int e = lane; e < total; e += CVF_WAVE) {
+    for (int e = tid; e < total; e += nthreads) {
       int fr = e / nc;
       int j = e - fr * nc;
       int64_t src = f0 + fr;

@@ -371,51 +371,131 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
   }
 }
 
-// Same result for the common layer (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION: every atom emits its aligned
-// position, the align atoms are the first n_align atoms): three passes over the atoms with NO read-modify-write
-// of a per-atom array - G_a is recomputed from g_a where it is needed - so all loads of a pass are independent
-// and the waits of a single resident wave overlap instead of adding up.
-__global__ __launch_bounds__(64) void metric_pure_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
-                                                          const float* __restrict__ aux_tiled,
-                                                          const float* __restrict__ a, int k,
-                                                          const float* __restrict__ g_tiled,
-                                                          float* __restrict__ q_tiled, float* __restrict__ e_tiled) {
+// ------------------------------------------------------------------------------------
+// metric, fast path (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION): feature 3a..3a+2 = aligned position of atom a,
+// align atom b = atom b.  Block = one 64-frame tile x `wpb` nets (one wave per net): the waves stage the
+// coordinate tile together, once, and each keeps its own [3N][64] image U in LDS that first holds g, then
+// u = a .* G.  Three passes, none with a read-modify-write of LDS or a re-read of global memory:
+//   1  g -> U, sum_a R g_a, M = sum_a xc_a (x) g_a            (g prefetched one chunk of atoms ahead)
+//   2  G_a = R g_a [+ Z ref_a - shift], E, u_a -> U, sums for the rotation's tangent   (LDS only)
+//   3  q_a = (u_a - ubar) R + xc_a dR                          (LDS -> global)
+// ------------------------------------------------------------------------------------
+constexpr int kGChunk = 8;   // atoms per prefetch chunk of pass 1
+
+// Fused first stage of K5: every block also reduces its tile's contribution to the batch sums of
+// EigenFunctionTask.loss_func into one row of `partial` (fp64, fixed DPP order); cvf_ef_stats_finish (stats.hip)
+// adds the rows in a fixed order - the separate pass over w, y and E and its launch are gone.
+// (A last-block-done epilogue that also finished the sum and the loss tail in this launch was measured and dropped:
+// 313 returning atomics on one counter serialise to ~7 us, more than the launch boundary it saves.)
+struct MetricFuse {
+  int on;
+  int ns;
+  const float* w;
+  const float* y_tiled;
+  double* partial;       // [T][ns]
+};
+constexpr int kFuseMaxTiles = 1024;   // above this the row sum of the finishing kernel would be too serial
+
+__global__ __launch_bounds__(512) void metric_pure_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
+                                                           const float* __restrict__ aux_tiled,
+                                                           const float* __restrict__ a, int k,
+                                                           const float* __restrict__ g_tiled,
+                                                           float* __restrict__ q_tiled, float* __restrict__ e_tiled,
+                                                           MetricFuse fuse) {
   extern __shared__ float lds[];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int64_t tile = blockIdx.x;
-  const int net = blockIdx.y;
+  const int net = blockIdx.y * (nthreads >> 6) + wave;   // the host launches wpb | k, so net < k
   const int nc = pp.n_coord, N = pp.n_rec, nal = pp.n_align;
   const int stride = x_tile_stride(nc);
-  load_x_tile(x, B, nc, tile, lds, lane);
-  float* Ul = lds + CVF_TILE * stride + lane;                        // u(j) = Ul[j*64]
-  float* refL = lds + CVF_TILE * (stride + nc);                      // [3*nal]
-  float* aL = refL + 3 * nal;                                        // [nc]
-  for (int i = lane; i < 3 * nal; i += CVF_WAVE) refL[i] = pp.ref_c[i];
-  for (int i = lane; i < nc; i += CVF_WAVE) aL[i] = a[i];
-  __syncthreads();
-  const float* my = lds + lane * stride;
+  float* refL = lds + CVF_TILE * stride;                              // [3*nal]
+  float* aL = refL + 3 * nal;                                         // [nc]
+  float* Ul = aL + nc + (size_t)wave * nc * CVF_TILE + lane;          // this wave's image: U(j) = Ul[j*64]
+  CVF_STAMP(8);
+  // everything the passes need from global memory besides g is requested before the tile is staged
   const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
-  float R[9], Kinv[6];
+  float auxv[CVF_AUX_ROWS];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = ax[i * CVF_TILE];
-  const Centre c = centre_of(ax[9 * CVF_TILE], ax[10 * CVF_TILE], ax[11 * CVF_TILE]);
+  for (int i = 0; i < CVF_AUX_ROWS; ++i) auxv[i] = ax[i * CVF_TILE];
+  float wv = 0.0f, yv[CVF_MAX_NETS];
+  if (fuse.on) {
+    const int64_t frame = tile * CVF_TILE + lane;
+    wv = fuse.w[frame < B ? frame : B - 1];
+    if (frame >= B) wv = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) Kinv[i] = ax[(12 + i) * CVF_TILE];
+    for (int j = 0; j < CVF_MAX_NETS; ++j) yv[j] = fuse.y_tiled[(tile * k + (j < k ? j : k - 1)) * CVF_TILE + lane];
+  }
+  const int ntab = 3 * nal + nc;
+  float tabv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = tid + nthreads * i;
+    const int jc = j < ntab ? j : ntab - 1;
+    tabv[i] = jc < 3 * nal ? pp.ref_c[jc] : a[jc - 3 * nal];
+  }
+  // ... including the first chunk of g
+  const int N0 = pp.n_rec;
   const int64_t base = (tile * k + net) * (int64_t)pp.d_r * CVF_TILE + lane;
   const float* gt = g_tiled + base;
   float* qt = q_tiled + base;
-  // pass 1: sum of p_a = R g_a and M = sum xc_a (x) g_a
+  // atoms past N (tail of the last chunk) are clamped to atom N-1 and masked out of the sums: no branch per atom,
+  // so the LDS reads and the arithmetic of a chunk's eight atoms interleave
+  float cur[3 * kGChunk], nxt[3 * kGChunk];
+#pragma unroll
+  for (int i = 0; i < kGChunk; ++i) {
+    const int at = i < N0 ? i : N0 - 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) cur[3 * i + d] = gt[(3 * at + d) * CVF_TILE];
+  }
+  load_x_tile(x, B, nc, tile, lds, tid, nthreads);
+  CVF_STAMP(9);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = tid + nthreads * i;
+    if (j < ntab) refL[j] = tabv[i];
+  }
+  for (int j = tid + 2 * nthreads; j < ntab; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : a[j - 3 * nal];
+  __syncthreads();
+  const float* my = lds + lane * stride;
+  float R[9], Kinv[6];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = auxv[i];
+  const Centre c = centre_of(auxv[9], auxv[10], auxv[11]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Kinv[i] = auxv[12 + i];
+  CVF_STAMP(10);
+  // pass 1
   V3 sump = v3(0, 0, 0);
   float M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-  for (int at = 0; at < N; ++at) {
-    const V3 g = v3(gt[(3 * at) * CVF_TILE], gt[(3 * at + 1) * CVF_TILE], gt[(3 * at + 2) * CVF_TILE]);
-    sump = sump + mat_times(R, g);
-    const V3 xc = centred(my, at, c);
-    M[0] += xc.x * g.x; M[1] += xc.x * g.y; M[2] += xc.x * g.z;
-    M[3] += xc.y * g.x; M[4] += xc.y * g.y; M[5] += xc.y * g.z;
-    M[6] += xc.z * g.x; M[7] += xc.z * g.y; M[8] += xc.z * g.z;
+  const int nchunk = (N + kGChunk - 1) / kGChunk;
+  for (int ch = 0; ch < nchunk; ++ch) {
+#pragma unroll
+    for (int i = 0; i < kGChunk; ++i) {   // next chunk: clamped, unconditional
+      const int an = kGChunk * (ch + 1) + i;
+      const int at = an < N ? an : N - 1;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) nxt[3 * i + d] = gt[(3 * at + d) * CVF_TILE];
+    }
+#pragma unroll
+    for (int i = 0; i < kGChunk; ++i) {
+      const int an = kGChunk * ch + i;
+      const int at = an < N ? an : N - 1;
+      const float m = an < N ? 1.0f : 0.0f;
+      const V3 g = v3(cur[3 * i], cur[3 * i + 1], cur[3 * i + 2]);
+      Ul[(3 * at) * CVF_TILE] = g.x;   // (a clamped atom rewrites atom N-1's own g)
+      Ul[(3 * at + 1) * CVF_TILE] = g.y;
+      Ul[(3 * at + 2) * CVF_TILE] = g.z;
+      const V3 gm = m * g;
+      sump = sump + mat_times(R, gm);
+      const V3 xc = centred(my, at, c);
+      M[0] += xc.x * gm.x; M[1] += xc.x * gm.y; M[2] += xc.x * gm.z;
+      M[3] += xc.y * gm.x; M[4] += xc.y * gm.y; M[5] += xc.y * gm.z;
+      M[6] += xc.z * gm.x; M[7] += xc.z * gm.y; M[8] += xc.z * gm.z;
+    }
+#pragma unroll
+    for (int i = 0; i < 3 * kGChunk; ++i) cur[i] = nxt[i];
   }
+  CVF_STAMP(11);
   float T[9], Z[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -430,31 +510,55 @@ __global__ __launch_bounds__(64) void metric_pure_kernel(cvf_pp_desc pp, const f
   }
   const float inv_nal = 1.0f / (float)nal;
   const V3 shift = inv_nal * sump;
-  // pass 2: G_a, E, u_a = a .* G_a (kept in LDS, write only), sums for the tangent of the rotation
+  CVF_STAMP(12);
+  // pass 2: align atoms first (they carry the rotation's and the centroid's derivative), then the rest
   float E = 0.0f;
   V3 usum = v3(0, 0, 0), rsum = v3(0, 0, 0);
   float dH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 4
-  for (int at = 0; at < N; ++at) {
-    const V3 g = v3(gt[(3 * at) * CVF_TILE], gt[(3 * at + 1) * CVF_TILE], gt[(3 * at + 2) * CVF_TILE]);
-    V3 G = mat_times(R, g);
-    const bool al = at < nal;
-    const V3 rf = al ? v3(refL[3 * at], refL[3 * at + 1], refL[3 * at + 2]) : v3(0, 0, 0);
-    if (al) G = G + (mat_times(Z, rf) - shift);
+  for (int at = 0; at < nal; ++at) {
+    const V3 g = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
+    const V3 rf = v3(refL[3 * at], refL[3 * at + 1], refL[3 * at + 2]);
+    const V3 G = mat_times(R, g) + (mat_times(Z, rf) - shift);
     const V3 u = v3(aL[3 * at] * G.x, aL[3 * at + 1] * G.y, aL[3 * at + 2] * G.z);
     E += u.x * G.x + u.y * G.y + u.z * G.z;
     Ul[(3 * at) * CVF_TILE] = u.x;
     Ul[(3 * at + 1) * CVF_TILE] = u.y;
     Ul[(3 * at + 2) * CVF_TILE] = u.z;
-    if (al) {
-      usum = usum + u;
-      rsum = rsum + rf;
-      dH[0] += u.x * rf.x; dH[1] += u.x * rf.y; dH[2] += u.x * rf.z;
-      dH[3] += u.y * rf.x; dH[4] += u.y * rf.y; dH[5] += u.y * rf.z;
-      dH[6] += u.z * rf.x; dH[7] += u.z * rf.y; dH[8] += u.z * rf.z;
-    }
+    usum = usum + u;
+    rsum = rsum + rf;
+    dH[0] += u.x * rf.x; dH[1] += u.x * rf.y; dH[2] += u.x * rf.z;
+    dH[3] += u.y * rf.x; dH[4] += u.y * rf.y; dH[5] += u.y * rf.z;
+    dH[6] += u.z * rf.x; dH[7] += u.z * rf.y; dH[8] += u.z * rf.z;
   }
+#pragma unroll 4
+  for (int at = nal; at < N; ++at) {
+    const V3 g = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
+    const V3 G = mat_times(R, g);
+    const V3 u = v3(aL[3 * at] * G.x, aL[3 * at + 1] * G.y, aL[3 * at + 2] * G.z);
+    E += u.x * G.x + u.y * G.y + u.z * G.z;
+    Ul[(3 * at) * CVF_TILE] = u.x;
+    Ul[(3 * at + 1) * CVF_TILE] = u.y;
+    Ul[(3 * at + 2) * CVF_TILE] = u.z;
+  }
+  CVF_STAMP(13);
   e_tiled[(tile * k + net) * CVF_TILE + lane] = E;
+  if (fuse.on) {
+    // this wave's slots of the tile's row: [W | S1(k) | S2(i<=j) | E(k)]  (include/cvf.h)
+    double* row = fuse.partial + tile * (int64_t)fuse.ns;
+    const double wb = (double)wv, yn = (double)yv[net];
+    auto put = [&](int slot, double v) {
+      const double sum = wave_sum(v);
+      if (lane == 0) row[slot] = sum;
+    };
+    if (net == 0) put(0, wb);
+    put(1 + net, wb * yn);
+    const int s2o = 1 + k + net * k - (net * (net - 1)) / 2 - net;   // + j : slot of S2[net][j], j >= net
+#pragma unroll
+    for (int j = 0; j < CVF_MAX_NETS; ++j)
+      if (j >= net && j < k) put(s2o + j, wb * yn * (double)yv[j]);
+    put(1 + k + CVF_NPAIR(k) + net, wb * (double)E);
+  }
   const V3 ubar = inv_nal * usum;
   // dH = sum_b (u_b - ubar) (x) ref_b = dH' - ubar (x) sum_b ref_b
   dH[0] -= ubar.x * rsum.x; dH[1] -= ubar.x * rsum.y; dH[2] -= ubar.x * rsum.z;
@@ -472,7 +576,8 @@ __global__ __launch_bounds__(64) void metric_pure_kernel(cvf_pp_desc pp, const f
     dR[3 * i + 1] = -R[3 * i + 0] * w.z + R[3 * i + 2] * w.x;
     dR[3 * i + 2] = R[3 * i + 0] * w.y - R[3 * i + 1] * w.x;
   }
-  // pass 3: q_a = (u_a - ubar) R + xc_a dR
+  CVF_STAMP(14);
+  // pass 3
 #pragma unroll 4
   for (int at = 0; at < N; ++at) {
     const V3 u = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
@@ -481,6 +586,7 @@ __global__ __launch_bounds__(64) void metric_pure_kernel(cvf_pp_desc pp, const f
     qt[(3 * at + 1) * CVF_TILE] = qa.y;
     qt[(3 * at + 2) * CVF_TILE] = qa.z;
   }
+  CVF_STAMP(15);
 }
 
 __global__ __launch_bounds__(64) void metric_identity_kernel(int d, const float* __restrict__ a, int k,
@@ -506,6 +612,8 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
                         float* aux_tiled, float* slot_xyz, hipStream_t s);
 size_t cvf_k1_large_scratch_bytes(const cvf_pp_desc* pp, int64_t B);
 size_t cvf_metric_large_lds(const cvf_pp_desc* pp);
+int cvf_ef_stats_finish(const cvf_ef_cfg* cfg, int n_rows, const double* partial, double* stats, double* loss_vec, double* coef,
+                        hipStream_t s);
 int cvf_metric_large_launch(const cvf_pp_desc* pp, int64_t B, const float* aux_tiled, const float* a, int k,
                             const float* slot_xyz, const double* dense, const float* g_tiled, float* q_tiled, float* e_tiled,
                             hipStream_t s);
@@ -557,9 +665,10 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
   return cvf_check_launch("k1_align_kernel");
 }
 
-extern "C" int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled,
-                                const float* a, int k, const float* g_tiled, float* q_tiled, float* e_tiled,
-                                const float* slot_xyz, const double* dense, void* stream) {
+static int metric_apply_impl(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled, const float* a,
+                             int k, const float* g_tiled, float* q_tiled, float* e_tiled, const float* slot_xyz,
+                             const double* dense, const MetricFuse& fuse, bool* fused, void* stream) {
+  if (fused) *fused = false;
   CVF_REQUIRE(pp && a && g_tiled && q_tiled && e_tiled && B > 0 && k >= 1 && k <= CVF_MAX_NETS,
               "cvf_metric_apply: bad argument (B=%lld k=%d)", (long long)B, k);
   const int64_t T = cvf_ntiles(B);
@@ -581,17 +690,64 @@ extern "C" int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B
   CVF_REQUIRE(lds <= 160 * 1024, "frames of %d coordinates do not fit the lane-per-frame metric kernel's LDS", pp->n_coord);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)metric_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const bool fast = (pp->flags & (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION)) == (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION);
+  // the three-pass kernel additionally wants every align atom to be a feature atom (atoms 0..n_align-1)
+  const bool fast = (pp->flags & (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION)) == (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION) &&
+                    pp->n_align <= pp->n_rec;
   if (fast) {
-    CVF_REQUIRE(pp->d_r == 3 * pp->n_rec && 3 * pp->n_rec <= pp->n_coord && pp->n_align <= pp->n_rec,
-                "cvf_metric_apply: flags do not match the descriptor");
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)metric_pure_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(metric_pure_kernel, dim3((unsigned)T, k), dim3(64), lds, s, *pp, x, B, aux_tiled, a, k, g_tiled, q_tiled,
-                       e_tiled);
+    CVF_REQUIRE(pp->d_r == 3 * pp->n_rec && 3 * pp->n_rec <= pp->n_coord, "cvf_metric_apply: flags do not match the descriptor");
+    // all k nets of a tile in one block (one staged coordinate tile) when their images fit, else one net per block
+    auto lds_for = [&](int wpb) {
+      return ((size_t)CVF_TILE * x_tile_stride(pp->n_coord) + 3 * (size_t)pp->n_align + pp->n_coord +
+              (size_t)wpb * pp->n_coord * CVF_TILE) * sizeof(float);
+    };
+    const int wpb = lds_for(k) <= 80 * 1024 ? k : 1;
+    const size_t lds_p = lds_for(wpb);
+    CVF_REQUIRE(lds_p <= 160 * 1024, "frames of %d coordinates do not fit the lane-per-frame metric kernel's LDS", pp->n_coord);
+    if (lds_p > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)metric_pure_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+    MetricFuse f = fuse;
+    if (T > kFuseMaxTiles) f.on = 0;
+    hipLaunchKernelGGL(metric_pure_kernel, dim3((unsigned)T, k / wpb), dim3(64 * wpb), lds_p, s, *pp, x, B, aux_tiled, a, k,
+                       g_tiled, q_tiled, e_tiled, f);
+    if (fused) *fused = f.on != 0;
     return cvf_check_launch("metric_pure_kernel");
   }
   hipLaunchKernelGGL(metric_align_kernel, dim3((unsigned)T, k), dim3(64), lds, s, *pp, x, B, aux_tiled, a, k, g_tiled,
                      q_tiled, e_tiled);
   return cvf_check_launch("metric_align_kernel");
+}
+
+extern "C" int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled,
+                                const float* a, int k, const float* g_tiled, float* q_tiled, float* e_tiled,
+                                const float* slot_xyz, const double* dense, void* stream) {
+  MetricFuse none = {};
+  return metric_apply_impl(pp, x, B, aux_tiled, a, k, g_tiled, q_tiled, e_tiled, slot_xyz, dense, none, nullptr, stream);
+}
+
+extern "C" int64_t cvf_metric_stats_scratch_doubles(int64_t B, int k) {
+  return cvf_ntiles(B) * (int64_t)cvf_ef_nstats(k, 0) + cvf_ef_stats_scratch_doubles(k, 0);
+}
+
+extern "C" int cvf_metric_apply_stats(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled,
+                                      const float* a, int k, const float* g_tiled, float* q_tiled, float* e_tiled,
+                                      const float* slot_xyz, const double* dense, const cvf_ef_cfg* cfg, const float* w,
+                                      const float* y_tiled, double* scratch, double* stats, double* loss_vec, double* coef,
+                                      void* stream) {
+  CVF_REQUIRE(cfg && w && y_tiled && scratch && stats, "cvf_metric_apply_stats: bad argument");
+  CVF_REQUIRE(cfg->k == k && cfg->lag_idx == 0, "cvf_metric_apply_stats: generator mode only, cfg.k must equal k");
+  CVF_REQUIRE(loss_vec == nullptr || coef != nullptr, "cvf_metric_apply_stats: loss_vec without coef");
+  const int ns = cvf_ef_nstats(k, 0);
+  const int64_t T = cvf_ntiles(B);
+  MetricFuse f = {};
+  f.on = 1;
+  f.ns = ns;
+  f.w = w;
+  f.y_tiled = y_tiled;
+  f.partial = scratch;
+  bool fused = false;
+  const int rc = metric_apply_impl(pp, x, B, aux_tiled, a, k, g_tiled, q_tiled, e_tiled, slot_xyz, dense, f, &fused, stream);
+  if (rc) return rc;
+  if (fused) return cvf_ef_stats_finish(cfg, (int)T, scratch, stats, loss_vec, coef, (hipStream_t)stream);
+  // shapes without the fused first stage: the two-stage reduction on the rest of the scratch
+  return cvf_ef_stats(cfg, B, w, y_tiled, e_tiled, nullptr, nullptr, scratch + T * ns, stats, loss_vec, coef, stream);
 }

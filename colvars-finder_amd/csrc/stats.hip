@@ -4,6 +4,7 @@
 // tail of the loss (core.py:426-457) with its partial derivatives, and K6: Adam.
 #include "cvf_common.hpp"
 #include "cvf_adam.hpp"
+#include "cvf_loss_tail.hpp"
 #include <stdarg.h>
 #include <stdio.h>
 #include <type_traits>
@@ -37,7 +38,6 @@ extern "C" int cvf_ef_nstats(int k, int lag_idx) {
 namespace {
 
 constexpr int kStatBlocks = 128;
-constexpr int kMaxStats = 1 + CVF_MAX_NETS + CVF_NPAIR(CVF_MAX_NETS) + 1 + 3 * CVF_MAX_NETS;
 
 // one wave per block; block g handles tiles g, g+G, ...; lane = frame.  K is a template
 // parameter so that every accumulator lives in a register (no runtime-indexed arrays).
@@ -93,164 +93,42 @@ __global__ __launch_bounds__(64) void ef_stats_partial_kernel(int64_t B, const f
   }
 }
 
-// second stage: stat i is summed by 8 threads (strided over the partial rows), then the 8 sub-sums
-// are added in a fixed order -> bitwise reproducible
-__global__ void ef_stats_final_kernel(int ns, int nblocks, const double* __restrict__ partial, double* __restrict__ stats) {
-  __shared__ double sub[8 * kMaxStats];
-  const int j = threadIdx.x & 7, i = threadIdx.x >> 3;
-  if (i < ns) {
-    double s = 0.0;
-    for (int g = j; g < nblocks; g += 8) s += partial[(int64_t)g * ns + i];
-    sub[i * 8 + j] = s;
-  }
-  __syncthreads();
-  if (i < ns && j == 0) {
-    double s = 0.0;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) s += sub[i * 8 + t];
-    stats[i] = s;
-  }
-}
-
-// the scalar tail of loss_func, one thread, fp64
-template <int KT>
-__device__ void ef_loss_tail(const cvf_ef_cfg& cfg, const double* __restrict__ stats, double* __restrict__ loss_vec,
-                             double* __restrict__ coef) {
-  constexpr int k = KT;
-  const int npair = CVF_NPAIR(k);
-  const double W = stats[0];
-  const double* S1 = stats + 1;
-  const double* S2 = stats + 1 + k;
-  double m[KT], v[KT], s2[KT][KT];
-  {
-    int p = 0;
-    for (int i = 0; i < k; ++i)
-      for (int j = i; j < k; ++j) {
-        s2[i][j] = s2[j][i] = S2[p++];
-      }
-  }
-  for (int i = 0; i < k; ++i) {
-    m[i] = S1[i] / W;                       // core.py:409
-    v[i] = s2[i][i] / W - m[i] * m[i];      // core.py:410
-  }
-  double eig[KT], num[KT], den[KT];
-  double pref;
-  double vl[KT], ml[KT], Wl = 1.0;
-  const int o = 1 + k + npair;
-  if (cfg.lag_idx == 0) {
-    pref = 1.0 / (W * cfg.beta);            // core.py:426,438
-    for (int i = 0; i < k; ++i) {
-      num[i] = stats[o + i];
-      den[i] = v[i];
-      eig[i] = pref * num[i] / den[i];
-    }
-  } else {
-    Wl = stats[o];
-    for (int i = 0; i < k; ++i) {
-      ml[i] = stats[o + 1 + i] / Wl;                          // core.py:415
-      vl[i] = stats[o + 1 + k + i] / Wl - ml[i] * ml[i];      // core.py:416
-      num[i] = stats[o + 1 + 2 * k + i];
-      den[i] = v[i] + vl[i];
-    }
-    pref = 1.0 / (cfg.dt * cfg.lag_idx) / W;                  // core.py:428,440
-    for (int i = 0; i < k; ++i) eig[i] = pref * num[i] / den[i];
-  }
-  // cvec = argsort(eig) (core.py:432), stable insertion sort
-  int cvec[KT];
-#pragma unroll
-  for (int i = 0; i < k; ++i) cvec[i] = i;
-  if (cfg.sort_eigvals) {
-    for (int i = 1; i < k; ++i) {
-      const int c = cvec[i];
-      int j = i - 1;
-      while (j >= 0 && eig[cvec[j]] > eig[c]) {
-        cvec[j + 1] = cvec[j];
-        --j;
-      }
-      cvec[j + 1] = c;
-    }
-  }
-  // variational objective; generator: numerator AND denominator at cvec[idx] (core.py:438);
-  // transfer: numerator at idx, denominator at cvec[idx] (core.py:440, reproduced as is)
-  double npl = 0.0;
-  double gnum[KT], gden[KT];
-  for (int i = 0; i < k; ++i) gnum[i] = gden[i] = 0.0;
-  for (int idx = 0; idx < k; ++idx) {
-    const int c = cvec[idx];
-    const int nsrc = cfg.lag_idx == 0 ? c : idx;
-    npl += cfg.eig_w[idx] * num[nsrc] / den[c];
-    gnum[nsrc] += pref * cfg.eig_w[idx] / den[c];
-    gden[c] += -pref * cfg.eig_w[idx] * num[nsrc] / (den[c] * den[c]);
-  }
-  npl *= pref;
-  double pen = 0.0;
-  double cov[KT][KT];
-  for (int i = 0; i < k; ++i) pen += (v[i] - 1.0) * (v[i] - 1.0);           // core.py:446
-  for (int i = 0; i < k; ++i)
-    for (int j = i + 1; j < k; ++j) {
-      cov[i][j] = cov[j][i] = s2[i][j] / W - m[i] * m[j];                   // core.py:452
-      pen += cov[i][j] * cov[i][j];
-    }
-  const double loss = npl + cfg.alpha * pen;                                // core.py:455
-  loss_vec[0] = loss;
-  loss_vec[1] = npl;
-  loss_vec[2] = pen;
-  for (int idx = 0; idx < k; ++idx) {
-    loss_vec[3 + idx] = eig[cvec[idx]];                                     // core.py:434
-    loss_vec[3 + k + idx] = (double)cvec[idx];
-  }
-  // ---- partial derivatives (eigenvalues and cvec are constants: core.py:426,428 detach them)
-  double* gS1 = coef;
-  double* gS2 = coef + k;
-  double* gEt = coef + k + k * k;
-  double* gS1l = coef + 2 * k + k * k;
-  double* gS2l = coef + 3 * k + k * k;
-  for (int i = 0; i < k; ++i) {
-    const double Lv = gden[i] + 2.0 * cfg.alpha * (v[i] - 1.0);   // d loss / d var_i
-    double g1 = Lv * (-2.0 * m[i] / W);
-    for (int j = 0; j < k; ++j)
-      if (j != i) g1 += 2.0 * cfg.alpha * cov[i][j] * (-m[j] / W);
-    gS1[i] = g1;
-    for (int j = 0; j < k; ++j) gS2[i * k + j] = (i == j) ? Lv / W : 2.0 * cfg.alpha * cov[i][j] / W;
-    gEt[i] = gnum[i];
-    if (cfg.lag_idx > 0) {
-      const double Lvl = gden[i];                                 // d loss / d var'_i
-      gS1l[i] = Lvl * (-2.0 * ml[i] / Wl);
-      gS2l[i] = Lvl / Wl;
-    } else {
-      gS1l[i] = 0.0;
-      gS2l[i] = 0.0;
-    }
-  }
-}
-
 template <int KT>
 __global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats, double* __restrict__ loss_vec,
                                double* __restrict__ coef) {
   if (threadIdx.x == 0 && blockIdx.x == 0) ef_loss_tail<KT>(cfg, stats, loss_vec, coef);
 }
 
-// single-process fast path: second reduction stage and the scalar tail in ONE launch
+// Second reduction stage (+ the scalar tail when loss_vec != NULL, i.e. no cross-rank reduction in between) in ONE
+// launch.  Stat i is summed by one wave: lane l adds rows l, l+64, ... (loads issued eight at a time), the 64 lane
+// sums are combined by the fixed-order DPP reduction -> bitwise reproducible for a given number of rows.
 template <int KT>
-__global__ void ef_stats_final_loss_kernel(cvf_ef_cfg cfg, int ns, int nblocks, const double* __restrict__ partial,
-                                           double* __restrict__ stats, double* __restrict__ loss_vec,
-                                           double* __restrict__ coef) {
-  __shared__ double sub[8 * kMaxStats];
+__global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, int ns, int n_rows,
+                                                               const double* __restrict__ partial,
+                                                               double* __restrict__ stats, double* __restrict__ loss_vec,
+                                                               double* __restrict__ coef) {
   __shared__ double fin[kMaxStats];
-  const int j = threadIdx.x & 7, i = threadIdx.x >> 3;
-  if (i < ns) {
-    double s = 0.0;
-    for (int g = j; g < nblocks; g += 8) s += partial[(int64_t)g * ns + i];
-    sub[i * 8 + j] = s;
-  }
-  __syncthreads();
-  if (i < ns && j == 0) {
-    double s = 0.0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  constexpr int kRows = 8;
+  for (int i = wave; i < ns; i += nw) {
+    double acc = 0.0;
+    for (int g0 = lane; g0 < n_rows; g0 += CVF_WAVE * kRows) {
+      double v[kRows];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) s += sub[i * 8 + t];
-    fin[i] = s;
-    stats[i] = s;
+      for (int b = 0; b < kRows; ++b) {
+        const int g = g0 + CVF_WAVE * b;
+        v[b] = partial[(int64_t)(g < n_rows ? g : n_rows - 1) * ns + i];
+      }
+#pragma unroll
+      for (int b = 0; b < kRows; ++b) acc += (g0 + CVF_WAVE * b < n_rows) ? v[b] : 0.0;
+    }
+    const double sum = wave_sum(acc);
+    if (lane == 0) {
+      fin[i] = sum;
+      stats[i] = sum;
+    }
   }
+  if (loss_vec == nullptr) return;
   __syncthreads();
   if (threadIdx.x == 0) ef_loss_tail<KT>(cfg, fin, loss_vec, coef);
 }
@@ -284,6 +162,19 @@ static bool k_dispatch(int k, F&& f) {
   return false;
 }
 
+// rows of per-block (or per-tile, see k1_align.hip) partial sums -> stats [+ loss_vec, coef]
+int cvf_ef_stats_finish(const cvf_ef_cfg* cfg, int n_rows, const double* partial, double* stats, double* loss_vec, double* coef,
+                        hipStream_t s) {
+  const int ns = cvf_ef_nstats(cfg->k, cfg->lag_idx);
+  const int waves = ns < 16 ? ns : 16;
+  k_dispatch(cfg->k, [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    hipLaunchKernelGGL((ef_stats_finish_kernel<K>), dim3(1), dim3(64 * waves), 0, s, *cfg, ns, n_rows, partial, stats, loss_vec,
+                       coef);
+  });
+  return cvf_check_launch("ef_stats_finish_kernel");
+}
+
 extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
                             const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, double* loss_vec,
                             double* coef, void* stream) {
@@ -307,17 +198,8 @@ extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, co
   });
   int rc = cvf_check_launch("ef_stats_partial_kernel");
   if (rc) return rc;
-  if (loss_vec != nullptr) {  // no cross-rank reduction in between: finish the loss in the same launch
-    CVF_REQUIRE(coef != nullptr, "cvf_ef_stats: loss_vec without coef");
-    k_dispatch(cfg->k, [&](auto kc) {
-      constexpr int K = decltype(kc)::value;
-      hipLaunchKernelGGL((ef_stats_final_loss_kernel<K>), dim3(1), dim3(8 * kMaxStats), 0, s, *cfg, ns, G, scratch, stats,
-                         loss_vec, coef);
-    });
-    return cvf_check_launch("ef_stats_final_loss_kernel");
-  }
-  hipLaunchKernelGGL(ef_stats_final_kernel, dim3(1), dim3(8 * kMaxStats), 0, s, ns, G, scratch, stats);
-  return cvf_check_launch("ef_stats_final_kernel");
+  CVF_REQUIRE(loss_vec == nullptr || coef != nullptr, "cvf_ef_stats: loss_vec without coef");
+  return cvf_ef_stats_finish(cfg, G, scratch, stats, loss_vec, coef, s);
 }
 
 extern "C" int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* loss_vec, double* coef, void* stream) {

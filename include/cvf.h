@@ -136,6 +136,15 @@ int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, floa
 int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled, const float* a,
                      int k, const float* g_tiled, float* q_tiled, float* e_tiled, const float* slot_xyz,
                      const double* dense, void* stream);
+/* The same launch with the first stage of K5 (cvf_ef_stats in generator mode, below) folded in: every block reduces its
+ * tile's share of the batch sums, one short launch adds the tiles in a fixed order and, when loss_vec != NULL,
+ * evaluates cvf_ef_loss.  Shapes the fused stage does not cover run cvf_metric_apply and cvf_ef_stats back to back -
+ * the results agree to fp64 summation order.  scratch: cvf_metric_stats_scratch_doubles() doubles. */
+int64_t cvf_metric_stats_scratch_doubles(int64_t B, int k);
+int cvf_metric_apply_stats(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled, const float* a,
+                           int k, const float* g_tiled, float* q_tiled, float* e_tiled, const float* slot_xyz,
+                           const double* dense, const cvf_ef_cfg* cfg, const float* w, const float* y_tiled,
+                           double* scratch, double* stats, double* loss_vec, double* coef, void* stream);
 /* large molecules only (slot_xyz / dense may be NULL otherwise): dense[42] = moments of (a, ref) over the align atoms,
  * T0[c] = sum a_bc, T1[c][j] = sum a_bc ref_bj, T2[c][j][k] = sum a_bc ref_bj ref_bk, R1[j] = sum ref_bj (fp64). */
 int cvf_metric_dense_tensors(const cvf_pp_desc* pp, const float* a, double* dense, void* stream);

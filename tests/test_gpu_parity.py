@@ -337,3 +337,43 @@ def test_large_molecule_generator_step_vs_oracle(dev, n_atoms, B, contig, k):
     want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
     got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("n_atoms,n_pos,B,k", [(22, 22, 1000, 3), (22, 22, 64, 1), (12, 9, 333, 2)])
+def test_fused_metric_stats_equals_two_launch_path(dev, n_atoms, n_pos, B, k):
+    """cvf_metric_apply_stats (batch sums + loss tail in the derivative kernel's epilogue) against cvf_metric_apply +
+    cvf_ef_stats on the same buffers: same sums up to fp64 summation order, same ordering, same coefficients; and the
+    fused sums are bitwise reproducible run to run (the last block adds the tiles in a fixed order)."""
+    from colvarsfinder import core, nn, _hip
+    from oracle import nnref
+    traj, w, ref = make_molecule_traj(n_atoms, B, seed=900 + B, scale=2.0, sigma=0.3)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_pos)))], use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    dims = [layer.d_r, 12, 12, 1]
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(11)))
+    a = torch.tensor(diag_coeff_for(n_atoms, 3), dtype=torch.float32)
+    task = core.EigenFunctionTask(Traj(traj, w, 1.0), layer, model, "/tmp/cvf_test", 10.0, [1.0, 0.7, 0.4][:k], diag_coeff=a,
+                                  beta=1.0, lag_tau=0, k=k, device=dev, verbose=False, save_model_every_step=0)
+    X, wt = torch.tensor(traj), torch.tensor(w)
+    task.loss_func(X, wt, None, None)
+    ws = task._ws[B]
+    fused = [t.clone() for t in (ws.stats, ws.loss_vec, ws.coef, ws.e, ws.q)]
+    for _ in range(3):
+        task.loss_func(X, wt, None, None)
+        assert torch.equal(ws.stats, fused[0]) and torch.equal(ws.loss_vec, fused[1])
+    # the two-launch path on the same y / g
+    lib, P = _hip.lib(), _hip.ptr
+    Xd, wd = X.to(dev).float().contiguous(), wt.to(dev).float().contiguous()
+    q2, e2 = torch.empty_like(ws.q), torch.empty_like(ws.e)
+    stats2, lv2, cf2 = torch.empty_like(ws.stats), torch.empty_like(ws.loss_vec), torch.empty_like(ws.coef)
+    scratch2 = torch.zeros(lib.cvf_ef_stats_scratch_doubles(k, 0), device=dev, dtype=torch.float64)
+    _hip.check(lib.cvf_metric_apply(task._pp, P(Xd), B, P(ws.aux), P(task._diag_coeff), k, P(ws.g), P(q2), P(e2), None, None,
+                                    _hip.stream()), "cvf_metric_apply")
+    _hip.check(lib.cvf_ef_stats(task._cfg, B, P(wd), P(ws.y), P(e2), None, None, P(scratch2), P(stats2), P(lv2), P(cf2),
+                                _hip.stream()), "cvf_ef_stats")
+    torch.cuda.synchronize()
+    assert torch.equal(e2, fused[3]) and torch.equal(q2, fused[4])
+    np.testing.assert_allclose(fused[0].cpu().numpy(), stats2.cpu().numpy(), rtol=1e-13)
+    np.testing.assert_allclose(fused[1].cpu().numpy(), lv2.cpu().numpy(), rtol=1e-10)
+    np.testing.assert_allclose(fused[2].cpu().numpy(), cf2.cpu().numpy(), rtol=1e-8, atol=1e-10 * float(cf2.abs().max()))

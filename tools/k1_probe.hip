@@ -64,6 +64,60 @@ int main(int argc, char** argv) {
     double tot = 0;
     for (int i = 1; i < 7; ++i) { printf("   %-22s %8.0f cycles\n", nm[i], acc[i] / n); tot += acc[i] / n; }
     printf("   total %8.0f cycles over %d waves\n", tot, n);
+    if (B == 20000) {   // the derivative kernel on the same tile, three nets
+      const int k = 3;
+      std::vector<float> g((size_t)T * k * nc * 64), av(nc, 1.0f);
+      for (auto& v : g) v = G(rng);
+      float *dg, *dq, *de, *da;
+      (void)hipMalloc(&dg, g.size() * 4); (void)hipMalloc(&dq, g.size() * 4); (void)hipMalloc(&de, T * k * 64 * 4); (void)hipMalloc(&da, nc * 4);
+      (void)hipMemcpy(dg, g.data(), g.size() * 4, hipMemcpyHostToDevice);
+      (void)hipMemcpy(da, av.data(), nc * 4, hipMemcpyHostToDevice);
+      for (int it = 0; it < 3; ++it) cvf_metric_apply(&pp, dx, B, daux, da, k, dg, dq, de, nullptr, nullptr, nullptr);
+      (void)hipEventRecord(e0, nullptr);
+      for (int it = 0; it < reps; ++it) {
+        int rc = cvf_metric_apply(&pp, dx, B, daux, da, k, dg, dq, de, nullptr, nullptr, nullptr);
+        if (rc) { printf("failed: %s\n", cvf_last_error()); return 1; }
+      }
+      (void)hipEventRecord(e1, nullptr);
+      (void)hipDeviceSynchronize();
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      printf("metric_apply B=%lld k=%d: %.1f us/launch\n", (long long)B, k, 1e3 * ms / reps);
+      (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+      const char* mn[8] = {"", "tile staged", "tables+aux", "pass 1 (M, sum p)", "Z", "pass 2 (G,E,u)", "dR", "pass 3 (q)"};
+      double am[8] = {0}; int nm2 = 0;
+      for (int b = 0; b < 4096 && b < T; ++b) {
+        const unsigned long long* s2 = &st[(b * 2) % 4096 * 64];
+        if (s2[15] == 0) continue;
+        for (int i = 1; i < 8; ++i) am[i] += double(s2[8 + i] - s2[8 + i - 1]);
+        ++nm2;
+      }
+      double tm = 0;
+      for (int i = 1; i < 8; ++i) { printf("   %-22s %8.0f cycles\n", mn[i], am[i] / nm2); tm += am[i] / nm2; }
+      printf("   total %8.0f cycles over %d waves\n", tm, nm2);
+      // fused epilogue (batch sums + loss tail)
+      cvf_ef_cfg cfg = {};
+      cfg.k = k; cfg.lag_idx = 0; cfg.sort_eigvals = 1; cfg.alpha = 10.0; cfg.beta = 1.0; cfg.dt = 1.0;
+      for (int i = 0; i < k; ++i) cfg.eig_w[i] = 1.0 - 0.3 * i;
+      std::vector<float> hw(B, 1.0f), hy((size_t)T * k * 64);
+      for (auto& v : hy) v = G(rng);
+      float *dw, *dy; double *dscr, *dstats, *dlv, *dcf;
+      const int64_t nscr = cvf_metric_stats_scratch_doubles(B, k);
+      (void)hipMalloc(&dw, B * 4); (void)hipMalloc(&dy, hy.size() * 4); (void)hipMalloc(&dscr, nscr * 8);
+      (void)hipMalloc(&dstats, 64 * 8); (void)hipMalloc(&dlv, 64 * 8); (void)hipMalloc(&dcf, 128 * 8);
+      (void)hipMemcpy(dw, hw.data(), B * 4, hipMemcpyHostToDevice);
+      (void)hipMemcpy(dy, hy.data(), hy.size() * 4, hipMemcpyHostToDevice);
+      (void)hipMemset(dscr, 0, nscr * 8);
+      for (int it = 0; it < 3; ++it) cvf_metric_apply_stats(&pp, dx, B, daux, da, k, dg, dq, de, nullptr, nullptr, &cfg, dw, dy, dscr, dstats, dlv, dcf, nullptr);
+      (void)hipEventRecord(e0, nullptr);
+      for (int it = 0; it < reps; ++it) {
+        int rc = cvf_metric_apply_stats(&pp, dx, B, daux, da, k, dg, dq, de, nullptr, nullptr, &cfg, dw, dy, dscr, dstats, dlv, dcf, nullptr);
+        if (rc) { printf("failed: %s\n", cvf_last_error()); return 1; }
+      }
+      (void)hipEventRecord(e1, nullptr);
+      (void)hipDeviceSynchronize();
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      printf("metric_apply_stats B=%lld k=%d: %.1f us/launch\n", (long long)B, k, 1e3 * ms / reps);
+    }
     (void)hipFree(dx); (void)hipFree(dfeat); (void)hipFree(daux);
   }
   return 0;
