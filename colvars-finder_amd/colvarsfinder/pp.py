@@ -100,6 +100,9 @@ class AlignFeatureLayer(torch.nn.Module):
         for r in rec:
             na = 1 if r[0] == _hip.FEAT_POSITION else _TYPE_NATOMS[{v: k_ for k_, v in _TYPE_ID.items()}[r[0]]]
             rec_slot.append([r[0]] + [int(atom_slot[a]) for a in r[1:1 + na]] + [0] * (4 - na) + [r[5]])
+        # the streaming kernels hand one record to each lane: records of one type side by side keep a wave's lanes on
+        # one code path (the output offset travels with the record, so the order is free)
+        rec_slot.sort(key=lambda r: r[0])
         self._n_slot = len(used)
         self.register_buffer("atom_align", torch.tensor(atom_align))
         self.register_buffer("atom_slot", torch.tensor(atom_slot))

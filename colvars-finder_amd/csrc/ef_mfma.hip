@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kPitch = 66;
+constexpr int kPitch = 68;   // multiple of 4: every image row is 16-byte aligned, MFMA operands are read as ds_read_b128
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -672,22 +672,35 @@ struct EfBwdArgs {
 };
 
 // One 16x16 tile of a weight gradient over the block's 64 frames:  A (rows 16*rt..) x B (rows 16*ct..),
-// operand images [feature][frame] with pitch kPitch.  All 16 k-steps are unrolled: 32-64 LDS reads in flight.
+// operand images [feature][frame] with pitch kPitch.  The order in which the frames are summed is free as long as
+// A and B agree: k-slot kq of k-step (j, c) is frame 16 j + 4 kq + c, so a lane's sixteen values of one operand
+// are four 16-byte LDS reads (the natural order 4 s + kq needs sixteen 4-byte reads, four-way bank conflicted).
+__device__ __forceinline__ f32x4 outer_half(const float* __restrict__ A, const float* __restrict__ B, int rt, int ct,
+                                            int lane, f32x4 acc) {
+  const int row = lane & 15, kq = lane >> 4;
+  const float4* a = reinterpret_cast<const float4*>(A + (16 * rt + row) * kPitch + 4 * kq);
+  const float4* b = reinterpret_cast<const float4*>(B + (16 * ct + row) * kPitch + 4 * kq);
+  float4 av[4], bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    av[j] = a[4 * j];
+    bv[j] = b[4 * j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    acc = mfma4(av[j].x, bv[j].x, acc);
+    acc = mfma4(av[j].y, bv[j].y, acc);
+    acc = mfma4(av[j].z, bv[j].z, acc);
+    acc = mfma4(av[j].w, bv[j].w, acc);
+  }
+  return acc;
+}
 __device__ __forceinline__ f32x4 outer_tile(const float* __restrict__ A1, const float* __restrict__ B1,
                                             const float* __restrict__ A2, const float* __restrict__ B2, int rt, int ct,
                                             bool two, int lane) {
-  const int row = lane & 15, kq = lane >> 4;
-  const float* a1 = A1 + (16 * rt + row) * kPitch + kq;
-  const float* b1 = B1 + (16 * ct + row) * kPitch + kq;
-  const float* a2 = A2 + (16 * rt + row) * kPitch + kq;
-  const float* b2 = B2 + (16 * ct + row) * kPitch + kq;
   f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int s = 0; s < 16; ++s) acc = mfma4(a1[4 * s], b1[4 * s], acc);
-  if (two) {
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc = mfma4(a2[4 * s], b2[4 * s], acc);
-  }
+  acc = outer_half(A1, B1, rt, ct, lane, acc);
+  if (two) acc = outer_half(A2, B2, rt, ct, lane, acc);
   return acc;
 }
 
@@ -755,7 +768,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
   // multiple of 16 rows, i.e. into the following image - finite values that only reach output rows/columns
   // which are discarded.  Keeps the block under 40 KiB of LDS (4 blocks per CU).
   constexpr int kRows = 2 * H + 2 * (H + 1) + 16;
-  __shared__ float IMG[kRows * kPitch];
+  __shared__ __attribute__((aligned(16))) float IMG[kRows * kPitch];
   extern __shared__ float GI[];  // this block's partial gradient of `net` (flat parameter order)
   float* SA1 = IMG;
   float* SA2 = SA1 + H * kPitch;
@@ -776,6 +789,12 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
   for (int i = tid; i < gspan; i += NT) GI[i] = 0.0f;
   __syncthreads();
   if (tid < 64) SB1[H * kPitch + tid] = 1.0f;  // bias column of [h ; 1]  (row H of SB2 stays 0)
+
+  const double* gS1 = coef;
+  const double* gS2 = coef + k;
+  const double* gEt = coef + k + k * k;
+  const double* gS1l = coef + 2 * k + k * k;
+  const double* gS2l = coef + 3 * k + k * k;
 
   // this net's coefficients d loss / d sums (wave-uniform, loaded once)
   const double cS1 = coef[net], cEt = coef[k + k * k + net];
@@ -821,23 +840,23 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
       const float wb = valid ? wraw : 0.0f;
       const float* yb = y_tiled + t0 * k * CVF_TILE + fo + ft;
       gamma[ft] = 0.0f;
-      double a = cS1;
-#pragma unroll
-      for (int j = 0; j < CVF_MAX_NETS; ++j)
-        if (j < k) a = fma(cS2[j], (double)yb[j * CVF_TILE], a);
       if (args.lag_idx == 0) {
+        double a = gS1[net];
+        for (int j = 0; j < k; ++j) a += (j == net ? 2.0 : 1.0) * gS2[net * k + j] * (double)yb[j * CVF_TILE];
         alpha[ft] = (float)((double)wb * a);
-        gamma[ft] = (float)(2.0 * (double)wb * cEt);
+        gamma[ft] = (float)(2.0 * (double)wb * gEt[net]);
       } else {
         const float* yl = y_tiled + (args.T + t0) * k * CVF_TILE + fo + ft;
         const double diff = (double)yl[net * CVF_TILE] - (double)yb[net * CVF_TILE];
-        const double tterm = 2.0 * (double)wb * cEt * diff;
+        const double tterm = 2.0 * (double)wb * gEt[net] * diff;
         if (pass == 0) {
+          double a = gS1[net];
+          for (int j = 0; j < k; ++j) a += (j == net ? 2.0 : 1.0) * gS2[net * k + j] * (double)yb[j * CVF_TILE];
           alpha[ft] = (float)((double)wb * a - tterm);
         } else {
           const float wlraw = w_lag[fc];
           const float wlg = valid ? wlraw : 0.0f;
-          alpha[ft] = (float)((double)wlg * (cS1l + cS2l * 2.0 * (double)yl[net * CVF_TILE]) + tterm);
+          alpha[ft] = (float)((double)wlg * (gS1l[net] + 2.0 * gS2l[net] * (double)yl[net * CVF_TILE]) + tterm);
         }
       }
     }
@@ -973,41 +992,70 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
         // (j, c) is frame 16 j + 4 q + c: a lane's sixteen B values are then four 16-byte loads, and one load
         // instruction covers 64 contiguous bytes of each of its 16 feature rows (with the natural order 4 s + q
         // every 4-byte load touched 16 different sectors: 12k cycles per tile pair, half of this kernel).
-        for (int pr = wave; pr < RTO * CT1; pr += WPB) {
-          const int rt = pr / CT1, ct = pr - rt * CT1;
+        // A wave owns whole column tiles (both row tiles reuse the B registers); an odd last column tile is split by
+        // row tile.  (Fetching the next column tile during the current one's MFMAs was tried: the 32 extra live
+        // registers spill elsewhere in the kernel and cost more than the overlap gains.)
+        static_assert(WPB == 2, "the column-tile schedule below is written for two waves per block");
+        // column tile `ct` for the row tiles rt0, rt0 + rstep, ...: first the [f ; 1] half of the contraction for
+        // all of them, then the q half - sixteen B registers live at a time
+        auto outer0 = [&](int ct, int rt0, int rstep) {
           const int i = 16 * ct + row16;
-          const float* a1 = SA1 + (16 * rt + row16) * kPitch + 4 * q;
-          const float* a2 = SA2 + (16 * rt + row16) * kPitch + 4 * q;
-          // (no MFMA under lane-divergent control flow: operand values are selected per lane, the MFMAs are uniform)
           const int ic = i < D ? i : D - 1;
+          // (no MFMA under lane-divergent control flow: operand values are selected per lane, the MFMAs are uniform)
           const float pad1 = i == D ? 1.0f : 0.0f;   // bias column; columns past it stay 0
-          const float4* fb = reinterpret_cast<const float4*>(f_tile + (int64_t)ic * CVF_TILE + 4 * q);
-          float4 b1[4];
+          f32x4 acc[RTO];
+          {
+            const float4* fb = reinterpret_cast<const float4*>(f_tile + (int64_t)ic * CVF_TILE + 4 * q);
+            float4 b[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) b1[j] = fb[4 * j];
-          f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int j = 0; j < 4; ++j) b[j] = fb[4 * j];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc = mfma4(a1[16 * j + 0], i < D ? b1[j].x : pad1, acc);
-            acc = mfma4(a1[16 * j + 1], i < D ? b1[j].y : pad1, acc);
-            acc = mfma4(a1[16 * j + 2], i < D ? b1[j].z : pad1, acc);
-            acc = mfma4(a1[16 * j + 3], i < D ? b1[j].w : pad1, acc);
+            for (int rt = 0; rt < RTO; ++rt) {
+              acc[rt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+              if (rt >= rt0 && (rt - rt0) % rstep == 0) {
+                const float4* a1 = reinterpret_cast<const float4*>(SA1 + (16 * rt + row16) * kPitch + 4 * q);
+                float4 av[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = a1[4 * j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  acc[rt] = mfma4(av[j].x, i < D ? b[j].x : pad1, acc[rt]);
+                  acc[rt] = mfma4(av[j].y, i < D ? b[j].y : pad1, acc[rt]);
+                  acc[rt] = mfma4(av[j].z, i < D ? b[j].z : pad1, acc[rt]);
+                  acc[rt] = mfma4(av[j].w, i < D ? b[j].w : pad1, acc[rt]);
+                }
+              }
+            }
           }
           if (tangent) {
             const float4* qb = reinterpret_cast<const float4*>(q_tile + (int64_t)ic * CVF_TILE + 4 * q);
-            float4 b2[4];
+            float4 b[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b2[j] = qb[4 * j];
+            for (int j = 0; j < 4; ++j) b[j] = qb[4 * j];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              acc = mfma4(a2[16 * j + 0], i < D ? b2[j].x : 0.0f, acc);
-              acc = mfma4(a2[16 * j + 1], i < D ? b2[j].y : 0.0f, acc);
-              acc = mfma4(a2[16 * j + 2], i < D ? b2[j].z : 0.0f, acc);
-              acc = mfma4(a2[16 * j + 3], i < D ? b2[j].w : 0.0f, acc);
+            for (int rt = 0; rt < RTO; ++rt) {
+              if (rt >= rt0 && (rt - rt0) % rstep == 0) {
+                const float4* a2 = reinterpret_cast<const float4*>(SA2 + (16 * rt + row16) * kPitch + 4 * q);
+                float4 av[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = a2[4 * j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  acc[rt] = mfma4(av[j].x, i < D ? b[j].x : 0.0f, acc[rt]);
+                  acc[rt] = mfma4(av[j].y, i < D ? b[j].y : 0.0f, acc[rt]);
+                  acc[rt] = mfma4(av[j].z, i < D ? b[j].z : 0.0f, acc[rt]);
+                  acc[rt] = mfma4(av[j].w, i < D ? b[j].w : 0.0f, acc[rt]);
+                }
+              }
             }
           }
-          add_tile(0, H, D, rt, ct, acc);
-        }
+#pragma unroll
+          for (int rt = 0; rt < RTO; ++rt)
+            if (rt >= rt0 && (rt - rt0) % rstep == 0) add_tile(0, H, D, rt, ct, acc[rt]);
+        };
+        const int nfull = CT1 & ~1;
+        for (int ct = wave; ct < nfull; ct += WPB) outer0(ct, 0, 1);
+        if (CT1 & 1) outer0(CT1 - 1, wave, WPB);
         __syncthreads();
       }
     }
@@ -1144,12 +1192,6 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
 
 extern "C" int64_t cvf_ef_backward_slab_rows(int64_t n_tiles) { return bwd_grid(n_tiles); }
 
-// developer switch while tuning: CVF_BWD_WPB=4 runs four waves per tile (one 16-frame group each)
-static bool bwd_wpb4() {
-  static const int v = [] { const char* e = getenv("CVF_BWD_WPB"); return e ? atoi(e) : 2; }();
-  return v == 4;
-}
-
 extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
                                int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
                                const float* y_tiled, const float* q_tiled, const double* coef, float* slab,
@@ -1182,12 +1224,8 @@ extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, c
   const size_t lds_dyn = (size_t)span * sizeof(float);
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    if (bwd_wpb4())
-      hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 4>), grid, dim3(256), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed,
-                         w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count);
-    else
-      hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed,
-                         w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count);
+    hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed,
+                       w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count);
   });
   CVF_REQUIRE(launched, "cvf_ef_backward: no kernel instance for hidden width %d x %d layers", H, NH);
   return cvf_check_launch("ef_bwd_mfma_kernel");

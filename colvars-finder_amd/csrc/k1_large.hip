@@ -92,9 +92,12 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_gather_kernel(cvf_pp_des
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = bc[fi][i];
   const double cc0 = cD[fi][0], cc1 = cD[fi][1], cc2 = cD[fi][2];
-  float* fr = (feat_rows && real) ? feat_rows + frame * pp.d_r : nullptr;
+  // (rows of padded frames land in the last real frame's row: same values)
+  float* fr = feat_rows ? feat_rows + frame * pp.d_r : nullptr;
+  const bool tiled = feat_tiled != nullptr;
+  float* fl = featL + fi;
   auto emit = [&](int o, float v) {
-    if (feat_tiled) featL[o * kGroup + fi] = v;
+    if (tiled) fl[o * kGroup] = v;
     if (fr) fr[o] = v;
   };
   for (int r = lane; r < pp.n_rec; r += 64) {
@@ -153,6 +156,123 @@ __device__ __forceinline__ void acc_atom(Acc15& A, float x0, float x1, float x2,
   A.v[12] += e0; A.v[13] += e1; A.v[14] += e2;
 }
 
+// Everything after the streaming pass, shared by the two captured-atom kernels: the workgroup's kGroup 3x3
+// problems (one per lane of one wave) from sums[frame][0..14] = {sum x (3), sum x (x) ref (9), sum ref (3)}, then
+// per frame (wave fi) aux, the compact feature-atom copy, the features from the captured atoms, and the flush.
+__device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int64_t B, int64_t f0, int tid, int lane, int fi,
+                                                     bool real, int64_t frame, const double (*sums)[16],
+                                                     float (*bc)[CVF_AUX_ROWS + 2], double (*cD)[3], const float* capL,
+                                                     float* featL, float* __restrict__ feat_tiled,
+                                                     float* __restrict__ feat_rows, float* __restrict__ aux_tiled,
+                                                     float* __restrict__ slot_xyz) {
+  const int nal = pp.n_align, nslot = pp.n_slot;
+  CVF_STAMP(4);
+  constexpr int kRecPre = 4;
+  Rec pre[kRecPre];
+#pragma unroll
+  for (int it = 0; it < kRecPre; ++it) {
+    const int r = lane + 64 * it;
+    const int32_t* p = pp.rec_slot + 6 * (r < pp.n_rec ? r : pp.n_rec - 1);
+    pre[it] = Rec{p[0], p[1], p[2], p[3], p[4], p[5]};
+  }
+  if (tid < kGroup) {  // the group's 3x3 problems, one per lane of one wave
+    const double* t = sums[tid];
+    const double inv = fast_rcp((double)nal);
+    const double c0 = t[0] * inv, c1 = t[1] * inv, c2 = t[2] * inv;
+    double H[3][3];
+    H[0][0] = t[3] - c0 * t[12]; H[0][1] = t[4] - c0 * t[13]; H[0][2] = t[5] - c0 * t[14];
+    H[1][0] = t[6] - c1 * t[12]; H[1][1] = t[7] - c1 * t[13]; H[1][2] = t[8] - c1 * t[14];
+    H[2][0] = t[9] - c2 * t[12]; H[2][1] = t[10] - c2 * t[13]; H[2][2] = t[11] - c2 * t[14];
+    KabschOut ko;
+    kabsch_from_H(H, ko);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) bc[tid][i] = ko.R[i];
+    bc[tid][9] = (float)c0; bc[tid][10] = (float)c1; bc[tid][11] = (float)c2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bc[tid][12 + i] = ko.Kinv[i];
+    cD[tid][0] = c0; cD[tid][1] = c1; cD[tid][2] = c2;
+  } else if (slot_xyz != nullptr && tid >= 64) {
+    // meanwhile the other waves write the compact copy of the feature atoms for the derivative kernels: the
+    // workgroup's kGroup frames are one contiguous run of both the LDS image and slot_xyz (padded frame index)
+    const float4* src = reinterpret_cast<const float4*>(capL - (size_t)fi * nslot * 3);
+    float4* dst = reinterpret_cast<float4*>(slot_xyz + f0 * (int64_t)nslot * 3);
+    const int n4 = kGroup * nslot * 3 / 4;
+    for (int i = tid - 64; i < n4; i += 64 * (kGroup - 1)) dst[i] = src[i];
+  }
+  __syncthreads();
+  CVF_STAMP(5);
+  const int64_t tile = f0 / CVF_TILE;
+  const int l0 = (int)(f0 % CVF_TILE);
+  if (aux_tiled != nullptr && lane < CVF_AUX_ROWS) aux_tiled[(tile * CVF_AUX_ROWS + lane) * CVF_TILE + l0 + fi] = bc[fi][lane];
+  CVF_STAMP(6);
+  float R[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = bc[fi][i];
+  const double cc0 = cD[fi][0], cc1 = cD[fi][1], cc2 = cD[fi][2];
+  float* fr = (feat_rows && real) ? feat_rows + frame * pp.d_r : nullptr;
+  auto emit = [&](int o, float v) {
+    if (feat_tiled) featL[o * kGroup + fi] = v;
+    if (fr) fr[o] = v;
+  };
+  auto satom = [&](int sl) { return V3{capL[3 * sl], capL[3 * sl + 1], capL[3 * sl + 2]}; };
+  auto feature = [&](const Rec& rc) {
+    if (rc.type == CVF_FEAT_POSITION) {
+      const V3 xa = satom(rc.a0);
+      const V3 xc = v3((float)((double)xa.x - cc0), (float)((double)xa.y - cc1), (float)((double)xa.z - cc2));
+      const V3 al = row_times(xc, R);
+      emit(rc.out, al.x);
+      emit(rc.out + 1, al.y);
+      emit(rc.out + 2, al.z);
+    } else if (rc.type == CVF_FEAT_BOND) {
+      emit(rc.out, bond_eval(satom(rc.a0), satom(rc.a1)).val);
+    } else if (rc.type == CVF_FEAT_ANGLE) {
+      const float cs = angle_eval(satom(rc.a0), satom(rc.a1), satom(rc.a2)).cs;
+      emit(rc.out, pp.use_angle_value ? acosf(cs) : cs);
+    } else {
+      const DihedralG dg = dihedral_eval(satom(rc.a0), satom(rc.a1), satom(rc.a2), satom(rc.a3));
+      if (pp.use_angle_value) {
+        emit(rc.out, atan2f(dg.sn, dg.cs));
+      } else {
+        emit(rc.out, dg.cs);
+        emit(rc.out + 1, dg.sn);
+      }
+    }
+  };
+  // the first kRecPre records of each lane were fetched before the solve (their round trip to L2 is hidden there)
+#pragma unroll
+  for (int it = 0; it < kRecPre; ++it)
+    if (lane + 64 * it < pp.n_rec) feature(pre[it]);
+  for (int r = lane + 64 * kRecPre; r < pp.n_rec; r += 64) {
+    const int32_t* p = pp.rec_slot + 6 * r;   // like rec, atom fields hold slots
+    feature(Rec{p[0], p[1], p[2], p[3], p[4], p[5]});
+  }
+  CVF_STAMP(7);
+  if (feat_tiled != nullptr) {
+    __syncthreads();
+    for (int idx = tid; idx < pp.d_r * kGroup; idx += 64 * kGroup) {
+      const int o = idx / kGroup, f = idx % kGroup;
+      feat_tiled[(tile * pp.d_r + o) * CVF_TILE + l0 + f] = featL[idx];
+    }
+  }
+  CVF_STAMP(8);
+}
+
+// fp32 partial sums of the same fifteen quantities over a few atoms (see the VEC4 loop)
+__device__ __forceinline__ void part_first(float (&s)[15], float x0, float x1, float x2, float r0, float r1, float r2) {
+  s[0] = x0; s[1] = x1; s[2] = x2;
+  s[3] = x0 * r0; s[4] = x0 * r1; s[5] = x0 * r2;
+  s[6] = x1 * r0; s[7] = x1 * r1; s[8] = x1 * r2;
+  s[9] = x2 * r0; s[10] = x2 * r1; s[11] = x2 * r2;
+  s[12] = r0; s[13] = r1; s[14] = r2;
+}
+__device__ __forceinline__ void part_next(float (&s)[15], float x0, float x1, float x2, float r0, float r1, float r2) {
+  s[0] += x0; s[1] += x1; s[2] += x2;
+  s[3] = fmaf(x0, r0, s[3]); s[4] = fmaf(x0, r1, s[4]); s[5] = fmaf(x0, r2, s[5]);
+  s[6] = fmaf(x1, r0, s[6]); s[7] = fmaf(x1, r1, s[7]); s[8] = fmaf(x1, r2, s[8]);
+  s[9] = fmaf(x2, r0, s[9]); s[10] = fmaf(x2, r1, s[10]); s[11] = fmaf(x2, r2, s[11]);
+  s[12] += r0; s[13] += r1; s[14] += r2;
+}
+
 template <bool VEC4>
 __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
                                                                        float* __restrict__ feat_tiled,
@@ -184,11 +304,18 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
       const float4 a = x4[3 * g], b = x4[3 * g + 1], c = x4[3 * g + 2];  // atoms 4g..4g+3
       const int4 sl = s4[g];
       if (g < nqa) {
+        // The four atoms' sums are formed in fp32 and only those partial sums enter the fp64 accumulators: 30 instead
+        // of 84 double-rate instructions per 48 bytes (with all of it in fp64 this loop was VALU-bound at ~4.4 TB/s,
+        // tools/stream_probe.hip reads 6.3 TB/s with the same load pattern).  A partial sum of four products of
+        // O(1e3) magnitude carries ~4e-4 absolute rounding; over 1250 of them that is 1e-8 of the covariance entries.
         const float4 p = r4[3 * g], q = r4[3 * g + 1], r = r4[3 * g + 2];
-        acc_atom(A, a.x, a.y, a.z, p.x, p.y, p.z);
-        acc_atom(A, a.w, b.x, b.y, p.w, q.x, q.y);
-        acc_atom(A, b.z, b.w, c.x, q.z, q.w, r.x);
-        acc_atom(A, c.y, c.z, c.w, r.y, r.z, r.w);
+        float s[15];
+        part_first(s, a.x, a.y, a.z, p.x, p.y, p.z);
+        part_next(s, a.w, b.x, b.y, p.w, q.x, q.y);
+        part_next(s, b.z, b.w, c.x, q.z, q.w, r.x);
+        part_next(s, c.y, c.z, c.w, r.y, r.z, r.w);
+#pragma unroll
+        for (int i = 0; i < 15; ++i) A.v[i] += (double)s[i];
       }
       if (sl.x >= 0) { capL[3 * sl.x] = a.x; capL[3 * sl.x + 1] = a.y; capL[3 * sl.x + 2] = a.z; }
       if (sl.y >= 0) { capL[3 * sl.y] = a.w; capL[3 * sl.y + 1] = b.x; capL[3 * sl.y + 2] = b.y; }
@@ -215,73 +342,143 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
     if (lane < 15) sums[fi][lane] = mine;
   }
   __syncthreads();
-  if (tid < kGroup) {  // the group's 3x3 problems, one per lane of one wave
-    const double* t = sums[tid];
-    const double inv = fast_rcp((double)nal);
-    const double c0 = t[0] * inv, c1 = t[1] * inv, c2 = t[2] * inv;
-    double H[3][3];
-    H[0][0] = t[3] - c0 * t[12]; H[0][1] = t[4] - c0 * t[13]; H[0][2] = t[5] - c0 * t[14];
-    H[1][0] = t[6] - c1 * t[12]; H[1][1] = t[7] - c1 * t[13]; H[1][2] = t[8] - c1 * t[14];
-    H[2][0] = t[9] - c2 * t[12]; H[2][1] = t[10] - c2 * t[13]; H[2][2] = t[11] - c2 * t[14];
-    KabschOut ko;
-    kabsch_from_H(H, ko);
+  large_solve_features(pp, B, f0, tid, lane, fi, real, frame, sums, bc, cD, capL, featL, feat_tiled, feat_rows, aux_tiled,
+                       slot_xyz);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Slice variant of the streaming pass (VEC4 layouts, N <= 8192): the eight waves of a workgroup split the ATOMS of
+// a frame (wave w, step i owns the 4-atom groups (8 i + w) 64 + lane) and walk through the workgroup's eight frames
+// together.  A lane then meets the same atoms in every frame, so their reference coordinates and capture slots are
+// loaded ONCE into registers: the streaming loop issues coordinate loads only.  (With one frame per wave each wave
+// re-read the 12 N-byte reference and the slot table from L2 for every frame - twice the vector-memory
+// instructions per byte of coordinates - and tools/stream_probe.hip shows exactly that costing 6.2 -> 3.9 TB/s.)
+// Per frame a wave reduces its twelve partial sums through a small wave-private LDS transpose (4 values a round:
+// 4 writes, one 16-byte read, four DPP steps) instead of twelve full-wave butterflies.
+// ---------------------------------------------------------------------------------------------------------
+template <int NI>
+__global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
+                                                                     float* __restrict__ feat_tiled,
+                                                                     float* __restrict__ feat_rows,
+                                                                     float* __restrict__ aux_tiled,
+                                                                     float* __restrict__ slot_xyz) {
+  extern __shared__ float dyn[];                  // [kGroup][n_slot][3] captured atoms | [d_r][kGroup] features (first: reduction scratch)
+  __shared__ float bc[kGroup][CVF_AUX_ROWS + 2];
+  __shared__ double cD[kGroup][3];
+  __shared__ double sums[kGroup][16];
+  __shared__ double part[kGroup][kGroup][12];     // [frame][wave][value]
+  __shared__ double rpart[kGroup][3];             // per-wave sums of the reference rows it owns
+  constexpr int kRedPitch = 68;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nc = pp.n_coord, nal = pp.n_align, nslot = pp.n_slot, N = nc / 3;
+  const int nq = N >> 2, nqa = nal >> 2;
+  float* featL = dyn + (size_t)kGroup * nslot * 3;
+  float* red = featL + w * (4 * kRedPitch);       // wave-private, reused by the feature staging later
+  const int64_t f0 = (int64_t)blockIdx.x * kGroup;
+  CVF_STAMP(0);
+  // ---- this lane's atoms: reference rows, capture slots (registers for the whole batch)
+  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(pp.ref_c);
+  const int4* __restrict__ s4 = reinterpret_cast<const int4*>(pp.atom_slot);
+  float4 rp[NI], rq[NI], rr[NI];
+  int4 sl[NI];
+  int gi[NI];
+  float mk[NI];
+  float rs0 = 0.0f, rs1 = 0.0f, rs2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) bc[tid][i] = ko.R[i];
-    bc[tid][9] = (float)c0; bc[tid][10] = (float)c1; bc[tid][11] = (float)c2;
+  for (int i = 0; i < NI; ++i) {
+    const int g = (i * kGroup + w) * 64 + lane;
+    const bool valid = g < nq, al = g < nqa;
+    gi[i] = valid ? g : nq - 1;
+    const int ga = al ? g : 0;
+    const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float4 p = r4[3 * ga], q = r4[3 * ga + 1], r = r4[3 * ga + 2];
+    rp[i] = al ? p : z;
+    rq[i] = al ? q : z;
+    rr[i] = al ? r : z;
+    mk[i] = al ? 1.0f : 0.0f;
+    const int4 sv = s4[gi[i]];
+    sl[i] = valid ? sv : int4{-1, -1, -1, -1};
+    rs0 += rp[i].x + rp[i].w + rq[i].z + rr[i].y;
+    rs1 += rp[i].y + rq[i].x + rq[i].w + rr[i].z;
+    rs2 += rp[i].z + rq[i].y + rr[i].x + rr[i].w;
+  }
+  {
+    const double t0 = wave_sum((double)rs0), t1 = wave_sum((double)rs1), t2 = wave_sum((double)rs2);
+    if (lane == 0) { rpart[w][0] = t0; rpart[w][1] = t1; rpart[w][2] = t2; }
+  }
+  CVF_STAMP(1);
+  // ---- the batch's frames, one after the other
+  // (issuing the next frame's loads before this frame's arithmetic was tried: 36 more live registers push the
+  // kernel past 128 VGPRs, i.e. to one workgroup per CU or into spills - 2.8 TB/s instead of 4.5)
+#pragma unroll 1
+  for (int j = 0; j < kGroup; ++j) {
+    const int64_t frame = f0 + j < B ? f0 + j : B - 1;
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + frame * nc);
+    float* capL = dyn + (size_t)j * nslot * 3;
+    float4 a[NI], b[NI], c[NI];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) bc[tid][12 + i] = ko.Kinv[i];
-    cD[tid][0] = c0; cD[tid][1] = c1; cD[tid][2] = c2;
+    for (int i = 0; i < NI; ++i) {
+      a[i] = x4[3 * gi[i]];
+      b[i] = x4[3 * gi[i] + 1];
+      c[i] = x4[3 * gi[i] + 2];
+    }
+    float s[12];
+#pragma unroll
+    for (int v = 0; v < 12; ++v) s[v] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      // (rows of atoms outside the align set are zero, their coordinates are masked out of the centroid)
+      auto atom4 = [&](float x0, float x1, float x2, float r0, float r1, float r2) {
+        s[0] = fmaf(mk[i], x0, s[0]); s[1] = fmaf(mk[i], x1, s[1]); s[2] = fmaf(mk[i], x2, s[2]);
+        s[3] = fmaf(x0, r0, s[3]); s[4] = fmaf(x0, r1, s[4]); s[5] = fmaf(x0, r2, s[5]);
+        s[6] = fmaf(x1, r0, s[6]); s[7] = fmaf(x1, r1, s[7]); s[8] = fmaf(x1, r2, s[8]);
+        s[9] = fmaf(x2, r0, s[9]); s[10] = fmaf(x2, r1, s[10]); s[11] = fmaf(x2, r2, s[11]);
+      };
+      atom4(a[i].x, a[i].y, a[i].z, rp[i].x, rp[i].y, rp[i].z);
+      atom4(a[i].w, b[i].x, b[i].y, rp[i].w, rq[i].x, rq[i].y);
+      atom4(b[i].z, b[i].w, c[i].x, rq[i].z, rq[i].w, rr[i].x);
+      atom4(c[i].y, c[i].z, c[i].w, rr[i].y, rr[i].z, rr[i].w);
+      if (sl[i].x >= 0) { capL[3 * sl[i].x] = a[i].x; capL[3 * sl[i].x + 1] = a[i].y; capL[3 * sl[i].x + 2] = a[i].z; }
+      if (sl[i].y >= 0) { capL[3 * sl[i].y] = a[i].w; capL[3 * sl[i].y + 1] = b[i].x; capL[3 * sl[i].y + 2] = b[i].y; }
+      if (sl[i].z >= 0) { capL[3 * sl[i].z] = b[i].z; capL[3 * sl[i].z + 1] = b[i].w; capL[3 * sl[i].z + 2] = c[i].x; }
+      if (sl[i].w >= 0) { capL[3 * sl[i].w] = c[i].y; capL[3 * sl[i].w + 1] = c[i].z; capL[3 * sl[i].w + 2] = c[i].w; }
+    }
+    // wave reduction of the 12 sums, 4 per round (the per-lane sums cover <= 4 NI atoms: fp32; from here on fp64)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[v * kRedPitch + lane] = s[4 * r + v];
+      const float4 t = *reinterpret_cast<const float4*>(red + (lane >> 4) * kRedPitch + 4 * (lane & 15));
+      double d = ((double)t.x + (double)t.y) + ((double)t.z + (double)t.w);
+      d += dpp_movd<0x111, 0xf>(d);
+      d += dpp_movd<0x112, 0xf>(d);
+      d += dpp_movd<0x114, 0xf>(d);
+      d += dpp_movd<0x118, 0xf>(d);
+      if ((lane & 15) == 15) part[j][w][4 * r + (lane >> 4)] = d;
+    }
+  }
+  CVF_STAMP(2);
+  __syncthreads();
+  CVF_STAMP(3);
+  if (tid < kGroup * 15) {   // sums[frame][value] over the eight waves, fixed order
+    const int j = tid / 15, v = tid - 15 * j;
+    double t = 0.0;
+    if (v < 12) {
+#pragma unroll
+      for (int ww = 0; ww < kGroup; ++ww) t += part[j][ww][v];
+    } else {
+#pragma unroll
+      for (int ww = 0; ww < kGroup; ++ww) t += rpart[ww][v - 12];
+    }
+    sums[j][v] = t;
   }
   __syncthreads();
-  const int64_t tile = f0 / CVF_TILE;
-  const int l0 = (int)(f0 % CVF_TILE);
-  if (aux_tiled != nullptr && lane < CVF_AUX_ROWS) aux_tiled[(tile * CVF_AUX_ROWS + lane) * CVF_TILE + l0 + fi] = bc[fi][lane];
-  if (slot_xyz != nullptr) {  // compact copy of the feature atoms for the derivative kernels (padded frame index)
-    float* dst = slot_xyz + (f0 + fi) * (int64_t)nslot * 3;
-    for (int i = lane; i < nslot * 3; i += 64) dst[i] = capL[i];
-  }
-  float R[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = bc[fi][i];
-  const double cc0 = cD[fi][0], cc1 = cD[fi][1], cc2 = cD[fi][2];
-  float* fr = (feat_rows && real) ? feat_rows + frame * pp.d_r : nullptr;
-  auto emit = [&](int o, float v) {
-    if (feat_tiled) featL[o * kGroup + fi] = v;
-    if (fr) fr[o] = v;
-  };
-  auto satom = [&](int sl) { return V3{capL[3 * sl], capL[3 * sl + 1], capL[3 * sl + 2]}; };
-  for (int r = lane; r < pp.n_rec; r += 64) {
-    const int32_t* p = pp.rec_slot + 6 * r;   // like rec, atom fields hold slots
-    const Rec rc{p[0], p[1], p[2], p[3], p[4], p[5]};
-    if (rc.type == CVF_FEAT_POSITION) {
-      const V3 xa = satom(rc.a0);
-      const V3 xc = v3((float)((double)xa.x - cc0), (float)((double)xa.y - cc1), (float)((double)xa.z - cc2));
-      const V3 al = row_times(xc, R);
-      emit(rc.out, al.x);
-      emit(rc.out + 1, al.y);
-      emit(rc.out + 2, al.z);
-    } else if (rc.type == CVF_FEAT_BOND) {
-      emit(rc.out, bond_eval(satom(rc.a0), satom(rc.a1)).val);
-    } else if (rc.type == CVF_FEAT_ANGLE) {
-      const float cs = angle_eval(satom(rc.a0), satom(rc.a1), satom(rc.a2)).cs;
-      emit(rc.out, pp.use_angle_value ? acosf(cs) : cs);
-    } else {
-      const DihedralG dg = dihedral_eval(satom(rc.a0), satom(rc.a1), satom(rc.a2), satom(rc.a3));
-      if (pp.use_angle_value) {
-        emit(rc.out, atan2f(dg.sn, dg.cs));
-      } else {
-        emit(rc.out, dg.cs);
-        emit(rc.out + 1, dg.sn);
-      }
-    }
-  }
-  if (feat_tiled != nullptr) {
-    __syncthreads();
-    for (int idx = tid; idx < pp.d_r * kGroup; idx += 64 * kGroup) {
-      const int o = idx / kGroup, f = idx % kGroup;
-      feat_tiled[(tile * pp.d_r + o) * CVF_TILE + l0 + f] = featL[idx];
-    }
-  }
+  const int fi = w;
+  const bool real = f0 + fi < B;
+  const int64_t frame = real ? f0 + fi : B - 1;
+  const float* capL = dyn + (size_t)fi * nslot * 3;
+  large_solve_features(pp, B, f0, tid, lane, fi, real, frame, sums, bc, cD, capL, featL, feat_tiled, feat_rows, aux_tiled,
+                       slot_xyz);
 }
 
 }  // namespace
@@ -310,6 +507,22 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
       if (ldsc > 48 * 1024) {
         (void)hipFuncSetAttribute((const void*)k1_large_capture_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
         (void)hipFuncSetAttribute((const void*)k1_large_capture_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
+      }
+      const int ni = (N / 4 + 64 * kGroup - 1) / (64 * kGroup);
+      // (the slice kernel stages its reductions in the feature staging area: needs the tiled output's buffer)
+      const bool slice = vec4 && ni <= 4 && feat_tiled != nullptr && (size_t)pp->d_r * kGroup >= (size_t)kGroup * 4 * 68 &&
+                         getenv("CVF_K1_NOSLICE") == nullptr;
+      if (slice) {
+        auto go = [&](auto kernel) {
+          if (ldsc > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
+          hipLaunchKernelGGL(kernel, dim3((unsigned)groups), dim3(64 * kGroup), ldsc, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled,
+                             slot_xyz);
+        };
+        if (ni == 1) go(k1_large_slice_kernel<1>);
+        else if (ni == 2) go(k1_large_slice_kernel<2>);
+        else if (ni == 3) go(k1_large_slice_kernel<3>);
+        else go(k1_large_slice_kernel<4>);
+        return cvf_check_launch("k1_large_slice_kernel");
       }
       if (vec4)
         hipLaunchKernelGGL(k1_large_capture_kernel<true>, dim3((unsigned)groups), dim3(64 * kGroup), ldsc, s, *pp, x, B,

@@ -62,7 +62,7 @@ typedef struct cvf_pp_desc {
    * use ("slots") to LDS while the frame goes by, instead of gathering them from HBM afterwards */
   const int32_t* atom_align; /* [N]: index b of the atom in align_idx / ref_c, or -1 */
   const int32_t* atom_slot;  /* [N] (16-byte aligned): slot of the atom, or -1 when no feature uses it */
-  const int32_t* rec_slot;   /* [n_rec*6]: rec with the atom fields replaced by slots */
+  const int32_t* rec_slot;   /* [n_rec*6]: rec with the atom fields replaced by slots; any order (best grouped by type) */
   const int32_t* slot_atom;  /* [n_slot]: atom of each slot */
   int32_t n_slot;
   int32_t pad2_;
