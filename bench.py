@@ -162,6 +162,9 @@ def main():
         # a second, eager pass of the same K steps (not part of `value`)
         task._use_graphs, task._events = False, {}
         for i in range(args.steps):
+            # park the GPU while the host queues this step's launches, so that the events bracket back-to-back
+            # kernel executions rather than the host's launch latency
+            torch.cuda._sleep(2_000_000)
             step(args.warmup + args.steps + i)
         barrier()
         task._use_graphs = True
@@ -178,16 +181,28 @@ def main():
     if rank != 0:
         return
     dom = max(kern_ms, key=kern_ms.get)
+
+    def pmc_traffic(call):
+        """HBM bytes per launch of the kernel behind a C-ABI call, from the committed rocprofv3 PMC passes."""
+        kernel = {"cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
+                  "cvf_align_feature_fwd": "k1_align_kernel"}.get(call)
+        path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if kernel is None or not os.path.exists(path) or B != 20000 or args.workload != "c3":
+            return None
+        with open(path) as fh:
+            c = json.load(fh)["kernels"].get(kernel)
+        return None if c is None else (2.0 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024.0
+
     if dom in ("cvf_ef_backward", "cvf_ef_mlp_fwd"):
         flop = (FLOP_BWD if dom == "cvf_ef_backward" else FLOP_FWD) * B
         ach = flop / (kern_ms[dom] * 1e-3) / 1e12
         roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS,
-                    traffic=None, avg_launch_us=kern_ms[dom] * 1e3,
+                    traffic=pmc_traffic(dom), avg_launch_us=kern_ms[dom] * 1e3,
                     note="fp32 work (VALU chains + f32-input MFMA weight gradients); peak = fp32 vector = fp32 MFMA rate")
     else:
         ach = K1_BYTES * B / (kern_ms[dom] * 1e-3) / 1e9
-        roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
-                    avg_launch_us=kern_ms[dom] * 1e3)
+        roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                    traffic=pmc_traffic(dom), avg_launch_us=kern_ms[dom] * 1e3)
     k1 = kern_ms["cvf_align_feature_fwd"]
     k1_gbs = K1_BYTES * B / (k1 * 1e-3) / 1e9
     out = {
@@ -209,12 +224,15 @@ def main():
                    "parallelism": f"dp{world} (frames sharded; all-reduce of batch sums + flat gradient)"},
         "roofline": roof,
         "roofline_align_feature": {"kernel": "cvf_align_feature_fwd", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": k1 * 1e3,
+                                   "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("cvf_align_feature_fwd"),
+                                   "avg_launch_us": k1 * 1e3,
                                    "bytes_per_frame": K1_BYTES, "frames_per_launch": B},
         "kernel_avg_us": {n: v * 1e3 for n, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
         "kernel_timing": ("HIP events around each C-ABI call over a second, eager pass of the same steps (the timed region "
                           "replays one hipGraph per step)") if graphs else "HIP events around each C-ABI call in the timed region",
         "hip_graph": bool(graphs),
+        "traffic_note": ("roofline.traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from profiles/r1_pmc_traffic.json "
+                         "(separate rocprofv3 --pmc passes of this command; gfx950 FETCH_SIZE halving corrected)"),
         "final_loss": final_loss,
     }
     if world == 1 and args.cpu_seconds > 0:
