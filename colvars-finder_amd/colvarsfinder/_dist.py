@@ -23,9 +23,23 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def collectives():
+    """True when the step must run its two all-reduces: more than one rank, or CVF_FORCE_COLLECTIVES=1 in an
+    initialised (possibly one-rank) group - the latter exercises the data-parallel code path, including its hipGraph
+    capture with the RCCL kernels inside, on a single GPU."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("CVF_FORCE_COLLECTIVES", "0") == "1"
+
+
+def backend():
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
 def init_from_env(backend=None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run)."""
-    if world() > 1 or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    forced = os.environ.get("CVF_FORCE_COLLECTIVES", "0") == "1" and "MASTER_PORT" in os.environ
+    if world() > 1 or (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not forced) or (dist.is_available() and dist.is_initialized()):
         return
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
@@ -45,7 +59,7 @@ def local_slice(n_global, r=None, w=None):
 
 def allreduce_sum_(t):
     """In-place sum over ranks; a no-op in a single-process run."""
-    if world() > 1:
+    if collectives():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 

@@ -354,8 +354,9 @@ class EigenFunctionTask(TrainingTask):
                                                            _hip.stream()), "cvf_metric_dense_tensors")
         self._ws = {}
         self._graphs = {}
-        # whole-step hipGraph replay (single process; CVF_GRAPH=0 turns it off)
-        self._use_graphs = _dist.world() == 1 and os.environ.get("CVF_GRAPH", "1") != "0"
+        # whole-step hipGraph replay (CVF_GRAPH=0 turns it off).  In a data-parallel job the two RCCL all-reduces are
+        # captured inside the graph (backend nccl only; a failed capture falls back to eager launches for good)
+        self._use_graphs = os.environ.get("CVF_GRAPH", "1") != "0" and (not _dist.collectives() or _dist.backend() == "nccl")
 
     # ---------------------------------------------------------------- model views
     def get_reordered_eigenfunctions(self, model, cvec):
@@ -397,7 +398,7 @@ class EigenFunctionTask(TrainingTask):
                        P(ws.k1_scratch), s)
         self._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(ws.y),
                    P(ws.g) if lag == 0 else None, s)
-        single = _dist.world() == 1   # no cross-rank reduction: the loss tail runs inside the stats launch
+        single = not _dist.collectives()   # no cross-rank reduction: the loss tail runs inside the stats launch
         lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
         if lag == 0:   # q = J A J^T g, E, and the batch sums (K2/K3 + K5) in one launch
             self._call("cvf_metric_apply", lib.cvf_metric_apply_stats, self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), k,
@@ -430,7 +431,7 @@ class EigenFunctionTask(TrainingTask):
         """One optimisation step on device tensors; returns the device vector
         ``[loss, npl, pen, eig_1..k, cvec_1..k]`` (fp64) without synchronising the host."""
         ws = self._forward(X, w, X_lag, w_lag)
-        fused = self._backward(ws, w, w_lag, advance=True, fuse_adam=(_dist.world() == 1))
+        fused = self._backward(ws, w, w_lag, advance=True, fuse_adam=not _dist.collectives())
         if not fused:
             self.optimizer.step(advance=False)
         return ws.loss_vec
@@ -448,8 +449,18 @@ class EigenFunctionTask(TrainingTask):
             out_slot.copy_(fn())                      # eager warm-up: allocates the workspace of this batch size
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out_slot.copy_(fn())
+            try:
+                with torch.cuda.graph(g):
+                    out_slot.copy_(fn())
+            except Exception as exc:                   # e.g. a collective that cannot be captured on this stack
+                if not _dist.collectives():
+                    raise
+                self._use_graphs = False
+                self._graphs.clear()
+                torch.cuda.synchronize()
+                print(f"[colvarsfinder] hipGraph capture of the data-parallel step failed ({type(exc).__name__}: {exc}); "
+                      "continuing with eager launches", flush=True)
+                return
             self._graphs[key] = g
             return                                     # the warm-up call already did this step's work once... see note
         g.replay()
