@@ -134,11 +134,20 @@ def main():
 
     log = torch.zeros(n_batches, 3 + 2 * K_NETS, device=dev, dtype=torch.float64)
 
+    pipeline = task._pipeline
+
     def step(i):
-        # the product's own step path: whole-step hipGraph replay per (static) batch when world == 1
+        # the product's own step path (EigenFunctionTask.train): whole-step hipGraph replay per (static) batch, and the
+        # alignment kernel of batch i+1 - which does not depend on the parameters - running beside step i
         b = i % n_batches
         s = b * B
-        task._graph_step(("bench", b), lambda: task.train_step(X[s:s + B], Wt[s:s + B]), log[b])
+        if pipeline:
+            s2 = ((i + 1) % n_batches) * B
+            task._graph_step(("bench", b, i % 2, i > 0),
+                             lambda: task.train_step(X[s:s + B], Wt[s:s + B], slot=i % 2, aligned=i > 0, prefetch=(X[s2:s2 + B], None)),
+                             log[b])
+        else:
+            task._graph_step(("bench", b), lambda: task.train_step(X[s:s + B], Wt[s:s + B]), log[b])
         return log[b]
 
     def barrier():
@@ -231,6 +240,7 @@ def main():
         "kernel_timing": ("HIP events around each C-ABI call over a second, eager pass of the same steps (the timed region "
                           "replays one hipGraph per step)") if graphs else "HIP events around each C-ABI call in the timed region",
         "hip_graph": bool(graphs),
+        "pipelined_alignment": bool(pipeline),
         "traffic_note": ("roofline.traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from profiles/r1_pmc_traffic.json "
                          "(separate rocprofv3 --pmc passes of this command; gfx950 FETCH_SIZE halving corrected)"),
         "final_loss": final_loss,

@@ -272,8 +272,11 @@ class _EFWorkspace:
         f32 = dict(device=device, dtype=torch.float32)
         f64 = dict(device=device, dtype=torch.float64)
         self.B, self.T, self.Tt = B, T, Tt
-        self.feat = torch.empty(Tt * d_r * _hip.TILE, **f32)
-        self.aux = torch.empty(T * _hip.AUX_ROWS * _hip.TILE, **f32)
+        # features / alignment data are double-buffered: the alignment kernel of the NEXT batch does not depend on
+        # the parameters, so the training loop runs it beside this batch's step (EigenFunctionTask.train_step)
+        self.slot = 0
+        self._feat = [torch.empty(Tt * d_r * _hip.TILE, **f32) for _ in range(2)]
+        self._aux = [torch.empty(T * _hip.AUX_ROWS * _hip.TILE, **f32) for _ in range(2)]
         self.y = torch.empty(Tt * k * _hip.TILE, **f32)
         if lag == 0:
             self.g = torch.empty(T * k * d_r * _hip.TILE, **f32)
@@ -286,9 +289,13 @@ class _EFWorkspace:
         self.stats = torch.empty(lib.cvf_ef_nstats(k, lag), **f64)
         self.loss_vec = torch.empty(3 + 2 * k, **f64)
         self.coef = torch.empty(4 * k + k * k, **f64)
-        self.k1_scratch, self.k1_scratch_checked = None, False   # large-molecule alignment scratch, sized on first use
+        self._k1_scratch, self.k1_scratch_checked = [None, None], False   # large-molecule alignment scratch, sized on first use
         self.slab_rows = lib.cvf_ef_backward_slab_rows(Tt)
         self.slab = torch.empty(self.slab_rows * n_params, **f32)
+
+    feat = property(lambda self: self._feat[self.slot])
+    aux = property(lambda self: self._aux[self.slot])
+    k1_scratch = property(lambda self: self._k1_scratch[self.slot])
 
 
 class EigenFunctionTask(TrainingTask):
@@ -357,6 +364,11 @@ class EigenFunctionTask(TrainingTask):
         # whole-step hipGraph replay (CVF_GRAPH=0 turns it off).  In a data-parallel job the two RCCL all-reduces are
         # captured inside the graph (backend nccl only; a failed capture falls back to eager launches for good)
         self._use_graphs = os.environ.get("CVF_GRAPH", "1") != "0" and (not _dist.collectives() or _dist.backend() == "nccl")
+        # CVF_PIPELINE=1: the next batch's alignment (independent of the parameters) runs on this stream beside the
+        # current step's backward kernel.  Off by default: at 20 000 frames per step it measured 133 us/step against
+        # 126 serial - the two-branch graph costs more at the fork/join than the 14 us kernel it hides.
+        self._side = torch.cuda.Stream(device=self.device)
+        self._pipeline = os.environ.get("CVF_PIPELINE", "0") == "1"
 
     # ---------------------------------------------------------------- model views
     def get_reordered_eigenfunctions(self, model, cvec):
@@ -381,21 +393,31 @@ class EigenFunctionTask(TrainingTask):
             ws = self._ws[B] = _EFWorkspace(B, self.k, self._pp.d_r, self._flat.n, self.lag_idx, self._flat.desc, self.device)
         return ws
 
-    def _forward(self, X, w, X_lag=None, w_lag=None):
-        """Everything up to the loss for one (local) batch; leaves loss_vec / coef on the device."""
+    def _align(self, ws, slot, X, X_lag):
+        """K1 of one batch (and of its lagged partner) into feature buffer ``slot``."""
+        lib, P = _hip.lib(), _hip.ptr
+        B, d_r = ws.B, self._pp.d_r
+        self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X), B, P(ws._feat[slot]), None, P(ws._aux[slot]),
+                   P(ws._k1_scratch[slot]), _hip.stream())
+        if self.lag_idx > 0:
+            feat_lag = ws._feat[slot][ws.T * d_r * _hip.TILE:]
+            self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X_lag), B, P(feat_lag), None, None,
+                       P(ws._k1_scratch[slot]), _hip.stream())
+
+    def _forward(self, X, w, X_lag=None, w_lag=None, slot=0, aligned=False):
+        """Everything up to the loss for one (local) batch; leaves loss_vec / coef on the device.
+        ``aligned``: buffer ``slot`` already holds this batch's features (a previous step prefetched them)."""
         lib, s, P = _hip.lib(), _hip.stream(), _hip.ptr
         B = X.shape[0]
         ws = self._workspace(B)
+        ws.slot = slot
         fl, k, d_r = self._flat, self.k, self._pp.d_r
         lag = self.lag_idx
-        if ws.k1_scratch is None and not ws.k1_scratch_checked:
-            ws.k1_scratch, ws.k1_scratch_checked = _hip.align_scratch(self._pp, B, self.device), True
-        self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X), B, P(ws.feat), None, P(ws.aux),
-                   P(ws.k1_scratch), s)
-        if lag > 0:
-            feat_lag = ws.feat[ws.T * d_r * _hip.TILE:]
-            self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X_lag), B, P(feat_lag), None, None,
-                       P(ws.k1_scratch), s)
+        if not ws.k1_scratch_checked:
+            ws._k1_scratch = [_hip.align_scratch(self._pp, B, self.device) for _ in range(2)]
+            ws.k1_scratch_checked = True
+        if not aligned:
+            self._align(ws, slot, X, X_lag)
         self._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(ws.y),
                    P(ws.g) if lag == 0 else None, s)
         single = not _dist.collectives()   # no cross-rank reduction: the loss tail runs inside the stats launch
@@ -427,13 +449,21 @@ class EigenFunctionTask(TrainingTask):
             _dist.allreduce_sum_(fl.grad)                                                # collective #2
         return adam is not None
 
-    def train_step(self, X, w, X_lag=None, w_lag=None):
+    def train_step(self, X, w, X_lag=None, w_lag=None, slot=0, aligned=False, prefetch=None):
         """One optimisation step on device tensors; returns the device vector
-        ``[loss, npl, pen, eig_1..k, cvec_1..k]`` (fp64) without synchronising the host."""
-        ws = self._forward(X, w, X_lag, w_lag)
+        ``[loss, npl, pen, eig_1..k, cvec_1..k]`` (fp64) without synchronising the host.
+        ``prefetch = (X_next, X_lag_next)``: align that batch into the other feature buffer on a side stream while this
+        step's backward kernel runs; the next call then passes ``slot ^ 1, aligned=True``."""
+        ws = self._forward(X, w, X_lag, w_lag, slot, aligned)
+        if prefetch is not None:   # beside the backward kernel, which leaves SIMD slots and LDS free at these sizes
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self._align(ws, slot ^ 1, prefetch[0], prefetch[1])
         fused = self._backward(ws, w, w_lag, advance=True, fuse_adam=not _dist.collectives())
         if not fused:
             self.optimizer.step(advance=False)
+        if prefetch is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
         return ws.loss_vec
 
     # -- hipGraph replay of a whole step: batches are static (shuffle=False, core.py:472-481), so every
@@ -548,7 +578,13 @@ class EigenFunctionTask(TrainingTask):
             self.model.train()
             for it, (a, b) in enumerate(tr_batches):
                 X, w, Xl, wl = sl(Xtr, a, b)
-                self._graph_step(("train", it), lambda: self.train_step(X, w, Xl, wl), log_tr[it])
+                nxt = None
+                if self._pipeline and it + 1 < len(tr_batches):
+                    Xn, _, Xln, _ = sl(Xtr, *tr_batches[it + 1])
+                    nxt = (Xn, Xln)
+                self._graph_step(("train", it), lambda: self.train_step(X, w, Xl, wl, slot=it % 2,
+                                                                          aligned=self._pipeline and it > 0, prefetch=nxt),
+                                 log_tr[it])
             for it, (a, b) in enumerate(te_batches):              # core.py:535-551 (same loss, no update)
                 X, w, Xl, wl = sl(Xte, a, b)
                 self._graph_step(("test", it), lambda: self._forward(X, w, Xl, wl).loss_vec, log_te[it])
