@@ -105,10 +105,13 @@ def main():
     ap.add_argument("--batch", type=int, default=20000, help="frames per GPU per step (reference notebook: 20000)")
     ap.add_argument("--frames", type=int, default=100000, help="frames per GPU shard (config 3: 100k)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 disables it)")
-    ap.add_argument("--workload", choices=["c3", "c5"], default="c3", help="c3 = the benchmark line; c5 = config-5 shape (extra)")
+    ap.add_argument("--workload", choices=["c3", "c5", "c2"], default="c3",
+                    help="c3 = the benchmark line; c5 = config-5 shape, c2 = config-2 AutoEncoderTask (extra measurements)")
     args = ap.parse_args()
     if args.workload == "c5":
         return main_c5(args)
+    if args.workload == "c2":
+        return main_c2(args)
 
     from colvarsfinder import _dist, core, nn, pp
     from tests.synth import Traj, diag_coeff_for
@@ -299,6 +302,50 @@ def main_c5(args):
                           "ms_per_step": elapsed / args.steps * 1e3, "final_loss": float(lv[0]),
                           "kernel_avg_us": dict(sorted(kern.items(), key=lambda kv: -kv[1])),
                           "align_feature_GBps": bpf * B / (k1 * 1e-6) / 1e9, "align_feature_frac_of_8TBps": bpf * B / (k1 * 1e-6) / 8e12}))
+
+
+def main_c2(args):
+    """Config 2: alanine-dipeptide-shaped AutoEncoderTask, 22 atoms x 100k frames, bottleneck 2 (encoder [66,20,20,20,2],
+    decoder [2,10,10,66]), B = 20 000.  Extra measurement, not the benchmark line: the step is one fused kernel pair
+    (forward + weighted MSE + gradient, then slab sum + Adam) on the feature trajectory K1 produced once up front."""
+    from colvarsfinder import _dist, core, nn, pp
+    from tests.synth import Traj
+    _dist.init_from_env("nccl")
+    world, rank = _dist.world(), _dist.rank()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    x, w, ref = make_shard(args.frames, rank)
+    torch.manual_seed(SEED)
+    model = nn.AutoEncoder([66, 20, 20, 20, 2], [2, 10, 10, 66])
+    layer = pp.AlignFeatureLayer(N_ATOMS, list(range(N_ATOMS)), ref, [("position", tuple(range(N_ATOMS)))])
+    t0 = time.perf_counter()
+    task = core.AutoEncoderTask(Traj(x, w, 1.0), layer, model, "/tmp/cvf_bench", learning_rate=LR, batch_size=args.batch,
+                                device=dev, verbose=False, save_model_every_step=0)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t0
+    B = min(args.batch, args.frames)
+    n_batches = args.frames // B
+    idx = torch.arange(args.frames, device=dev, dtype=torch.long)
+    Wt = task._weights
+    inv = [1.0 / float(Wt[b * B:(b + 1) * B].sum(dtype=torch.float64)) for b in range(n_batches)]
+
+    def step(i):
+        b = i % n_batches
+        return task._step(task._feature_traj, idx[b * B:(b + 1) * B], Wt[b * B:(b + 1) * B], True, inv[b], advance=True,
+                          fuse_adam=(world == 1))
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"workload": "config 2: AutoEncoderTask [66,20,20,20,2]/[2,10,10,66], 22 atoms, B=20000", "n_gpus": world,
+                          "value": world * B * args.steps / elapsed, "unit": "frames/s", "ms_per_step": elapsed / args.steps * 1e3,
+                          "final_loss": float(loss), "init_seconds_incl_feature_trajectory": t_init}))
 
 
 if __name__ == "__main__":

@@ -189,6 +189,253 @@ __global__ __launch_bounds__(64) void ae_step_kernel(cvf_mlp_desc mlp, const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The training step on the matrix cores.  Block = one 64-frame tile, four waves; wave v owns the frames 16 v .. 16 v + 15
+// (the N = 16 columns of v_mfma_f32_16x16x4_f32).  The activations a_1 .. a_{L-1} stay in LDS as [row][frame] images;
+//   forward    z = W a  :  A = W (LDS copy of theta), B = the previous image's 16 frame columns  -> wave-local, no barrier
+//   error      zbar_L = 2 w (out - f) / sum w  (f re-read from global in the accumulator layout)
+//   per layer, backwards, one barrier each:
+//     W_l gradient = zbar_{l+1} (x) [a_l ; 1] over the 64 frames: 16x16 tiles dealt round-robin to the waves, both operands
+//                    read as 16-byte LDS vectors (k-slot order 16 j + 4 kq + c on both), written straight to the block's
+//                    slab row (each tile has exactly one owner: no atomics, fixed summation order);
+//                    the first layer's B operand (the features) comes from global memory in the same k order
+//     zbar_l     = (W^T zbar_{l+1}) .* act'(a_l):  A = W^T from LDS, B = zbar_{l+1}'s 16 frame columns -> wave-local
+// The first, lane-per-frame version of this step (one wave per tile, scalar weight loads, 256 blocks) took 290 us at
+// B = 20 000 with [66,20,20,20,2]/[2,10,10,66]; see DESIGN.md for this one.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int AP = 68;          // image pitch: rows are 16-byte aligned
+constexpr int kAeMaxBlocks = 2048;
+
+struct AeMLayout {
+  int img_off[CVF_MAX_LAYERS + 1];   // dword offset of image a_l, l = 1..L-1 (rows d_l + 1, the last one all ones)
+  int zb_off, ab_off, w_off, total;
+  int zb_rows, ab_rows;
+};
+__host__ __device__ inline AeMLayout ae_mlayout(const cvf_mlp_desc& m) {
+  AeMLayout lay;
+  int rows = 0, dh = 1, dall = 1;
+  for (int l = 1; l < m.n_layers; ++l) {
+    lay.img_off[l] = rows * AP;
+    rows += m.dims[l] + 1;
+    dh = m.dims[l] > dh ? m.dims[l] : dh;
+  }
+  rows += 16;   // an operand tile may read up to 15 rows past the last image: keep them inside the zeroed area
+  for (int l = 1; l <= m.n_layers; ++l) dall = m.dims[l] > dall ? m.dims[l] : dall;
+  lay.zb_rows = up16(dall) + 16;
+  lay.ab_rows = up16(dh) + 16;
+  lay.zb_off = rows * AP;
+  lay.ab_off = lay.zb_off + lay.zb_rows * AP;
+  lay.w_off = lay.ab_off + lay.ab_rows * AP;
+  lay.total = lay.w_off + ((m.n_params + 3) & ~3);
+  return lay;
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
+                                                       const float* __restrict__ feat_rows, const int64_t* __restrict__ idx,
+                                                       int64_t B, const float* __restrict__ w, double inv_wsum, int with_grad,
+                                                       float* __restrict__ slab, double* __restrict__ partial,
+                                                       int32_t* __restrict__ step) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int row16 = lane & 15, kq = lane >> 4;
+  const int fcol = 16 * wv + row16;          // this lane's frame column in forward / backward-data MFMAs
+  const int L = mlp.n_layers;
+  const int d0 = mlp.dims[0], dL = mlp.dims[L];
+  const AeMLayout lay = ae_mlayout(mlp);
+  float* ZB = lds + lay.zb_off;
+  float* AB = lds + lay.ab_off;
+  float* WL = lds + lay.w_off;
+  // zero everything (operand tiles read rows past an image: they must be finite), ones rows, weights
+  for (int i = tid; i < lay.w_off; i += 256) lds[i] = 0.0f;
+  for (int i = tid; i < mlp.n_params; i += 256) WL[i] = theta[i];
+  __syncthreads();
+  for (int l = 1; l < L; ++l)
+    if (tid < 64) lds[lay.img_off[l] + mlp.dims[l] * AP + tid] = 1.0f;
+  __syncthreads();
+  const int64_t T = (B + CVF_TILE - 1) / CVF_TILE;
+  double loss_acc = 0.0, w_acc = 0.0;
+  float* out_row = slab + (int64_t)blockIdx.x * mlp.n_params;
+  for (int64_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
+    const bool first = tile == (int64_t)blockIdx.x;
+    // ---- this lane's frame (forward layout) and the tile's 64 frames (outer-product layout)
+    const int64_t b = tile * CVF_TILE + fcol;
+    const bool valid = b < B;
+    const int64_t bb = valid ? b : B - 1;
+    const int64_t frame = idx ? idx[bb] : bb;
+    const float wb = valid ? w[bb] : 0.0f;
+    const float* __restrict__ frow = feat_rows + frame * d0;
+    // ---- forward
+    for (int l = 0; l < L; ++l) {
+      const int din = mlp.dims[l], dout = mlp.dims[l + 1];
+      const float* Wl = WL + mlp.w_off[0][l];
+      const float* bl = WL + mlp.b_off[0][l];
+      const float* in = l > 0 ? lds + lay.img_off[l] : nullptr;
+      float* dst = l + 1 < L ? lds + lay.img_off[l + 1] : ZB;
+      const bool act = mlp.act[l] != 0;
+      for (int rt = 0; 16 * rt < dout; ++rt) {
+        const int oa = 16 * rt + row16;
+        const int oac = oa < dout ? oa : dout - 1;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int s = 0; 4 * s < din; ++s) {
+          const int i = 4 * s + kq;
+          const int ic = i < din ? i : din - 1;
+          const float av = Wl[oac * din + ic];
+          const float a = (oa < dout && i < din) ? av : 0.0f;
+          const float bv = l > 0 ? in[i * AP + fcol] : frow[ic];
+          acc = mfma4(a, bv, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * rt + 4 * kq + r;
+          if (o < dout) {
+            const float v = acc[r] + bl[o];
+            dst[o * AP + fcol] = act ? cvf_tanh(v) : v;
+          }
+        }
+      }
+    }
+    // ---- weighted squared error and zbar_L = 2 w (out - f) / sum(w)     (core.py:666); rows o = 16 rt + 4 kq + r
+    {
+      const float scale = (float)(2.0 * (double)wb * inv_wsum);
+      float err2 = 0.0f;
+      for (int rt = 0; 16 * rt < dL; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * rt + 4 * kq + r;
+          if (o < dL) {
+            const float out = ZB[o * AP + fcol];
+            const float df = out - frow[o];
+            err2 = fmaf(df, df, err2);
+            float zb = scale * df;
+            if (mlp.act[L - 1]) zb *= 1.0f - out * out;
+            ZB[o * AP + fcol] = zb;
+          }
+        }
+      loss_acc += (double)wb * (double)err2;
+      if (kq == 0) w_acc += (double)wb;
+    }
+    if (!with_grad) continue;
+    // ---- backward
+    float* Zc = ZB;
+    float* Zn = AB;
+    for (int l = L - 1; l >= 0; --l) {
+      const int din = mlp.dims[l], dout = mlp.dims[l + 1];
+      const int wo = mlp.w_off[0][l], bo = mlp.b_off[0][l];
+      __syncthreads();   // zbar_{l+1}: all 64 frame columns are in place
+      // (a) weight gradient tiles, round-robin over the waves
+      const int nct = (din + 1 + 15) / 16, nrt = (dout + 15) / 16;
+      int64_t foff[16];   // first layer: row offsets of this lane's sixteen k-slot frames (see below)
+      if (l == 0) {
+#pragma unroll
+        for (int jc = 0; jc < 16; ++jc) {
+          const int64_t fb = tile * CVF_TILE + 16 * (jc >> 2) + 4 * kq + (jc & 3);
+          const int64_t fbc = fb < B ? fb : B - 1;
+          foff[jc] = (idx ? idx[fbc] : fbc) * d0;
+        }
+      }
+      for (int pr = wv; pr < nrt * nct; pr += 4) {
+        const int rt = pr / nct, ct = pr - rt * nct;
+        const int i = 16 * ct + row16;
+        const float4* za = reinterpret_cast<const float4*>(Zc + (16 * rt + row16) * AP + 4 * kq);
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (l > 0) {
+          const float4* ib = reinterpret_cast<const float4*>(lds + lay.img_off[l] + i * AP + 4 * kq);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 a = za[4 * j], bq = ib[4 * j];
+            acc = mfma4(a.x, bq.x, acc);
+            acc = mfma4(a.y, bq.y, acc);
+            acc = mfma4(a.z, bq.z, acc);
+            acc = mfma4(a.w, bq.w, acc);
+          }
+        } else {
+          // B = [f ; 1] from global memory: k-slot kq of k-step (j, c) is frame 16 j + 4 kq + c of the tile
+          const int ic = i < d0 ? i : d0 - 1;
+          const float pad = i == d0 ? 1.0f : 0.0f;
+          float bvals[16];
+#pragma unroll
+          for (int jc = 0; jc < 16; ++jc) bvals[jc] = feat_rows[foff[jc] + ic];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 a = za[4 * j];
+            acc = mfma4(a.x, i < d0 ? bvals[4 * j + 0] : pad, acc);
+            acc = mfma4(a.y, i < d0 ? bvals[4 * j + 1] : pad, acc);
+            acc = mfma4(a.z, i < d0 ? bvals[4 * j + 2] : pad, acc);
+            acc = mfma4(a.w, i < d0 ? bvals[4 * j + 3] : pad, acc);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * rt + 4 * kq + r;
+          if (o < dout && i <= din) {
+            float* dstp = out_row + (i < din ? wo + o * din + i : bo + o);
+            *dstp = first ? acc[r] : *dstp + acc[r];
+          }
+        }
+      }
+      // (b) zbar_l for this wave's frames
+      if (l > 0) {
+        const float* Wl = WL + wo;
+        const float* al = lds + lay.img_off[l];
+        const bool act = mlp.act[l - 1] != 0;
+        for (int rt = 0; 16 * rt < din; ++rt) {
+          const int ia = 16 * rt + row16;
+          const int iac = ia < din ? ia : din - 1;
+          f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+          for (int s = 0; 4 * s < dout; ++s) {
+            const int o = 4 * s + kq;
+            const int oc = o < dout ? o : dout - 1;
+            const float av = Wl[oc * din + iac];
+            const float a = (ia < din && o < dout) ? av : 0.0f;
+            acc = mfma4(a, Zc[o * AP + fcol], acc);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * rt + 4 * kq + r;
+            if (i < din) {
+              float v = acc[r];
+              if (act) {
+                const float a = al[i * AP + fcol];
+                v *= 1.0f - a * a;
+              }
+              Zn[i * AP + fcol] = v;
+            }
+          }
+        }
+        float* t = Zc;
+        Zc = Zn;
+        Zn = t;
+      }
+    }
+    __syncthreads();   // the next tile's forward overwrites the images / ZB
+  }
+  // ---- per-block loss partials: fixed-order reduction over the block's four waves
+  __shared__ double red[4][2];
+  const double ls = wave_sum(loss_acc), wsum = wave_sum(w_acc);
+  if (lane == 0) {
+    red[wv][0] = ls;
+    red[wv][1] = wsum;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    partial[2 * blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    partial[2 * blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    if (with_grad && step != nullptr && blockIdx.x == 0) *step += 1;  // one gradient per optimiser step
+  }
+}
+
+// out2 = fixed-order sums of the per-block {sum w*err, sum w}
+__global__ void ae_loss_sum_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out2) {
+  const int p = threadIdx.x;
+  if (p < 2) {
+    double acc = 0.0;
+    for (int g = 0; g < nblocks; ++g) acc += partial[2 * g + p];
+    out2[p] = acc;
+  }
+}
+
 __global__ void ae_reduce_kernel(const float* __restrict__ slab, const double* __restrict__ partial, int nblocks, int Pn,
                                  float* __restrict__ grad, double* __restrict__ out2, int use_adam, AdamDev adam) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,14 +477,15 @@ __global__ __launch_bounds__(64) void mlp_eval_rows_kernel(cvf_mlp_desc mlp, con
 
 int ae_grid(int64_t B) {
   const int64_t T = cvf_ntiles(B);
-  return (int)(T < kAeBlocks ? T : kAeBlocks);
+  return (int)(T < kAeMaxBlocks ? T : kAeMaxBlocks);
 }
 
 }  // namespace
 
 extern "C" int64_t cvf_ae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B) {
   // slab rows + (2 doubles per block) expressed in floats
-  return (int64_t)kAeBlocks * mlp->n_params + 4 * (int64_t)kAeBlocks + 4;
+  const int64_t G = ae_grid(B);
+  return G * mlp->n_params + 4 * G + 4;
 }
 
 extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
@@ -247,28 +495,33 @@ extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const fl
   CVF_REQUIRE(mlp->n_nets == 1 && mlp->n_layers >= 1 && mlp->n_layers <= CVF_MAX_LAYERS, "cvf_ae_step: one chain expected");
   CVF_REQUIRE(mlp->dims[0] == mlp->dims[mlp->n_layers], "cvf_ae_step: output width %d != input width %d",
               mlp->dims[mlp->n_layers], mlp->dims[0]);
-  const AeLayout lay = ae_layout(*mlp, grad != nullptr);
+  CVF_REQUIRE(adam == nullptr || (grad && adam->theta && adam->m && adam->v && adam->step_count),
+              "cvf_ae_step: incomplete adam arguments");
+  const AeMLayout lay = ae_mlayout(*mlp);
   const size_t lds = (size_t)lay.total * sizeof(float);
-  CVF_REQUIRE(lds <= 160 * 1024, "cvf_ae_step: the chain needs %zu B of LDS per wave (> 160 KiB)", lds);
+  CVF_REQUIRE(lds <= 160 * 1024, "cvf_ae_step: the chain needs %zu B of LDS per workgroup (> 160 KiB)", lds);
   const int G = ae_grid(B);
+  const int Pn = mlp->n_params;
   // scratch: [slab floats][partials as doubles, 8-byte aligned]
   float* slab = scratch;
-  double* partial = reinterpret_cast<double*>(scratch + (((int64_t)kAeBlocks * mlp->n_params + 1) & ~(int64_t)1));
+  double* partial = reinterpret_cast<double*>(scratch + (((int64_t)G * Pn + 1) & ~(int64_t)1));
   hipStream_t s = (hipStream_t)stream;
-  (void)hipFuncSetAttribute((const void*)ae_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  AdamDev ad{};
-  if (adam != nullptr) {
-    CVF_REQUIRE(grad && adam->theta && adam->m && adam->v && adam->step_count, "cvf_ae_step: incomplete adam arguments");
-    ad = AdamDev{adam->theta, adam->m, adam->v, (float)adam->lr, (float)adam->beta1, (float)adam->beta2, (float)adam->eps,
-                 adam->step_count, nullptr};
-  }
-  hipLaunchKernelGGL(ae_step_kernel, dim3(G), dim3(64), lds, s, *mlp, theta, feat_rows, idx, B, w, inv_wsum,
-                     grad ? 1 : 0, slab, partial, grad ? step_count : nullptr);
-  int rc = cvf_check_launch("ae_step_kernel");
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ae_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ae_mfma_kernel, dim3(G), dim3(256), lds, s, *mlp, theta, feat_rows, idx, B, w, inv_wsum, grad ? 1 : 0, slab,
+                     partial, grad ? step_count : nullptr);
+  int rc = cvf_check_launch("ae_mfma_kernel");
   if (rc) return rc;
-  const int Pn = mlp->n_params;
-  hipLaunchKernelGGL(ae_reduce_kernel, dim3((Pn + 255) / 256), dim3(256), 0, s, slab, partial, G, Pn, grad, out2, adam != nullptr ? 1 : 0, ad);
-  return cvf_check_launch("ae_reduce_kernel");
+  hipLaunchKernelGGL(ae_loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, G, out2);
+  rc = cvf_check_launch("ae_loss_sum_kernel");
+  if (rc || grad == nullptr) return rc;
+  // fixed-order sum of the slab rows (+ the Adam update when asked for): the kernel the eigenfunction path uses
+  cvf_adam_args ad;
+  if (adam != nullptr) {
+    ad = *adam;
+    ad.mlp = nullptr;      // an AutoEncoder has no MFMA fragment copy to refresh
+    ad.packed = nullptr;
+  }
+  return cvf_slab_reduce(slab, G, Pn, grad, adam != nullptr ? &ad : nullptr, stream);
 }
 
 extern "C" int cvf_mlp_eval_rows(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, int64_t B,
