@@ -239,21 +239,46 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
                                                        int32_t* __restrict__ step) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  CVF_STAMP(18);
   const int row16 = lane & 15, kq = lane >> 4;
   const int fcol = 16 * wv + row16;          // this lane's frame column in forward / backward-data MFMAs
-  const int L = mlp.n_layers;
-  const int d0 = mlp.dims[0], dL = mlp.dims[L];
+  // The layer table is indexed with a run-time l: read from the by-value kernel argument that turns into a private
+  // (scratch-memory) copy and a ~700-cycle round trip per access; a copy in LDS costs an LDS read.
+  __shared__ int s_dims[CVF_MAX_LAYERS + 1], s_woff[CVF_MAX_LAYERS], s_boff[CVF_MAX_LAYERS], s_act[CVF_MAX_LAYERS];
+  __shared__ int s_img[CVF_MAX_LAYERS + 1];
   const AeMLayout lay = ae_mlayout(mlp);
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i <= CVF_MAX_LAYERS; ++i) {
+      s_dims[i] = mlp.dims[i];
+      s_img[i] = lay.img_off[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CVF_MAX_LAYERS; ++i) {
+      s_woff[i] = mlp.w_off[0][i];
+      s_boff[i] = mlp.b_off[0][i];
+      s_act[i] = mlp.act[i];
+    }
+  }
+  __syncthreads();
+  const int L = mlp.n_layers;
+  const int d0 = s_dims[0], dL = s_dims[L];
   float* ZB = lds + lay.zb_off;
   float* AB = lds + lay.ab_off;
   float* WL = lds + lay.w_off;
   // zero everything (operand tiles read rows past an image: they must be finite), ones rows, weights
-  for (int i = tid; i < lay.w_off; i += 256) lds[i] = 0.0f;
-  for (int i = tid; i < mlp.n_params; i += 256) WL[i] = theta[i];
+  {
+    float4* l4 = reinterpret_cast<float4*>(lds);
+    const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = tid; i < lay.w_off / 4; i += 256) l4[i] = z4;   // (every region is a multiple of AP = 68 dwords)
+#pragma unroll 4
+    for (int i = tid; i < mlp.n_params; i += 256) WL[i] = theta[i];
+  }
   __syncthreads();
   for (int l = 1; l < L; ++l)
-    if (tid < 64) lds[lay.img_off[l] + mlp.dims[l] * AP + tid] = 1.0f;
+    if (tid < 64) lds[s_img[l] + s_dims[l] * AP + tid] = 1.0f;
   __syncthreads();
+  CVF_STAMP(19);
   const int64_t T = (B + CVF_TILE - 1) / CVF_TILE;
   double loss_acc = 0.0, w_acc = 0.0;
   float* out_row = slab + (int64_t)blockIdx.x * mlp.n_params;
@@ -266,26 +291,16 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
     const int64_t frame = idx ? idx[bb] : bb;
     const float wb = valid ? w[bb] : 0.0f;
     const float* __restrict__ frow = feat_rows + frame * d0;
+    CVF_STAMP(20);
     // ---- forward
     for (int l = 0; l < L; ++l) {
-      const int din = mlp.dims[l], dout = mlp.dims[l + 1];
-      const float* Wl = WL + mlp.w_off[0][l];
-      const float* bl = WL + mlp.b_off[0][l];
-      const float* in = l > 0 ? lds + lay.img_off[l] : nullptr;
-      float* dst = l + 1 < L ? lds + lay.img_off[l + 1] : ZB;
-      const bool act = mlp.act[l] != 0;
-      for (int rt = 0; 16 * rt < dout; ++rt) {
-        const int oa = 16 * rt + row16;
-        const int oac = oa < dout ? oa : dout - 1;
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int s = 0; 4 * s < din; ++s) {
-          const int i = 4 * s + kq;
-          const int ic = i < din ? i : din - 1;
-          const float av = Wl[oac * din + ic];
-          const float a = (oa < dout && i < din) ? av : 0.0f;
-          const float bv = l > 0 ? in[i * AP + fcol] : frow[ic];
-          acc = mfma4(a, bv, acc);
-        }
+      const int din = s_dims[l], dout = s_dims[l + 1];
+      const float* Wl = WL + s_woff[l];
+      const float* bl = WL + s_boff[l];
+      const float* in = l > 0 ? lds + s_img[l] : nullptr;
+      float* dst = l + 1 < L ? lds + s_img[l + 1] : ZB;
+      const bool act = s_act[l] != 0;
+      auto finish = [&](int rt, const f32x4& acc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = 16 * rt + 4 * kq + r;
@@ -294,36 +309,92 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
             dst[o * AP + fcol] = act ? cvf_tanh(v) : v;
           }
         }
-      }
+      };
+      // B operand = this lane's frame column of the input (global feature row for the first layer, LDS image after
+      // that).  CH k-steps' worth of B values are requested together and shared by up to kRT row tiles, whose A values
+      // (weights, LDS) are requested together as well: one wait per batch instead of one per matrix instruction.
+      constexpr int kRT = 8;
+      auto layer = [&](auto ch_) {
+        constexpr int CH = decltype(ch_)::value;
+        for (int rt0 = 0; 16 * rt0 < dout; rt0 += kRT) {
+          f32x4 acc[kRT];
+#pragma unroll
+          for (int t = 0; t < kRT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          for (int s0 = 0; 4 * s0 < din; s0 += CH) {
+            float bv[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+              const int i = 4 * (s0 + u) + kq;
+              bv[u] = l == 0 ? frow[i < din ? i : din - 1] : in[i * AP + fcol];   // (rows past the image: finite, times a = 0)
+            }
+#pragma unroll
+            for (int t = 0; t < kRT; ++t) {
+              const int rt = rt0 + t;
+              if (16 * rt < dout) {   // wave-uniform
+                const int oa = 16 * rt + row16;
+                const float* wr = Wl + (oa < dout ? oa : dout - 1) * din;
+                float av[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                  const int i = 4 * (s0 + u) + kq;
+                  av[u] = wr[i < din ? i : din - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                  const int i = 4 * (s0 + u) + kq;
+                  acc[t] = mfma4((oa < dout && i < din) ? av[u] : 0.0f, bv[u], acc[t]);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < kRT; ++t)
+            if (16 * (rt0 + t) < dout) finish(rt0 + t, acc[t]);
+        }
+      };
+      if (l == 0) layer(std::integral_constant<int, 20>{});   // 80 inputs per global round trip
+      else layer(std::integral_constant<int, 8>{});
+      CVF_STAMP(41 + l);
     }
+    CVF_STAMP(21);
     // ---- weighted squared error and zbar_L = 2 w (out - f) / sum(w)     (core.py:666); rows o = 16 rt + 4 kq + r
     {
       const float scale = (float)(2.0 * (double)wb * inv_wsum);
+      const bool act_last = s_act[L - 1] != 0;
       float err2 = 0.0f;
-      for (int rt = 0; 16 * rt < dL; ++rt)
+      for (int rt0 = 0; 16 * rt0 < dL; rt0 += 4) {
+        float fv[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int o = 16 * rt + 4 * kq + r;
+        for (int u = 0; u < 16; ++u) {
+          const int o = 16 * (rt0 + (u >> 2)) + 4 * kq + (u & 3);
+          fv[u] = frow[o < dL ? o : dL - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int o = 16 * (rt0 + (u >> 2)) + 4 * kq + (u & 3);
           if (o < dL) {
             const float out = ZB[o * AP + fcol];
-            const float df = out - frow[o];
+            const float df = out - fv[u];
             err2 = fmaf(df, df, err2);
             float zb = scale * df;
-            if (mlp.act[L - 1]) zb *= 1.0f - out * out;
+            if (act_last) zb *= 1.0f - out * out;
             ZB[o * AP + fcol] = zb;
           }
         }
+      }
       loss_acc += (double)wb * (double)err2;
       if (kq == 0) w_acc += (double)wb;
     }
+    CVF_STAMP(22);
     if (!with_grad) continue;
     // ---- backward
     float* Zc = ZB;
     float* Zn = AB;
     for (int l = L - 1; l >= 0; --l) {
-      const int din = mlp.dims[l], dout = mlp.dims[l + 1];
-      const int wo = mlp.w_off[0][l], bo = mlp.b_off[0][l];
+      const int din = s_dims[l], dout = s_dims[l + 1];
+      const int wo = s_woff[l], bo = s_boff[l];
       __syncthreads();   // zbar_{l+1}: all 64 frame columns are in place
+      CVF_STAMP(23 + 2 * (L - 1 - l));
       // (a) weight gradient tiles, round-robin over the waves
       const int nct = (din + 1 + 15) / 16, nrt = (dout + 15) / 16;
       int64_t foff[16];   // first layer: row offsets of this lane's sixteen k-slot frames (see below)
@@ -341,7 +412,7 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
         const float4* za = reinterpret_cast<const float4*>(Zc + (16 * rt + row16) * AP + 4 * kq);
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         if (l > 0) {
-          const float4* ib = reinterpret_cast<const float4*>(lds + lay.img_off[l] + i * AP + 4 * kq);
+          const float4* ib = reinterpret_cast<const float4*>(lds + s_img[l] + i * AP + 4 * kq);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float4 a = za[4 * j], bq = ib[4 * j];
@@ -375,32 +446,57 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
           }
         }
       }
+      CVF_STAMP(24 + 2 * (L - 1 - l));
       // (b) zbar_l for this wave's frames
       if (l > 0) {
         const float* Wl = WL + wo;
-        const float* al = lds + lay.img_off[l];
-        const bool act = mlp.act[l - 1] != 0;
-        for (int rt = 0; 16 * rt < din; ++rt) {
-          const int ia = 16 * rt + row16;
-          const int iac = ia < din ? ia : din - 1;
-          f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-          for (int s = 0; 4 * s < dout; ++s) {
-            const int o = 4 * s + kq;
-            const int oc = o < dout ? o : dout - 1;
-            const float av = Wl[oc * din + iac];
-            const float a = (ia < din && o < dout) ? av : 0.0f;
-            acc = mfma4(a, Zc[o * AP + fcol], acc);
+        const float* al = lds + s_img[l];
+        const bool act = s_act[l - 1] != 0;
+        constexpr int kBT = 4, kBC = 8;   // row tiles per pass, k-steps per batch (as in the forward layers)
+        for (int rt0 = 0; 16 * rt0 < din; rt0 += kBT) {
+          f32x4 acc[kBT];
+#pragma unroll
+          for (int t = 0; t < kBT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          for (int s0 = 0; 4 * s0 < dout; s0 += kBC) {
+            float bv[kBC];
+#pragma unroll
+            for (int u = 0; u < kBC; ++u) bv[u] = Zc[(4 * (s0 + u) + kq) * AP + fcol];
+#pragma unroll
+            for (int t = 0; t < kBT; ++t) {
+              const int rt = rt0 + t;
+              if (16 * rt < din) {   // wave-uniform
+                const int ia = 16 * rt + row16;
+                const int iac = ia < din ? ia : din - 1;
+                float av[kBC];
+#pragma unroll
+                for (int u = 0; u < kBC; ++u) {
+                  const int o = 4 * (s0 + u) + kq;
+                  av[u] = Wl[(o < dout ? o : dout - 1) * din + iac];
+                }
+#pragma unroll
+                for (int u = 0; u < kBC; ++u) {
+                  const int o = 4 * (s0 + u) + kq;
+                  acc[t] = mfma4((ia < din && o < dout) ? av[u] : 0.0f, bv[u], acc[t]);
+                }
+              }
+            }
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * rt + 4 * kq + r;
-            if (i < din) {
-              float v = acc[r];
-              if (act) {
-                const float a = al[i * AP + fcol];
-                v *= 1.0f - a * a;
+          for (int t = 0; t < kBT; ++t) {
+            const int rt = rt0 + t;
+            if (16 * rt < din) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = 16 * rt + 4 * kq + r;
+                if (i < din) {
+                  float v = acc[t][r];
+                  if (act) {
+                    const float a = al[i * AP + fcol];
+                    v *= 1.0f - a * a;
+                  }
+                  Zn[i * AP + fcol] = v;
+                }
               }
-              Zn[i * AP + fcol] = v;
             }
           }
         }
@@ -409,6 +505,7 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
         Zn = t;
       }
     }
+    CVF_STAMP(40);
     __syncthreads();   // the next tile's forward overwrites the images / ZB
   }
   // ---- per-block loss partials: fixed-order reduction over the block's four waves
@@ -426,13 +523,19 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
   }
 }
 
-// out2 = fixed-order sums of the per-block {sum w*err, sum w}
-__global__ void ae_loss_sum_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out2) {
-  const int p = threadIdx.x;
-  if (p < 2) {
-    double acc = 0.0;
-    for (int g = 0; g < nblocks; ++g) acc += partial[2 * g + p];
-    out2[p] = acc;
+// out2 = fixed-order sums of the per-block {sum w*err, sum w}: lane l adds rows l, l+64, ..., then the DPP reduction
+__global__ __launch_bounds__(64) void ae_loss_sum_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out2) {
+  const int lane = threadIdx.x;
+  double a0 = 0.0, a1 = 0.0;
+  for (int g = lane; g < nblocks; g += 64) {
+    a0 += partial[2 * g];
+    a1 += partial[2 * g + 1];
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if (lane == 0) {
+    out2[0] = a0;
+    out2[1] = a1;
   }
 }
 
