@@ -17,7 +17,7 @@ AUX_ROWS = 18
 
 FEAT_ANGLE, FEAT_BOND, FEAT_DIHEDRAL, FEAT_POSITION = 0, 1, 2, 3
 PP_IDENTITY, PP_ALIGN = 0, 1
-PP_ALIGN_CONTIG, PP_PURE_POSITION = 1, 2
+PP_ALIGN_CONTIG, PP_PURE_POSITION, PP_SLOT_BATCHED = 1, 2, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcvf_hip.so")
@@ -28,7 +28,7 @@ class PPDesc(C.Structure):
                 ("d_r", C.c_int32), ("use_angle_value", C.c_int32), ("has_position", C.c_int32), ("flags", C.c_int32),
                 ("align_idx", C.c_void_p), ("ref_c", C.c_void_p), ("rec", C.c_void_p),
                 ("atom_align", C.c_void_p), ("atom_slot", C.c_void_p), ("rec_slot", C.c_void_p), ("slot_atom", C.c_void_p), ("n_slot", C.c_int32),
-                ("pad2_", C.c_int32)]
+                ("n_rec_slot", C.c_int32)]
 
 
 class MLPDesc(C.Structure):

@@ -28,6 +28,26 @@ def _ix(atom_group):
     return np.asarray(atom_group.ix if hasattr(atom_group, "ix") else atom_group, dtype=np.int64)
 
 
+def _batch_records(recs, width=64):
+    """Greedy packing of slot records ``[type, s0, s1, s2, s3, out]`` into batches of ``width`` such that, inside a
+    batch, no (atom position, slot) pair occurs twice; short batches are padded with ``type = -1`` entries."""
+    natoms = {_hip.FEAT_POSITION: 1, _hip.FEAT_BOND: 2, _hip.FEAT_ANGLE: 3, _hip.FEAT_DIHEDRAL: 4}
+    batches = []   # [records, set of (position, slot)]
+    for r in recs:
+        keys = {(j, r[1 + j]) for j in range(natoms[r[0]])}
+        for b in batches:
+            if len(b[0]) < width and b[2] == r[0] and not (keys & b[1]):
+                b[0].append(r)
+                b[1] |= keys
+                break
+        else:
+            batches.append([[r], set(keys), r[0]])
+    out = []
+    for b in batches:
+        out += b[0] + [[-1, 0, 0, 0, 0, 0]] * (width - len(b[0]))
+    return out
+
+
 class Feature:
     """``Feature(name, feature_type, atom_group)`` as in molann (main.ipynb:335)."""
 
@@ -100,9 +120,13 @@ class AlignFeatureLayer(torch.nn.Module):
         for r in rec:
             na = 1 if r[0] == _hip.FEAT_POSITION else _TYPE_NATOMS[{v: k_ for k_, v in _TYPE_ID.items()}[r[0]]]
             rec_slot.append([r[0]] + [int(atom_slot[a]) for a in r[1:1 + na]] + [0] * (4 - na) + [r[5]])
-        # the streaming kernels hand one record to each lane: records of one type side by side keep a wave's lanes on
-        # one code path (the output offset travels with the record, so the order is free)
-        rec_slot.sort(key=lambda r: r[0])
+        # the streaming kernels hand one record to each lane, 64 at a time: records of one type side by side keep a
+        # wave's lanes on one code path, and a batch in which no two records name the same slot in the same atom
+        # position lets the derivative kernel scatter without atomics (CVF_PP_SLOT_BATCHED; the output offset travels
+        # with the record, so the order is free; type -1 entries are padding)
+        rec_slot = _batch_records(sorted(rec_slot, key=lambda r: r[0]))
+        self._n_rec_slot = len(rec_slot)
+        self._flags |= _hip.PP_SLOT_BATCHED
         self._n_slot = len(used)
         self.register_buffer("atom_align", torch.tensor(atom_align))
         self.register_buffer("atom_slot", torch.tensor(atom_slot))
@@ -121,7 +145,7 @@ class AlignFeatureLayer(torch.nn.Module):
         d.flags = self._flags
         d.align_idx, d.ref_c, d.rec = self.align_idx.data_ptr(), self.ref_c.data_ptr(), self.rec.data_ptr()
         d.atom_align, d.atom_slot, d.rec_slot = self.atom_align.data_ptr(), self.atom_slot.data_ptr(), self.rec_slot.data_ptr()
-        d.slot_atom, d.n_slot = self.slot_atom.data_ptr(), self._n_slot
+        d.slot_atom, d.n_slot, d.n_rec_slot = self.slot_atom.data_ptr(), self._n_slot, self._n_rec_slot
         return d
 
     def forward(self, x):

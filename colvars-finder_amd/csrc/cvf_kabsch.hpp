@@ -200,6 +200,7 @@ __device__ __forceinline__ AngleG angle_eval(V3 xa, V3 xb, V3 xc) {
 struct DihedralG {
   float cs, sn;
   V3 g1, g2, g3, g4;  // gradient of phi
+  float p, q;         // g2 = (-1 - p) g1 + q g4,  g3 = p g1 + (-1 - q) g4
 };
 __device__ __forceinline__ DihedralG dihedral_eval(V3 x1, V3 x2, V3 x3, V3 x4) {
   V3 b1 = x2 - x1, b2 = x3 - x2, b3 = x4 - x3;
@@ -215,5 +216,7 @@ __device__ __forceinline__ DihedralG dihedral_eval(V3 x1, V3 x2, V3 x3, V3 x4) {
   float p = dot(b1, b2) / b2sq, q = dot(b3, b2) / b2sq;
   o.g2 = (-1.0f - p) * o.g1 + q * o.g4;
   o.g3 = p * o.g1 + (-1.0f - q) * o.g4;
+  o.p = p;
+  o.q = q;
   return o;
 }

@@ -167,12 +167,13 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
                                                      float* __restrict__ slot_xyz) {
   const int nal = pp.n_align, nslot = pp.n_slot;
   CVF_STAMP(4);
-  constexpr int kRecPre = 4;
+  constexpr int kRecPre = 5;
+  const int nrs = pp.n_rec_slot > 0 ? pp.n_rec_slot : pp.n_rec;   // batched lists carry padding entries (type -1)
   Rec pre[kRecPre];
 #pragma unroll
   for (int it = 0; it < kRecPre; ++it) {
     const int r = lane + 64 * it;
-    const int32_t* p = pp.rec_slot + 6 * (r < pp.n_rec ? r : pp.n_rec - 1);
+    const int32_t* p = pp.rec_slot + 6 * (r < nrs ? r : nrs - 1);
     pre[it] = Rec{p[0], p[1], p[2], p[3], p[4], p[5]};
   }
   if (tid < kGroup) {  // the group's 3x3 problems, one per lane of one wave
@@ -216,6 +217,7 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
   };
   auto satom = [&](int sl) { return V3{capL[3 * sl], capL[3 * sl + 1], capL[3 * sl + 2]}; };
   auto feature = [&](const Rec& rc) {
+    if (rc.type < 0) return;   // padding
     if (rc.type == CVF_FEAT_POSITION) {
       const V3 xa = satom(rc.a0);
       const V3 xc = v3((float)((double)xa.x - cc0), (float)((double)xa.y - cc1), (float)((double)xa.z - cc2));
@@ -241,8 +243,8 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
   // the first kRecPre records of each lane were fetched before the solve (their round trip to L2 is hidden there)
 #pragma unroll
   for (int it = 0; it < kRecPre; ++it)
-    if (lane + 64 * it < pp.n_rec) feature(pre[it]);
-  for (int r = lane + 64 * kRecPre; r < pp.n_rec; r += 64) {
+    if (lane + 64 * it < nrs) feature(pre[it]);
+  for (int r = lane + 64 * kRecPre; r < nrs; r += 64) {
     const int32_t* p = pp.rec_slot + 6 * r;   // like rec, atom fields hold slots
     feature(Rec{p[0], p[1], p[2], p[3], p[4], p[5]});
   }

@@ -39,7 +39,10 @@ enum { CVF_PP_IDENTITY = 0, CVF_PP_ALIGN = 1 };
 /* cvf_pp_desc.flags: structure of the tables, enabling kernels whose LDS addresses are affine in the atom index */
 enum {
   CVF_PP_ALIGN_CONTIG = 1,   /* align_idx[b] == b for all b (the align atoms are the first n_align frame atoms) */
-  CVF_PP_PURE_POSITION = 2   /* record r is {POSITION, atom r, out 3r}: n_rec atoms emit their aligned positions in order */
+  CVF_PP_PURE_POSITION = 2,  /* record r is {POSITION, atom r, out 3r}: n_rec atoms emit their aligned positions in order */
+  CVF_PP_SLOT_BATCHED = 4    /* rec_slot holds n_rec_slot entries in batches of 64 (one per lane of a wave): within a batch no two
+                              * records name the same slot in the same atom position, entries of type -1 are padding.  Lets the
+                              * derivative kernel scatter with plain read-modify-write instead of LDS float atomics. */
 };
 
 /* The preprocessing layer r(x): torch.nn.Identity (examples/2d/2d.ipynb:485) or the
@@ -62,10 +65,10 @@ typedef struct cvf_pp_desc {
    * use ("slots") to LDS while the frame goes by, instead of gathering them from HBM afterwards */
   const int32_t* atom_align; /* [N]: index b of the atom in align_idx / ref_c, or -1 */
   const int32_t* atom_slot;  /* [N] (16-byte aligned): slot of the atom, or -1 when no feature uses it */
-  const int32_t* rec_slot;   /* [n_rec*6]: rec with the atom fields replaced by slots; any order (best grouped by type) */
+  const int32_t* rec_slot;   /* [n_rec_slot*6]: rec with the atom fields replaced by slots; any order (best grouped by type) */
   const int32_t* slot_atom;  /* [n_slot]: atom of each slot */
   int32_t n_slot;
-  int32_t pad2_;
+  int32_t n_rec_slot;        /* entries of rec_slot (0: n_rec, unbatched) */
 } cvf_pp_desc;
 
 /* k identical feed-forward nets (colvarsfinder.nn.EigenFunctions, nn.py:242-293) or one

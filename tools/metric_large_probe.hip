@@ -1,8 +1,11 @@
-// Developer tool: phase timing (s_memtime stamps) and throughput of the large-molecule align+feature kernel at the
+// Developer tool: phase timing (s_memtime stamps) of the large-molecule derivative kernel (metric_large) at the
 // config-5 shape (5000 atoms, 32 positions + 96 dihedrals + 96 distances).  Build on the GPU box:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCVF_STAMPS -Iinclude -Icolvars-finder_amd/csrc -Wno-pass-failed \
-//       tools/k1_large_probe.hip colvars-finder_amd/csrc/stats.hip -o /tmp/k1_large_probe
-#include "../colvars-finder_amd/csrc/k1_large.hip"
+//       tools/metric_large_probe.hip colvars-finder_amd/csrc/stats.hip colvars-finder_amd/csrc/k1_large.hip -o /tmp/metric_large_probe
+#include "../colvars-finder_amd/csrc/metric_large.hip"
+int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
+                        float* aux_tiled, float* slot_xyz, hipStream_t s);
+size_t cvf_k1_large_scratch_bytes(const cvf_pp_desc* pp, int64_t B);
 #include <cstdio>
 #include <random>
 #include <vector>
@@ -67,59 +70,54 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nc; ++i) one[i] = ref[i] + 0.5f * G(rng);
     for (int64_t b = 0; b < B; ++b) (void)hipMemcpy(dx + b * nc, one.data(), nc * 4, hipMemcpyHostToDevice);
   }
-  {
-    const size_t ldsc = ((size_t)kGroup * pp.n_slot * 3 + (size_t)pp.d_r * kGroup) * sizeof(float);
-    int nb = -1;
-    (void)hipFuncSetAttribute((const void*)k1_large_slice_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k1_large_slice_kernel<3>, 64 * kGroup, ldsc);
-    hipFuncAttributes fa;
-    (void)hipFuncGetAttributes(&fa, (const void*)k1_large_slice_kernel<3>);
-    printf("occupancy query: %d blocks/CU (err %d), dynamic LDS %zu B, static %zu B, regs %d\n", nb, (int)e, ldsc, fa.sharedSizeBytes, fa.numRegs);
-  }
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int it = 0; it < 2; ++it) cvf_k1_large_launch(&pp, dx, B, dfeat, nullptr, daux, dslot, nullptr);
-  (void)hipEventRecord(e0, nullptr);
   const int reps = 10;
-  for (int it = 0; it < reps; ++it) {
-    int rc = cvf_k1_large_launch(&pp, dx, B, dfeat, nullptr, daux, dslot, nullptr);
-    if (rc) { printf("failed: %s\n", cvf_last_error()); return 1; }
-  }
-  (void)hipEventRecord(e1, nullptr);
-  (void)hipDeviceSynchronize();
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  const double us = 1e3 * ms / reps, bpf = 12.0 * N + 4 + 4.0 * d_r;
-  printf("B=%lld N=%d n_slot=%d d_r=%d: %.1f us/launch, %.0f GB/s algorithmic (%.0f B/frame)\n", (long long)B, N, pp.n_slot, d_r, us,
-         bpf * B / us * 1e-3, bpf);
   std::vector<unsigned long long> st(64 * 4096);
-  (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
-  const char* nm[9] = {"", "static ref/slot loads", "8-frame stream + reduce", "barrier", "sum over waves", "solve", "aux + slot copy", "features", "flush"};
-  double acc[9] = {0}; int n = 0;
-  for (int b = 0; b < 2000; ++b) {
-    const unsigned long long* s = &st[(b * 2) % 4096 * 64];
-    bool ok = s[0] != 0;
-    for (int i = 1; i < 9; ++i) ok = ok && s[i] >= s[i - 1] && s[i] - s[i - 1] < 10000000ull;
-    if (!ok) continue;
-    for (int i = 1; i < 9; ++i) acc[i] += double(s[i] - s[i - 1]);
-    ++n;
-  }
-  double tot = 0;
-  for (int i = 1; i < 9; ++i) { printf("   %-26s %8.0f cycles\n", nm[i], acc[i] / n); tot += acc[i] / n; }
-  printf("   total %8.0f cycles over %d blocks (wave 0)\n", tot, n);
-  {  // residency: how many blocks started before the first one finished?
-    const int nb = (int)((B + 7) / 8) < 2048 ? (int)((B + 7) / 8) : 2048;
-    std::vector<unsigned long long> starts;
-    unsigned long long first_end = ~0ull;
-    for (int b = 0; b < nb; ++b) {
-      const unsigned long long* q = &st[(b * 2) % 4096 * 64];
-      starts.push_back(q[0]);
-      if (q[8] > q[0] && q[8] < first_end) first_end = q[8];
+  if (cvf_k1_large_launch(&pp, dx, B, dfeat, nullptr, daux, dslot, nullptr)) { printf("K1 failed: %s\n", cvf_last_error()); return 1; }
+  {  // the derivative kernel of large molecules on the same frames, k = 6 nets
+    const int k = 6;
+    std::vector<float> g((size_t)T * k * d_r * 64), av(nc, 1.0f);
+    for (auto& v : g) v = G(rng);
+    float *dg, *dq, *de, *da; double* ddense;
+    (void)hipMalloc(&dg, g.size() * 4); (void)hipMalloc(&dq, g.size() * 4); (void)hipMalloc(&de, T * k * 64 * 4); (void)hipMalloc(&da, nc * 4);
+    (void)hipMalloc(&ddense, 42 * 8);
+    (void)hipMemcpy(dg, g.data(), g.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(da, av.data(), nc * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(metric_dense_kernel, dim3(1), dim3(256), 0, 0, pp, da, ddense);
+    for (int it = 0; it < 2; ++it) cvf_metric_large_launch(&pp, B, daux, da, k, dslot, ddense, dg, dq, de, nullptr);
+    (void)hipEventRecord(e0, nullptr);
+    for (int it = 0; it < reps; ++it) {
+      int rc = cvf_metric_large_launch(&pp, B, daux, da, k, dslot, ddense, dg, dq, de, nullptr);
+      if (rc) { printf("failed: %s\n", cvf_last_error()); return 1; }
     }
-    std::sort(starts.begin(), starts.end());
-    int early = 0;
-    for (auto v : starts) early += v < first_end;
-    printf("   %d of %d blocks started before the first block ended (%.2f per CU)\n", early, nb, early / 256.0);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipDeviceSynchronize();
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("metric_large B=%lld k=%d: %.1f us/launch\n", (long long)B, k, 1e3 * ms / reps);
+    (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+    const char* mn[10] = {"", "prologue (slots, tables, geometry)", "net 0: g staged", "net 0: VJP", "net 0: sums + dense part", "net 0: touched atoms", "net 0: sums + dR", "net 0: JVP", "net 0: flush", "nets 1..5"};
+    double am[10] = {0}; int c2 = 0;
+    for (int b = 0; b < 2000; ++b) {
+      const unsigned long long* q = &st[(b * 2) % 4096 * 64];
+      bool ok = q[20] != 0;
+      for (int i = 21; i <= 29; ++i) ok = ok && q[i] >= q[i - 1] && q[i] - q[i - 1] < 10000000ull;
+      if (!ok) continue;
+      for (int i = 1; i < 10; ++i) am[i] += double(q[20 + i] - q[19 + i]);
+      ++c2;
+    }
+    for (int i = 1; i < 10; ++i) printf("   %-36s %8.0f cycles\n", mn[i], am[i] / c2);
+    {
+      double v[4] = {0}; int c3 = 0;
+      for (int b = 0; b < 2000; ++b) {
+        const unsigned long long* q = &st[(b * 2) % 4096 * 64];
+        if (q[33] == 0 || q[33] < q[22] || q[33] - q[22] > 10000000ull) continue;
+        v[0] += double(q[30] - q[22]); v[1] += double(q[31] - q[30]); v[2] += double(q[32] - q[31]); v[3] += double(q[33] - q[32]);
+        ++c3;
+      }
+      printf("   VJP record batches: %.0f %.0f %.0f %.0f cycles\n", v[0] / c3, v[1] / c3, v[2] / c3, v[3] / c3);
+    }
   }
   return 0;
 }
