@@ -268,6 +268,13 @@ def _large_spec(n_atoms, rs):
         feats.append(("bond", tuple(int(i) for i in rs.choice(n_atoms, 2, replace=False))))
     for _ in range(5):
         feats.append(("angle", tuple(int(i) for i in rs.choice(n_atoms, 3, replace=False))))
+    # a backbone-like stretch: consecutive dihedrals / bonds / angles share atoms, several bonds start at the same atom
+    # (the records then collide on slots: exercises the conflict-free batching of the derivative kernel's scatter)
+    a0 = int(rs.randint(0, n_atoms - 12))
+    for i in range(6):
+        feats.append(("dihedral", (a0 + i, a0 + i + 1, a0 + i + 2, a0 + i + 3)))
+        feats.append(("angle", (a0 + i, a0 + i + 1, a0 + i + 2)))
+        feats.append(("bond", (a0, a0 + i + 1)))
     return feats
 
 

@@ -207,3 +207,27 @@ def test_utils_match_reference_files(tmp_path):
         utils.WeightedTrajectory(traj_filename=os.path.join(tmp, "nope.txt"))
     with pytest.raises(NotImplementedError):
         utils.integrate_md_langevin()
+
+
+def test_slot_record_batches_are_conflict_free():
+    """pp._batch_records: every record appears once, batches are 64 wide and of one type, padding entries have type -1,
+    and inside a batch no (atom position, slot) pair repeats - what CVF_PP_SLOT_BATCHED promises the derivative kernel."""
+    from colvarsfinder import _hip, pp
+    rs = np.random.RandomState(5)
+    natoms = {_hip.FEAT_POSITION: 1, _hip.FEAT_BOND: 2, _hip.FEAT_ANGLE: 3, _hip.FEAT_DIHEDRAL: 4}
+    recs, out = [], 0
+    for t, n in ((_hip.FEAT_POSITION, 40), (_hip.FEAT_BOND, 150), (_hip.FEAT_ANGLE, 70), (_hip.FEAT_DIHEDRAL, 130)):
+        for _ in range(n):
+            atoms = [int(a) for a in rs.choice(30, natoms[t], replace=False)]    # few slots: plenty of collisions
+            recs.append([t] + atoms + [0] * (4 - len(atoms)) + [out])
+            out += 3 if t == _hip.FEAT_POSITION else 1
+    batched = pp._batch_records(sorted(recs, key=lambda r: r[0]))
+    assert len(batched) % 64 == 0
+    real = [r for r in batched if r[0] >= 0]
+    assert sorted(map(tuple, real)) == sorted(map(tuple, recs))
+    for b in range(0, len(batched), 64):
+        batch = [r for r in batched[b:b + 64] if r[0] >= 0]
+        assert len({r[0] for r in batch}) <= 1
+        for j in range(4):
+            slots = [r[1 + j] for r in batch if j < natoms[r[0]]]
+            assert len(slots) == len(set(slots))
