@@ -91,14 +91,15 @@ static __device__ unsigned long long g_stamps[64 * 4096];
 __host__ __device__ __forceinline__ int x_tile_stride(int nc) { return nc | 1; }
 
 // `tid` of `nthreads` (a multiple of 64) threads share the work; callers follow with a barrier.
+// `frames` (a multiple of 4) frames per tile: 64, or 16 for the four-lanes-per-frame kernels.
 __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int64_t B, int nc, int64_t tile, float* lds,
-                                            int tid, int nthreads = CVF_WAVE) {
+                                            int tid, int nthreads = CVF_WAVE, int frames = CVF_TILE) {
   const int stride = x_tile_stride(nc);
-  const int64_t f0 = tile * CVF_TILE;
-  const int total = CVF_TILE * nc;
-  if (f0 + CVF_TILE <= B) {
-    const float4* src = reinterpret_cast<const float4*>(x + f0 * nc);  // 64*nc*4 B tiles are 16-B aligned
-    const int nvec = total >> 2;                                       // total is a multiple of 64
+  const int64_t f0 = tile * frames;
+  const int total = frames * nc;
+  if (f0 + frames <= B) {
+    const float4* src = reinterpret_cast<const float4*>(x + f0 * nc);  // frames*nc*4 B tiles are 16-B aligned
+    const int nvec = total >> 2;                                       // total is a multiple of 4
     // (frame, j) of element 4*v advance incrementally: +4*nthreads elements per iteration
     int e = tid * 4;
     int fr = e / nc;

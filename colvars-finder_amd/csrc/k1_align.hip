@@ -191,6 +191,109 @@ __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const floa
   }
 }
 
+// ------------------------------------------------------------------------------------
+// K1, fast layouts, small launches: FOUR lanes per frame (lane = 4 f + p; a wave covers 16 frames).
+// With one lane per frame a 20 000-frame batch is 313 waves on a chip with 1024 SIMDs and each wave walks all
+// N atoms three times: the kernel's time is one wave's serial latency.  Here lane p takes the atoms a = p (mod 4)
+// in the covariance and feature loops and the four partial sums are combined by two quad-permute DPP steps;
+// the 3x3 solve is done (redundantly) by all four lanes.  Same arithmetic per frame, a quarter of the
+// per-wave chain, four times as many waves.  Chosen by the host for launches of at most kSplitMaxTiles tiles.
+// ------------------------------------------------------------------------------------
+constexpr int kQuadFrames = 16;
+
+__device__ __forceinline__ double quad_sum(double v) {
+  v += dpp_movd<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_movd<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ float quad_sumf(float v) {
+  v += dpp_movf<0xB1, 0xf>(v);
+  v += dpp_movf<0x4E, 0xf>(v);
+  return v;
+}
+
+template <bool TILED, bool ROWS>
+__global__ __launch_bounds__(64) void k1_align_quad_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
+                                                            float* __restrict__ feat_tiled, float* __restrict__ feat_rows,
+                                                            float* __restrict__ aux_tiled) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x, f = lane >> 2, p = lane & 3;
+  const int nc = pp.n_coord, nal = pp.n_align;
+  const int stride = x_tile_stride(nc);
+  const int64_t f0 = (int64_t)blockIdx.x * kQuadFrames;
+  float* refL = lds + kQuadFrames * stride;
+  // ---- stage the 16 frames (one contiguous run of 16 nc floats) and the reference
+  float rv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = lane + 64 * i;
+    rv[i] = pp.ref_c[j < 3 * nal ? j : 3 * nal - 1];
+  }
+  load_x_tile(x, B, nc, blockIdx.x, lds, lane, CVF_WAVE, kQuadFrames);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = lane + 64 * i;
+    if (j < 3 * nal) refL[j] = rv[i];
+  }
+  for (int j = lane + 128; j < 3 * nal; j += 64) refL[j] = pp.ref_c[j];
+  __syncthreads();
+  const float* my = lds + f * stride;
+  // ---- centroid and covariance: this lane's quarter of the align atoms, then the quad sums
+  double acc[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) acc[i] = 0.0;
+#pragma unroll 2
+  for (int b = p; b < nal; b += 4) {
+    const double x0 = (double)my[3 * b], x1 = (double)my[3 * b + 1], x2 = (double)my[3 * b + 2];
+    const double r0 = (double)refL[3 * b], r1 = (double)refL[3 * b + 1], r2 = (double)refL[3 * b + 2];
+    acc[0] += x0; acc[1] += x1; acc[2] += x2;
+    acc[3] = fma(x0, r0, acc[3]); acc[4] = fma(x0, r1, acc[4]); acc[5] = fma(x0, r2, acc[5]);
+    acc[6] = fma(x1, r0, acc[6]); acc[7] = fma(x1, r1, acc[7]); acc[8] = fma(x1, r2, acc[8]);
+    acc[9] = fma(x2, r0, acc[9]); acc[10] = fma(x2, r1, acc[10]); acc[11] = fma(x2, r2, acc[11]);
+    acc[12] += r0; acc[13] += r1; acc[14] += r2;
+  }
+#pragma unroll
+  for (int i = 0; i < 15; ++i) acc[i] = quad_sum(acc[i]);
+  const double inv = fast_rcp((double)nal);
+  double cd[3] = {acc[0] * inv, acc[1] * inv, acc[2] * inv};
+  double H[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) H[i][j] = fma(-cd[i], acc[12 + j], acc[3 + 3 * i + j]);
+  KabschOut ko;
+  kabsch_from_H(H, ko);
+  const Centre c = centre_of(cd);
+  // ---- outputs: the frame's column in its 64-frame tile
+  const int64_t frame = f0 + f;
+  const int64_t tile = f0 / CVF_TILE;
+  const int col = (int)(f0 % CVF_TILE) + f;
+  if (aux_tiled) {
+    float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + col;
+    const float av[CVF_AUX_ROWS] = {ko.R[0], ko.R[1], ko.R[2], ko.R[3], ko.R[4], ko.R[5], ko.R[6], ko.R[7], ko.R[8],
+                                    c.hi[0], c.hi[1], c.hi[2], ko.Kinv[0], ko.Kinv[1], ko.Kinv[2], ko.Kinv[3], ko.Kinv[4], ko.Kinv[5]};
+#pragma unroll
+    for (int i = 0; i < CVF_AUX_ROWS; ++i)
+      if ((i & 3) == p) ax[i * CVF_TILE] = av[i];   // the four lanes of a frame share the 18 rows
+  }
+  float* ft = TILED ? feat_tiled + tile * pp.d_r * CVF_TILE + col : nullptr;
+  float* fr = ROWS ? feat_rows + (frame < B ? frame : B - 1) * pp.d_r : nullptr;
+#pragma unroll 2
+  for (int a = p; a < pp.n_rec; a += 4) {
+    const V3 al = row_times(centred(my, a, c), ko.R);
+    if (TILED) {
+      ft[(3 * a) * CVF_TILE] = al.x;
+      ft[(3 * a + 1) * CVF_TILE] = al.y;
+      ft[(3 * a + 2) * CVF_TILE] = al.z;
+    }
+    if (ROWS) {
+      fr[3 * a] = al.x;
+      fr[3 * a + 1] = al.y;
+      fr[3 * a + 2] = al.z;
+    }
+  }
+}
+
 // identity preprocessing: features = coordinates; only the tiling changes
 __global__ __launch_bounds__(64) void k1_identity_kernel(int d, const float* __restrict__ x, int64_t B,
                                                           float* __restrict__ feat_tiled, float* __restrict__ feat_rows) {
@@ -620,6 +723,8 @@ int cvf_metric_large_launch(const cvf_pp_desc* pp, int64_t B, const float* aux_t
 
 // frames larger than this use the streaming workgroup-per-frame kernel (k1_large.hip)
 static constexpr int kLanePerFrameMaxCoord = 192;
+// launches of at most this many 64-frame tiles use the four-lanes-per-frame kernels (fast layouts)
+static constexpr int kSplitMaxTiles = 1024;
 
 extern "C" int64_t cvf_align_feature_scratch_bytes(const cvf_pp_desc* pp, int64_t B) {
   if (!pp || pp->mode != CVF_PP_ALIGN || pp->n_coord <= kLanePerFrameMaxCoord) return 0;
@@ -649,6 +754,21 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
   if (fast)
     CVF_REQUIRE(pp->d_r == 3 * pp->n_rec && 3 * pp->n_rec <= pp->n_coord && pp->n_align * 3 <= pp->n_coord,
                 "cvf_align_feature_fwd: flags do not match the descriptor");
+  // small launches of the fast layout: four lanes per frame (latency), otherwise one lane per frame (throughput)
+  static const int split_env = [] { const char* e = getenv("CVF_K1_QUAD"); return e ? atoi(e) : -1; }();
+  const bool quad = fast && (split_env >= 0 ? split_env != 0 : T <= kSplitMaxTiles);
+  if (quad) {
+    const size_t ldsq = ((size_t)kQuadFrames * x_tile_stride(pp->n_coord) + 3 * (size_t)pp->n_align) * sizeof(float);
+    const unsigned nb = (unsigned)((T * CVF_TILE) / kQuadFrames);   // whole tiles: padded frames replicate the last one
+    auto launchq = [&](auto kernel) {
+      if (ldsq > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq);
+      hipLaunchKernelGGL(kernel, dim3(nb), dim3(64), ldsq, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled);
+    };
+    if (feat_tiled && feat_rows) launchq(k1_align_quad_kernel<true, true>);
+    else if (feat_tiled) launchq(k1_align_quad_kernel<true, false>);
+    else launchq(k1_align_quad_kernel<false, true>);
+    return cvf_check_launch("k1_align_quad_kernel");
+  }
   auto launch = [&](auto kernel) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, dim3((unsigned)T), dim3(64), lds, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled);
