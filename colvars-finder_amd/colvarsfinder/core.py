@@ -241,13 +241,14 @@ class TrainingTask(ABC):
                 np.savetxt('%s/%d_' % (out_dir, idx) + name.replace('.', '_') + '.txt', param.detach().cpu().numpy())
         if self.verbose:
             print(f'  trained model saved at:\n\t{out_dir}/model.pt')
-        try:
-            cv = self.colvar_model()
-            torch.jit.script(copy.deepcopy(cv).to('cpu')).save(f'{out_dir}/scripted_cv_cpu.pt')
-            torch.jit.script(cv).save(f'{out_dir}/scripted_cv_gpu.pt')
-        except Exception as exc:  # the ctypes-backed alignment layer is not scriptable yet
-            if self.verbose:
-                print(f'  TorchScript export skipped: {type(exc).__name__}')
+        # TorchScript export (core.py:205-226): the kernel-backed alignment layer is replaced by its pure-torch export
+        # twin (export.py), so the saved files are self-contained; the GPU variant is the same module moved to the device
+        from .export import scriptable_cv
+        cv = scriptable_cv(self.colvar_model())
+        torch.jit.script(cv).save(f'{out_dir}/scripted_cv_cpu.pt')
+        torch.jit.script(copy.deepcopy(cv).to(self.device)).save(f'{out_dir}/scripted_cv_gpu.pt')
+        if self.verbose:
+            print(f'  script models for CVs saved at:\n\t{out_dir}/scripted_cv_cpu.pt\n\t{out_dir}/scripted_cv_gpu.pt\n', flush=True)
 
     @abstractmethod
     def train(self):

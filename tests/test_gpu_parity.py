@@ -384,3 +384,30 @@ def test_fused_metric_stats_equals_two_launch_path(dev, n_atoms, n_pos, B, k):
     np.testing.assert_allclose(fused[0].cpu().numpy(), stats2.cpu().numpy(), rtol=1e-13)
     np.testing.assert_allclose(fused[1].cpu().numpy(), lv2.cpu().numpy(), rtol=1e-10)
     np.testing.assert_allclose(fused[2].cpu().numpy(), cf2.cpu().numpy(), rtol=1e-8, atol=1e-10 * float(cf2.abs().max()))
+
+
+def test_save_model_exports_torchscript_cv(dev, tmp_path):
+    """save_model (core.py:168-227): model.pt, per-CV text files and the TorchScript CVs; the scripted CPU file must
+    reproduce what the task's own colvar_model() (alignment kernel + nets on the GPU) gives on the same frames."""
+    from colvarsfinder import core, nn
+    g = goldens.load("kat_gen_mol22_k3", "f32")
+    traj = np.array(g["traj"])
+    spec = goldens.pp_spec(g)
+    layer = make_layer(spec, traj.shape[1], dev)
+    k = int(g["k"])
+    model = nn.EigenFunctions([int(d) for d in g["layer_dims"]], k)
+    model.load_state_dict(goldens.state_dict(g, dtype=torch.float32))
+    a = torch.tensor(np.array(g["diag_coeff"]), dtype=torch.float32)
+    task = core.EigenFunctionTask(Traj(traj, np.array(g["w"]), float(g["dt"])), layer, model, str(tmp_path), float(g["alpha"]),
+                                  [float(x) for x in g["eig_w"]], diag_coeff=a, beta=float(g["beta"]), lag_tau=0, k=k,
+                                  device=dev, verbose=False, save_model_every_step=0)
+    task.save_model(0)
+    out = tmp_path / "latest"
+    for name in ("model.pt", "scripted_cv_cpu.pt", "scripted_cv_gpu.pt", "0_1_weight.txt"):
+        assert (out / name).exists(), name
+    X = torch.tensor(traj, dtype=torch.float32)
+    want = task.colvar_model()(X.to(dev)).detach().cpu().numpy()
+    got_cpu = torch.jit.load(str(out / "scripted_cv_cpu.pt"))(X).detach().numpy()
+    got_gpu = torch.jit.load(str(out / "scripted_cv_gpu.pt"), map_location=dev)(X.to(dev)).detach().cpu().numpy()
+    np.testing.assert_allclose(got_cpu, want, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(got_gpu, want, rtol=1e-4, atol=2e-5)

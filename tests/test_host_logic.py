@@ -231,3 +231,29 @@ def test_slot_record_batches_are_conflict_free():
         for j in range(4):
             slots = [r[1 + j] for r in batch if j < natoms[r[0]]]
             assert len(slots) == len(set(slots))
+
+
+@pytest.mark.parametrize("angle_value", [False, True])
+def test_export_twin_matches_oracle_and_scripts(tmp_path, angle_value):
+    """export.ScriptableAlignFeature (the TorchScript export twin of the kernel-backed layer, reference save_model
+    core.py:205-226): same features as the oracle layer, scriptable, and the saved file reloads and reproduces them."""
+    from colvarsfinder import export, pp
+    from oracle.pp import AlignFeature
+    from tests.synth import make_molecule_traj
+    n_atoms = 14
+    traj, _, ref = make_molecule_traj(n_atoms, 40, seed=77, scale=2.0, sigma=0.3)
+    feats = [("position", (0, 3, 4, 9)), ("bond", (0, 1)), ("dihedral", (1, 2, 3, 4)), ("angle", (5, 6, 7)), ("bond", (8, 13)),
+             ("dihedral", (9, 10, 11, 12))]
+    align = [0, 1, 2, 3, 4, 5, 6, 7, 9, 11]
+    layer = pp.AlignFeatureLayer(n_atoms, align, ref[align], feats, angle_value)
+    twin = export.ScriptableAlignFeature(layer)
+    x = torch.tensor(traj, dtype=torch.float64)
+    want = AlignFeature(align, ref[align], feats, angle_value).double()(x).numpy()
+    got = twin(x).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)   # the layer keeps its reference in fp32
+    cv = export.scriptable_cv(torch.nn.Sequential(layer, torch.nn.Linear(layer.d_r, 2)))
+    path = str(tmp_path / "scripted_cv_cpu.pt")
+    torch.jit.script(cv).save(path)
+    loaded = torch.jit.load(path)
+    x32 = torch.tensor(traj, dtype=torch.float32)
+    np.testing.assert_allclose(loaded(x32).detach().numpy(), cv(x32).detach().numpy(), rtol=1e-6, atol=1e-6)
