@@ -65,7 +65,8 @@ _SIGNATURES = {
     "cvf_ef_pack_floats": (C.c_int64, [C.POINTER(MLPDesc)]),
     "cvf_ef_pack": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_mlp_fwd": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                                 C.c_void_p]),
+                                 C.c_void_p, C.c_void_p]),
+    "cvf_ef_saved_floats": (C.c_int64, [C.POINTER(MLPDesc), C.c_int64]),
     "cvf_ef_stats_scratch_doubles": (C.c_int64, [C.c_int, C.c_int]),
     "cvf_ef_stats": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -73,7 +74,7 @@ _SIGNATURES = {
     "cvf_ef_backward_slab_rows": (C.c_int64, [C.c_int64]),
     "cvf_ef_backward": (C.c_int, [C.POINTER(EFCfg), C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p]),
+                                  C.c_void_p, C.c_void_p]),
     "cvf_slab_reduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p]),
     "cvf_ae_scratch_floats": (C.c_int64, [C.POINTER(MLPDesc), C.c_int64]),
     "cvf_ae_step": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double,

@@ -291,6 +291,9 @@ class _EFWorkspace:
         self.loss_vec = torch.empty(3 + 2 * k, **f64)
         self.coef = torch.empty(4 * k + k * k, **f64)
         self._k1_scratch, self.k1_scratch_checked = [None, None], False   # large-molecule alignment scratch, sized on first use
+        # hidden activations handed from the forward kernel to the backward kernel (0 floats: shape without hand-off)
+        n_saved = lib.cvf_ef_saved_floats(mlp_desc, Tt)
+        self.saved = torch.empty(n_saved, **f32) if n_saved > 0 else None
         self.slab_rows = lib.cvf_ef_backward_slab_rows(Tt)
         self.slab = torch.empty(self.slab_rows * n_params, **f32)
 
@@ -420,7 +423,7 @@ class EigenFunctionTask(TrainingTask):
         if not aligned:
             self._align(ws, slot, X, X_lag)
         self._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(ws.y),
-                   P(ws.g) if lag == 0 else None, s)
+                   P(ws.g) if lag == 0 else None, P(ws.saved), s)
         single = not _dist.collectives()   # no cross-rank reduction: the loss tail runs inside the stats launch
         lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
         if lag == 0:   # q = J A J^T g, E, and the batch sums (K2/K3 + K5) in one launch
@@ -443,7 +446,7 @@ class EigenFunctionTask(TrainingTask):
         lib, fl, P = _hip.lib(), self._flat, _hip.ptr
         self._call("cvf_ef_backward", lib.cvf_ef_backward, self._cfg, fl.desc, P(fl.theta), P(fl.packed), ws.B, P(w), P(w_lag),
                    P(ws.feat), P(ws.y), P(ws.q) if self.lag_idx == 0 else None, P(ws.coef), P(ws.slab),
-                   P(self.optimizer.step_count) if advance else None, _hip.stream())
+                   P(self.optimizer.step_count) if advance else None, P(ws.saved), _hip.stream())
         adam = self.optimizer.fused_args() if fuse_adam else None
         self._call("cvf_slab_reduce", lib.cvf_slab_reduce, P(ws.slab), ws.slab_rows, fl.n, P(fl.grad), adam, _hip.stream())
         if not fuse_adam:

@@ -44,6 +44,34 @@ struct Vec {
   f32x4 v[Hid<H>::RT][FT];
 };
 
+// Activations handed from the forward kernel to the backward kernel (cvf_ef_saved_floats): per (tile, net) the
+// vectors h_1..h_NH and e_1..e_{NH-1} (e_l = W_{l+1}^T d_{l+1}) in the register layout both kernels use - group g
+// (features 4g..4g+3 over q), frame-group pair w (the backward kernel's wave), lane, two frame groups:
+//   [vector][g < NG][w < 2][lane < 64][2]   ->  every (vector, g, w) is one coalesced 512-byte row.
+template <int H>
+__host__ __device__ constexpr int saved_per_vec() { return Hid<H>::NG * 2 * 64 * 2; }
+template <int H>
+__device__ __forceinline__ void save_vec(float* __restrict__ base, const Vec<H, 4>& X, int lane) {
+#pragma unroll
+  for (int g = 0; g < Hid<H>::NG; ++g)
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+      reinterpret_cast<float2*>(base + (g * 2 + w) * 128)[lane] = float2{X.v[g >> 2][2 * w][g & 3], X.v[g >> 2][2 * w + 1][g & 3]};
+}
+template <int H>
+__device__ __forceinline__ void load_vec(const float* __restrict__ base, Vec<H, 2>& X, int w, int lane) {
+#pragma unroll
+  for (int rt = 0; rt < Hid<H>::RT; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) X.v[rt][ft] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int g = 0; g < Hid<H>::NG; ++g) {
+    const float2 t = reinterpret_cast<const float2*>(base + (g * 2 + w) * 128)[lane];
+    X.v[g >> 2][0][g & 3] = t.x;
+    X.v[g >> 2][1][g & 3] = t.y;
+  }
+}
+
 // X <- bias (hidden order)
 template <int H, int FT>
 __device__ __forceinline__ void init_bias(Vec<H, FT>& X, const float* __restrict__ b, int q) {
@@ -535,7 +563,8 @@ template <int H, int NH>
 __global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                          const float* __restrict__ packed,
                                                          const float* __restrict__ feat, int64_t n_tiles,
-                                                         float* __restrict__ y_tiled, float* __restrict__ g_tiled) {
+                                                         float* __restrict__ y_tiled, float* __restrict__ g_tiled,
+                                                         float* __restrict__ saved) {
   constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG, FT = 4, CH = 6;
   extern __shared__ float wL[];   // this net's packed fragments
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q = lane >> 4;
@@ -615,6 +644,11 @@ __global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const 
     }
     if (q == 0 && live) store_frames<FT>(y_tiled + (tile * k + net) * CVF_TILE + fo, yv);
   }
+  float* sv = saved != nullptr && live ? saved + (tile * k + net) * (int64_t)((2 * NH - 1) * saved_per_vec<H>()) : nullptr;
+  if (sv != nullptr) {
+#pragma unroll
+    for (int l = 0; l < NH; ++l) save_vec<H>(sv + l * saved_per_vec<H>(), h[l], lane);
+  }
   if (!want_g) return;
   Vec<H, FT> d;
 #pragma unroll
@@ -631,6 +665,7 @@ __global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const 
     Vec<H, FT> e;
     init_bias<H, FT>(e, nullptr, q);
     hidden_apply<H, FT>(e, wL + L.th(l), d, lane);
+    if (sv != nullptr) save_vec<H>(sv + (NH + l - 1) * saved_per_vec<H>(), e, lane);
     tangent_of<H, FT>(d, h[l - 1], e);
   }
   const float* pT0 = wL + L.t0();
@@ -749,7 +784,7 @@ __device__ __forceinline__ void tangent_of(Vec<H, FT>& td, const Vec<H, FT>& h, 
 // 4*col + w*FT .. + FT-1 (FT = 4/WPB) for the register-resident chains, and every WPB-th 16x16 tile of
 // each weight-gradient product.  Splitting the tile over waves shortens each wave's dependent chain and
 // puts two waves on every SIMD, which is what hides the LDS / L2 latencies at small batch sizes.
-template <int H, int NH, int WPB>
+template <int H, int NH, int WPB, bool SAVED>
 __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp_desc mlp,
                                                                const float* __restrict__ theta,
                                                                const float* __restrict__ packed,
@@ -758,7 +793,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
                                                                const float* __restrict__ y_tiled,
                                                                const float* __restrict__ q_tiled,
                                                                const double* __restrict__ coef, float* __restrict__ slab,
-                                                               int32_t* __restrict__ step) {
+                                                               int32_t* __restrict__ step, const float* __restrict__ saved) {
   constexpr int FT = 4 / WPB;
   constexpr int RT = Hid<H>::RT;
   constexpr int RTO = (H + 15) / 16;      // row tiles of an H-row image (natural order)
@@ -866,12 +901,25 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
     CVF_STAMP(9);
     // ---- chains (registers, MFMA) for this wave's frames
     Vec<H, FT> h[NH];
-    chain_forward<H, NH, FT, true>(mlp, theta, pk, L, net, f_tile + fo, lane, h);
-    CVF_STAMP(10);
     Vec<H, FT> e[NH > 1 ? NH - 1 : 1];  // e[l] = W_{l+1}^T d_{l+1}, l = 0..NH-2  (e_{NH-1} = W_L is the constant wl)
     Vec<H, FT> t[NH];                   // t[l] = W_l tdot_{l-1}
+    if (SAVED) {
+      // the forward kernel left h and e for this (tile, net): 25 coalesced 8-byte loads instead of recomputing the
+      // forward chain (68 + 40 matrix instructions behind just-in-time weight loads) and the d chain
+      static_assert(!SAVED || FT == 2, "the saved layout pairs the frame groups of a two-wave block");
+      const float* sv = saved + (tile * k + net) * (int64_t)((2 * NH - 1) * saved_per_vec<H>());
+#pragma unroll
+      for (int l = 0; l < NH; ++l) load_vec<H>(sv + l * saved_per_vec<H>(), h[l], wave, lane);
+      if (tangent) {
+#pragma unroll
+        for (int l = 0; l + 1 < NH; ++l) load_vec<H>(sv + (NH + l) * saved_per_vec<H>(), e[l], wave, lane);
+      }
+    } else {
+      chain_forward<H, NH, FT, true>(mlp, theta, pk, L, net, f_tile + fo, lane, h);
+    }
+    CVF_STAMP(10);
     if (tangent) {
-      {
+      if (!SAVED) {
         Vec<H, FT> d;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -1152,8 +1200,23 @@ extern "C" int cvf_ef_pack(const cvf_mlp_desc* mlp, const float* theta, float* p
   return cvf_check_launch("ef_pack_kernel");
 }
 
+// The forward kernel that shares one weight fetch among four tiles can also hand its activations to the backward kernel.
+static bool fwd_wg_ok(const cvf_mlp_desc* mlp, int H, int NH) {
+  bool wg = (size_t)pack_layout(H, NH, mlp->dims[0]).per_net * sizeof(float) <= 64 * 1024;
+  if (getenv("CVF_FWD_WG")) wg = wg && atoi(getenv("CVF_FWD_WG")) != 0;   // developer override
+  return wg;
+}
+
+extern "C" int64_t cvf_ef_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles) {
+  int H, NH;
+  if (!mlp || !ef_shape(mlp, &H, &NH) || !fwd_wg_ok(mlp, H, NH) || getenv("CVF_NO_SAVED")) return 0;
+  int64_t per_vec = 0;
+  const bool ok = ef_dispatch(H, NH, [&](auto h_, auto) { per_vec = saved_per_vec<decltype(h_)::value>(); });
+  return ok ? n_tiles * mlp->n_nets * (2 * NH - 1) * per_vec : 0;
+}
+
 extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* packed, const float* feat_tiled,
-                              int64_t n_tiles, float* y_tiled, float* g_tiled, void* stream) {
+                              int64_t n_tiles, float* y_tiled, float* g_tiled, float* saved, void* stream) {
   CVF_REQUIRE(mlp && theta && packed && feat_tiled && y_tiled && n_tiles > 0, "cvf_ef_mlp_fwd: bad argument");
   int H, NH;
   CVF_REQUIRE(ef_shape(mlp, &H, &NH),
@@ -1164,15 +1227,15 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
   if (getenv("CVF_FWD_SPLIT")) split = atoi(getenv("CVF_FWD_SPLIT")) != 0;   // developer override
   const bool pre = mlp->dims[0] <= 72;   // every load up front (see ef_fwd_pre_kernel)
   const size_t wlds = (size_t)pack_layout(H, NH, mlp->dims[0]).per_net * sizeof(float);
-  bool wg = wlds <= 64 * 1024;            // one fetch of the weights per four tiles (see ef_fwd_wg_kernel)
-  if (getenv("CVF_FWD_WG")) wg = wg && atoi(getenv("CVF_FWD_WG")) != 0;   // developer override
+  const bool wg = fwd_wg_ok(mlp, H, NH);  // one fetch of the weights per four tiles (see ef_fwd_wg_kernel)
+  CVF_REQUIRE(saved == nullptr || wg, "cvf_ef_mlp_fwd: this shape has no activation hand-off (cvf_ef_saved_floats() == 0)");
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
     if (wg) {
       if (wlds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)ef_fwd_wg_kernel<kH, kNH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
       hipLaunchKernelGGL((ef_fwd_wg_kernel<kH, kNH>), dim3((unsigned)((n_tiles + 3) / 4), mlp->n_nets), dim3(256), wlds,
-                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, n_tiles, y_tiled, g_tiled);
+                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, n_tiles, y_tiled, g_tiled, saved);
     } else if (pre && split)
       hipLaunchKernelGGL((ef_fwd_pre_kernel<kH, kNH, 2>), dim3((unsigned)(2 * n_tiles), mlp->n_nets), dim3(64), 0,
                          (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
@@ -1195,7 +1258,7 @@ extern "C" int64_t cvf_ef_backward_slab_rows(int64_t n_tiles) { return bwd_grid(
 extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
                                int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
                                const float* y_tiled, const float* q_tiled, const double* coef, float* slab,
-                               int32_t* step_count, void* stream) {
+                               int32_t* step_count, const float* saved, void* stream) {
   CVF_REQUIRE(cfg && mlp && theta && packed && w && feat_tiled && y_tiled && coef && slab && B > 0,
               "cvf_ef_backward: bad argument");
   CVF_REQUIRE(cfg->lag_idx > 0 || q_tiled, "cvf_ef_backward: generator mode needs q");
@@ -1224,8 +1287,12 @@ extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, c
   const size_t lds_dyn = (size_t)span * sizeof(float);
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta, packed,
-                       w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count);
+    if (saved != nullptr)
+      hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2, true>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta,
+                         packed, w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved);
+    else
+      hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2, false>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta,
+                         packed, w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved);
   });
   CVF_REQUIRE(launched, "cvf_ef_backward: no kernel instance for hidden width %d x %d layers", H, NH);
   return cvf_check_launch("ef_bwd_mfma_kernel");

@@ -162,7 +162,11 @@ int cvf_ef_pack(const cvf_mlp_desc* mlp, const float* theta, float* packed, void
  * Replaces self.model(...) at core.py:403,414 (nn.py:293).
  * y_tiled [T][k][64]; g_tiled [T][k][d0][64] or NULL. */
 int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* packed, const float* feat_tiled,
-                   int64_t n_tiles, float* y_tiled, float* g_tiled, void* stream);
+                   int64_t n_tiles, float* y_tiled, float* g_tiled, float* saved, void* stream);
+/* `saved` (may be NULL): cvf_ef_saved_floats() floats in which the forward kernel leaves the hidden activations (and
+ * the back-propagated output sensitivities) of every (tile, net) for cvf_ef_backward, which then skips recomputing
+ * them.  Opaque layout; 0 floats = this shape has no hand-off, pass NULL to both calls. */
+int64_t cvf_ef_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles);
 
 /* --- K5: batch statistics (core.py:406-416,426,428,446-452), fp64, fixed-order two
  * stage reduction.  w [B]; y_tiled [T][k][64]; generator: e_tiled [T][k][64];
@@ -186,7 +190,8 @@ int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* loss_vec, do
 int64_t cvf_ef_backward_slab_rows(int64_t n_tiles);
 int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed, int64_t B,
                     const float* w, const float* w_lag, const float* feat_tiled, const float* y_tiled,
-                    const float* q_tiled, const double* coef, float* slab, int32_t* step_count, void* stream);
+                    const float* q_tiled, const double* coef, float* slab, int32_t* step_count, const float* saved,
+                    void* stream);
                     /* step_count (may be NULL): the optimiser's device step counter, advanced by one */
 int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,
                     void* stream); /* adam (may be NULL): apply the update in the same launch */

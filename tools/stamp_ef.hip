@@ -31,8 +31,10 @@ int main() {
   hipMalloc(&dy, T * k * 64 * 4); hipMalloc(&dg, T * k * D * 64 * 4);
   hipMemcpy(dth, theta.data(), pos * 4, hipMemcpyHostToDevice);
   hipMemcpy(dfeat, feat.data(), feat.size() * 4, hipMemcpyHostToDevice);
+  float* dsaved = nullptr;
+  if (cvf_ef_saved_floats(&m, T) > 0) hipMalloc(&dsaved, cvf_ef_saved_floats(&m, T) * 4);
   cvf_ef_pack(&m, dth, dpk, nullptr);
-  for (int it = 0; it < 5; ++it) cvf_ef_mlp_fwd(&m, dth, dpk, dfeat, T, dy, dg, nullptr);
+  for (int it = 0; it < 5; ++it) cvf_ef_mlp_fwd(&m, dth, dpk, dfeat, T, dy, dg, dsaved, nullptr);
   hipDeviceSynchronize();
   std::vector<unsigned long long> st(64 * 4096);
   hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
@@ -68,7 +70,7 @@ int main() {
     cfg.k = k; cfg.lag_idx = 0;
     (void)0;
     for (int it = 0; it < 5; ++it) {
-      int rc = cvf_ef_backward(&cfg, &m, dth, dpk, B, dw, nullptr, dfeat, dy, dq, dcoef, dslab, nullptr, nullptr);
+      int rc = cvf_ef_backward(&cfg, &m, dth, dpk, B, dw, nullptr, dfeat, dy, dq, dcoef, dslab, nullptr, dsaved, nullptr);
       if (rc) { printf("bwd failed: %s\n", cvf_last_error()); return 1; }
     }
     hipDeviceSynchronize();
