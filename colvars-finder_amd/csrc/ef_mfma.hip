@@ -938,7 +938,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
         }
       }
       init_bias<H, FT>(t[0], nullptr, q);
-      layer0_apply<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane);
+      layer0_apply<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane);   // (deeper chunks: more spills, no gain)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
