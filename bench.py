@@ -40,7 +40,7 @@ FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector == fp32-input MF
 P_W = 66 * 20 + 20 * 20 + 20 * 20 + 20            # multiply-adds of one net's forward
 K1_BYTES = 12 * N_ATOMS + 4 + 4 * 66              # 532 B/frame
 FLOP_FWD = 2 * K_NETS * (P_W + (P_W - 66 * 20) + 66 * 20)            # forward + d-chain + g = W1^T d
-FLOP_BWD = 2 * K_NETS * (P_W + (P_W - 66 * 20) + P_W + 800 + 2 * P_W)  # fwd, d-chain, tangent, zbar-chain, outer products
+FLOP_BWD = 2 * K_NETS * (P_W + 800 + 2 * P_W)  # tangent chain, zbar chain, outer products (h and the d chain come from the forward kernel)
 
 
 def make_shard(n_frames, rank, n_atoms=N_ATOMS, scale=2.0, sigma=0.3):
@@ -197,7 +197,7 @@ def main():
     def pmc_traffic(call):
         """HBM bytes per launch of the kernel behind a C-ABI call, from the committed rocprofv3 PMC passes."""
         kernel = {"cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
-                  "cvf_align_feature_fwd": "k1_align_kernel"}.get(call)
+                  "cvf_align_feature_fwd": "k1_align_quad_kernel"}.get(call)
         path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
         if kernel is None or not os.path.exists(path) or B != 20000 or args.workload != "c3":
             return None
