@@ -45,7 +45,7 @@ struct Vec {
 };
 
 // Activations handed from the forward kernel to the backward kernel (cvf_ef_saved_floats): per (tile, net) the
-// vectors h_1..h_NH and e_1..e_{NH-1} (e_l = W_{l+1}^T d_{l+1}) in the register layout both kernels use - group g
+// vectors h_1..h_NH in the register layout both kernels use - group g
 // (features 4g..4g+3 over q), frame-group pair w (the backward kernel's wave), lane, two frame groups:
 //   [vector][g < NG][w < 2][lane < 64][2]   ->  every (vector, g, w) is one coalesced 512-byte row.
 template <int H>
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const 
     }
     if (q == 0 && live) store_frames<FT>(y_tiled + (tile * k + net) * CVF_TILE + fo, yv);
   }
-  float* sv = saved != nullptr && live ? saved + (tile * k + net) * (int64_t)((2 * NH - 1) * saved_per_vec<H>()) : nullptr;
+  float* sv = saved != nullptr && live ? saved + (tile * k + net) * (int64_t)(NH * saved_per_vec<H>()) : nullptr;
   if (sv != nullptr) {
 #pragma unroll
     for (int l = 0; l < NH; ++l) save_vec<H>(sv + l * saved_per_vec<H>(), h[l], lane);
@@ -665,7 +665,6 @@ __global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const 
     Vec<H, FT> e;
     init_bias<H, FT>(e, nullptr, q);
     hidden_apply<H, FT>(e, wL + L.th(l), d, lane);
-    if (sv != nullptr) save_vec<H>(sv + (NH + l - 1) * saved_per_vec<H>(), e, lane);
     tangent_of<H, FT>(d, h[l - 1], e);
   }
   const float* pT0 = wL + L.t0();
@@ -904,22 +903,19 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
     Vec<H, FT> e[NH > 1 ? NH - 1 : 1];  // e[l] = W_{l+1}^T d_{l+1}, l = 0..NH-2  (e_{NH-1} = W_L is the constant wl)
     Vec<H, FT> t[NH];                   // t[l] = W_l tdot_{l-1}
     if (SAVED) {
-      // the forward kernel left h and e for this (tile, net): 25 coalesced 8-byte loads instead of recomputing the
-      // forward chain (68 + 40 matrix instructions behind just-in-time weight loads) and the d chain
+      // the forward kernel left h_1..h_NH for this (tile, net): 15 coalesced 8-byte loads instead of recomputing the
+      // forward chain (68 + 40 matrix instructions behind just-in-time weight loads).  (Handing over the d chain too
+      // was measured: 10 MB more traffic each way and no change in this kernel's time.)
       static_assert(!SAVED || FT == 2, "the saved layout pairs the frame groups of a two-wave block");
-      const float* sv = saved + (tile * k + net) * (int64_t)((2 * NH - 1) * saved_per_vec<H>());
+      const float* sv = saved + (tile * k + net) * (int64_t)(NH * saved_per_vec<H>());
 #pragma unroll
       for (int l = 0; l < NH; ++l) load_vec<H>(sv + l * saved_per_vec<H>(), h[l], wave, lane);
-      if (tangent) {
-#pragma unroll
-        for (int l = 0; l + 1 < NH; ++l) load_vec<H>(sv + (NH + l) * saved_per_vec<H>(), e[l], wave, lane);
-      }
     } else {
       chain_forward<H, NH, FT, true>(mlp, theta, pk, L, net, f_tile + fo, lane, h);
     }
     CVF_STAMP(10);
     if (tangent) {
-      if (!SAVED) {
+      {
         Vec<H, FT> d;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -1212,7 +1208,7 @@ extern "C" int64_t cvf_ef_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles)
   if (!mlp || !ef_shape(mlp, &H, &NH) || !fwd_wg_ok(mlp, H, NH) || getenv("CVF_NO_SAVED")) return 0;
   int64_t per_vec = 0;
   const bool ok = ef_dispatch(H, NH, [&](auto h_, auto) { per_vec = saved_per_vec<decltype(h_)::value>(); });
-  return ok ? n_tiles * mlp->n_nets * (2 * NH - 1) * per_vec : 0;
+  return ok ? n_tiles * mlp->n_nets * NH * per_vec : 0;
 }
 
 extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* packed, const float* feat_tiled,
