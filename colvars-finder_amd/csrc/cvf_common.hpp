@@ -92,6 +92,7 @@ __host__ __device__ __forceinline__ int x_tile_stride(int nc) { return nc | 1; }
 
 // `tid` of `nthreads` (a multiple of 64) threads share the work; callers follow with a barrier.
 // `frames` (a multiple of 4) frames per tile: 64, or 16 for the four-lanes-per-frame kernels.
+template <int kBatch = 18>
 __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int64_t B, int nc, int64_t tile, float* lds,
                                             int tid, int nthreads = CVF_WAVE, int frames = CVF_TILE) {
   const int stride = x_tile_stride(nc);
@@ -110,7 +111,6 @@ __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int64_t
     // alone on its SIMD, and a load -> wait -> write loop paid one full memory round trip per 1 KiB of the tile
     // (17 of them for 22 atoms).  Indices are clamped instead of
     // predicated so the loads stay unconditional (counted waits).
-    constexpr int kBatch = 18;
     for (int v0 = tid; v0 < nvec; v0 += nthreads * kBatch) {
       float4 val[kBatch];
 #pragma unroll

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void k1_align_quad_kernel(cvf_pp_desc pp, const
     const int j = lane + 64 * i;
     rv[i] = pp.ref_c[j < 3 * nal ? j : 3 * nal - 1];
   }
-  load_x_tile(x, B, nc, blockIdx.x, lds, lane, CVF_WAVE, kQuadFrames);
+  load_x_tile<6>(x, B, nc, blockIdx.x, lds, lane, CVF_WAVE, kQuadFrames);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int j = lane + 64 * i;
@@ -475,6 +475,9 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
 }
 
 // ------------------------------------------------------------------------------------
+// (A four-lanes-per-frame variant of this kernel, as for K1, was built and measured: same 20 us.  At this batch the
+// kernel is bound by the g read / q write phases of 16 MB each, which all waves enter together, not by the
+// per-wave chain.)
 // metric, fast path (CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION): feature 3a..3a+2 = aligned position of atom a,
 // align atom b = atom b.  Block = one 64-frame tile x `wpb` nets (one wave per net): the waves stage the
 // coordinate tile together, once, and each keeps its own [3N][64] image U in LDS that first holds g, then
