@@ -371,6 +371,7 @@ class EigenFunctionTask(TrainingTask):
         # CVF_PIPELINE=1: the next batch's alignment (independent of the parameters) runs on this stream beside the
         # current step's backward kernel.  Off by default: at 20 000 frames per step it measured 133 us/step against
         # 126 serial - the two-branch graph costs more at the fork/join than the 14 us kernel it hides.
+        self._fused_fm = None   # decided on first use: cvf_ef_fwd_metric_supported(nets, layer)
         self._side = torch.cuda.Stream(device=self.device)
         self._pipeline = os.environ.get("CVF_PIPELINE", "0") == "1"
 
@@ -422,10 +423,20 @@ class EigenFunctionTask(TrainingTask):
             ws.k1_scratch_checked = True
         if not aligned:
             self._align(ws, slot, X, X_lag)
-        self._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(ws.y),
-                   P(ws.g) if lag == 0 else None, P(ws.saved), s)
         single = not _dist.collectives()   # no cross-rank reduction: the loss tail runs inside the stats launch
         lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
+        if self._fused_fm is None:
+            self._fused_fm = lag == 0 and bool(lib.cvf_ef_fwd_metric_supported(fl.desc, self._pp))
+        if self._fused_fm:   # nets forward, q = J A J^T g, E and the batch sums in one launch: g never leaves the chip
+            self._call("cvf_ef_fwd_metric_stats", lib.cvf_ef_fwd_metric_stats, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat),
+                       self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), P(ws.y), P(ws.saved), P(ws.q), P(ws.e), self._cfg,
+                       P(w), P(ws.scratch), P(ws.stats), lv, cf, s)
+            if not single:
+                _dist.allreduce_sum_(ws.stats)                                           # collective #1
+                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_vec), P(ws.coef), s)
+            return ws
+        self._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(ws.y),
+                   P(ws.g) if lag == 0 else None, P(ws.saved), s)
         if lag == 0:   # q = J A J^T g, E, and the batch sums (K2/K3 + K5) in one launch
             self._call("cvf_metric_apply", lib.cvf_metric_apply_stats, self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), k,
                        P(ws.g), P(ws.q), P(ws.e), P(ws.k1_scratch), P(self._dense), self._cfg, P(w), P(ws.y),

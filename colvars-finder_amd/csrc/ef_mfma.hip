@@ -20,6 +20,7 @@
 // net's parameters; each block writes one slab row, rows are summed in fixed order by cvf_slab_reduce.
 #include "cvf_common.hpp"
 #include "cvf_adam.hpp"
+#include "cvf_metric.hpp"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -553,6 +554,172 @@ __global__ __launch_bounds__(64) void ef_fwd_pre_kernel(cvf_mlp_desc mlp, const 
   }
   CVF_STAMP(6);
   CVF_STAMP(7);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K4a + K2/K3 (+K5a) in one launch, fast layout (pure positions, contiguous align set, D <= 72): block = one 64-frame
+// tile, one wave per net.  Each wave runs the forward chain of its net on the matrix cores (as ef_fwd_pre_kernel:
+// every operand load up front), keeps g = dy/dfeat in ITS LDS image instead of writing it to HBM, and goes straight
+// on, lane = frame, with the three passes of q = J A J^T g (cvf_metric.hpp), which read that image in place.
+// Against the two separate launches this removes the 16 MB g store, the 16 MB g load (at 20 000 frames both kernels
+// spend about half their time in those phases, which all waves enter together) and one launch boundary.
+// ------------------------------------------------------------------------------------------------------------------
+template <int H, int NH>
+__global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
+                                                             const float* __restrict__ packed,
+                                                             const float* __restrict__ feat, cvf_pp_desc pp,
+                                                             const float* __restrict__ x, int64_t B,
+                                                             const float* __restrict__ aux_tiled,
+                                                             const float* __restrict__ a, float* __restrict__ y_tiled,
+                                                             float* __restrict__ saved, float* __restrict__ q_tiled,
+                                                             float* __restrict__ e_tiled, MetricFuse fuse) {
+  constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG, FT = 4, CH = 6, CTMAX = 5;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int col = lane & 15, q = lane >> 4;
+  const int64_t tile = blockIdx.x;
+  const int net = wave;                         // the host launches one wave per net
+  const int k = mlp.n_nets, D = mlp.dims[0];
+  const int S = (D + 3) >> 2, CT = (D + 15) >> 4;
+  const int nc = pp.n_coord, nal = pp.n_align;
+  const int stride = x_tile_stride(nc);
+  float* refL = lds + CVF_TILE * stride;                              // [3*nal]
+  float* aL = refL + 3 * nal;                                         // [nc]
+  float* Ub = lds + ((CVF_TILE * stride + 3 * nal + nc + 3) & ~3);   // images start 16-byte aligned
+  float* Uw = Ub + (size_t)wave * nc * CVF_TILE;                      // this wave's image [nc][64]
+  float* yL = Ub + (size_t)k * nc * CVF_TILE;                         // [k][64]
+  const PackLayout L = pack_layout(H, NH, D);
+  const float* pk = packed + (int64_t)net * L.per_net;
+  const int fo = 4 * col;
+  const float* in_lane = feat + tile * (int64_t)D * CVF_TILE + fo;
+  // ---- requests: derivative part (lane = frame) ...
+  const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
+  float auxv[CVF_AUX_ROWS];
+#pragma unroll
+  for (int i = 0; i < CVF_AUX_ROWS; ++i) auxv[i] = ax[i * CVF_TILE];
+  float wv = 0.0f;
+  if (fuse.on) {
+    const int64_t frame = tile * CVF_TILE + lane;
+    wv = fuse.w[frame < B ? frame : B - 1];
+    if (frame >= B) wv = 0.0f;
+  }
+  const int ntab = 3 * nal + nc;
+  float tabv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = tid + nthreads * i;
+    const int jc = j < ntab ? j : ntab - 1;
+    tabv[i] = jc < 3 * nal ? pp.ref_c[jc] : a[jc - 3 * nal];
+  }
+  // ---- ... and forward part (matrix-core layout): every operand of the chain
+  L0Chunk<H, FT, CH> c0, c1, c2;
+  load_l0chunk<H, FT, CH>(c0, pk + L.f0(), D, S, in_lane, 0, lane);
+  load_l0chunk<H, FT, CH>(c1, pk + L.f0(), D, S, in_lane, CH, lane);
+  load_l0chunk<H, FT, CH>(c2, pk + L.f0(), D, S, in_lane, 2 * CH, lane);
+  HConst<H> bias[NH];
+#pragma unroll
+  for (int l = 0; l < NH; ++l) load_hconst<H>(bias[l], theta + mlp.b_off[net][l], q);
+  HFrag<H> hf[NH > 1 ? NH - 1 : 1];
+#pragma unroll
+  for (int l = 1; l < NH; ++l) load_hfrag<H>(hf[l - 1], pk + L.fh(l), lane);
+  float wl[RT][4];
+  load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
+  const float bL = theta[mlp.b_off[net][NH]];
+  load_x_tile(x, B, nc, tile, lds, tid, nthreads);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = tid + nthreads * i;
+    if (j < ntab) refL[j] = tabv[i];
+  }
+  for (int j = tid + 2 * nthreads; j < ntab; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : a[j - 3 * nal];
+  // ---- forward chain
+  Vec<H, FT> h[NH];
+  set_const<H, FT>(h[0], bias[0]);
+  mul_l0chunk<H, FT, CH>(h[0], c0);
+  mul_l0chunk<H, FT, CH>(h[0], c1);
+  mul_l0chunk<H, FT, CH>(h[0], c2);
+  tanh_inplace<H, FT>(h[0]);
+#pragma unroll
+  for (int l = 1; l < NH; ++l) {
+    set_const<H, FT>(h[l], bias[l]);
+    hidden_mul<H, FT>(h[l], hf[l - 1], h[l - 1]);
+    tanh_inplace<H, FT>(h[l]);
+  }
+  {
+    float yv4[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      float part = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(wl[rt][r], h[NH - 1].v[rt][ft][r], part);
+      yv4[ft] = sum_over_q(part) + bL;
+    }
+    if (q == 0) {
+      store_frames<FT>(y_tiled + (tile * k + net) * CVF_TILE + fo, yv4);
+      *reinterpret_cast<float4*>(yL + net * CVF_TILE + fo) = float4{yv4[0], yv4[1], yv4[2], yv4[3]};
+    }
+  }
+  if (saved != nullptr) {
+    float* sv = saved + (tile * k + net) * (int64_t)(NH * saved_per_vec<H>());
+#pragma unroll
+    for (int l = 0; l < NH; ++l) save_vec<H>(sv + l * saved_per_vec<H>(), h[l], lane);
+  }
+  // ---- d chain and g = W_1^T d_1 -> this wave's LDS image [feature][frame]
+  {
+    HFrag<H> tf[NH > 1 ? NH - 1 : 1];
+#pragma unroll
+    for (int l = 1; l < NH; ++l) load_hfrag<H>(tf[l - 1], pk + L.th(l), lane);
+    Vec<H, FT> d;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float hv = h[NH - 1].v[rt][ft][r];
+          d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
+        }
+#pragma unroll
+    for (int l = NH - 1; l >= 1; --l) {
+      Vec<H, FT> e;
+      init_bias<H, FT>(e, nullptr, q);
+      hidden_mul<H, FT>(e, tf[l - 1], d);
+      tangent_of<H, FT>(d, h[l - 1], e);
+    }
+    const float* pT0 = pk + L.t0();
+#pragma unroll
+    for (int rt = 0; rt < CTMAX; ++rt) {
+      if (rt < CT) {  // wave-uniform
+        float t0[NG];
+#pragma unroll
+        for (int s = 0; s < NG; ++s) t0[s] = pT0[(rt * NG + s) * 64 + lane];
+        f32x4 acc[FT];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) acc[ft] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < NG; ++s)
+#pragma unroll
+          for (int ft = 0; ft < FT; ++ft) acc[ft] = mfma4(t0[s], d.v[s >> 2][ft][s & 3], acc[ft]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * rt + 4 * q + r;
+          if (i < D) *reinterpret_cast<float4*>(Uw + i * CVF_TILE + fo) = float4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        }
+      }
+    }
+  }
+  __syncthreads();   // coordinate tile, tables and every net's y are in LDS; the g images are wave-private
+  float yv[CVF_MAX_NETS];
+#pragma unroll
+  for (int j = 0; j < CVF_MAX_NETS; ++j) yv[j] = yL[(j < k ? j : k - 1) * CVF_TILE + lane];
+  float cur[3 * kGChunk];
+#pragma unroll
+  for (int i = 0; i < 3 * kGChunk; ++i) cur[i] = 0.0f;
+  float* qt = q_tiled + (tile * k + net) * (int64_t)pp.d_r * CVF_TILE + lane;
+  metric_pure_passes<true>(pp, lane, net, k, tile, B, lds + lane * stride, refL, aL, Uw + lane, auxv, nullptr, qt, e_tiled, fuse, wv,
+                           yv, cur);
 }
 
 // K4a, workgroup form: four waves = four consecutive 64-frame tiles of ONE net.  The net's weight fragments
@@ -1247,6 +1414,59 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
   });
   CVF_REQUIRE(launched, "cvf_ef_mlp_fwd: no kernel instance for hidden width %d x %d layers", H, NH);
   return cvf_check_launch("ef_fwd_mfma_kernel");
+}
+
+int cvf_ef_stats_finish(const cvf_ef_cfg* cfg, int n_rows, const double* partial, double* stats, double* loss_vec, double* coef,
+                        hipStream_t s);
+
+static size_t fwd_metric_lds(const cvf_pp_desc* pp, int k) {
+  const size_t head = ((size_t)CVF_TILE * x_tile_stride(pp->n_coord) + 3 * (size_t)pp->n_align + pp->n_coord + 3) & ~(size_t)3;
+  return (head + (size_t)k * pp->n_coord * CVF_TILE + (size_t)k * CVF_TILE) * sizeof(float);
+}
+
+extern "C" int cvf_ef_fwd_metric_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp) {
+  int H, NH;
+  if (!mlp || !pp || !ef_shape(mlp, &H, &NH) || getenv("CVF_NO_FWD_METRIC")) return 0;
+  if (!ef_dispatch(H, NH, [](auto, auto) {})) return 0;
+  const int fast = CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION;
+  if (pp->mode != CVF_PP_ALIGN || (pp->flags & fast) != fast || pp->n_align > pp->n_rec) return 0;
+  if (pp->d_r != 3 * pp->n_rec || pp->d_r != mlp->dims[0] || pp->d_r > 72 || pp->n_coord > 192) return 0;
+  return fwd_metric_lds(pp, mlp->n_nets) <= 80 * 1024 && cvf_ef_saved_floats(mlp, 1) > 0;
+}
+
+extern "C" int cvf_ef_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, const float* packed, const float* feat_tiled,
+                                       const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled,
+                                       const float* a, float* y_tiled, float* saved, float* q_tiled, float* e_tiled,
+                                       const cvf_ef_cfg* cfg, const float* w, double* scratch, double* stats,
+                                       double* loss_vec, double* coef, void* stream) {
+  CVF_REQUIRE(cvf_ef_fwd_metric_supported(mlp, pp), "cvf_ef_fwd_metric_stats: shape not covered (cvf_ef_fwd_metric_supported() == 0)");
+  CVF_REQUIRE(theta && packed && feat_tiled && x && aux_tiled && a && y_tiled && q_tiled && e_tiled && cfg && w && scratch && stats &&
+                  B > 0, "cvf_ef_fwd_metric_stats: bad argument");
+  CVF_REQUIRE(cfg->k == mlp->n_nets && cfg->lag_idx == 0, "cvf_ef_fwd_metric_stats: generator mode only, cfg.k must equal the number of nets");
+  CVF_REQUIRE(loss_vec == nullptr || coef != nullptr, "cvf_ef_fwd_metric_stats: loss_vec without coef");
+  int H, NH;
+  ef_shape(mlp, &H, &NH);
+  const int k = mlp->n_nets;
+  const int64_t T = cvf_ntiles(B);
+  const int ns = cvf_ef_nstats(k, 0);
+  MetricFuse f = {};
+  f.on = T <= kFuseMaxTiles ? 1 : 0;
+  f.ns = ns;
+  f.w = w;
+  f.y_tiled = y_tiled;
+  f.partial = scratch;
+  const size_t lds = fwd_metric_lds(pp, k);
+  ef_dispatch(H, NH, [&](auto h_, auto nh_) {
+    constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)ef_fwd_metric_kernel<kH, kNH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ef_fwd_metric_kernel<kH, kNH>), dim3((unsigned)T), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed,
+                       feat_tiled, *pp, x, B, aux_tiled, a, y_tiled, saved, q_tiled, e_tiled, f);
+  });
+  int rc = cvf_check_launch("ef_fwd_metric_kernel");
+  if (rc) return rc;
+  if (f.on) return cvf_ef_stats_finish(cfg, (int)T, scratch, stats, loss_vec, coef, (hipStream_t)stream);
+  return cvf_ef_stats(cfg, B, w, y_tiled, e_tiled, nullptr, nullptr, scratch + T * ns, stats, loss_vec, coef, stream);
 }
 
 extern "C" int64_t cvf_ef_backward_slab_rows(int64_t n_tiles) { return bwd_grid(n_tiles); }

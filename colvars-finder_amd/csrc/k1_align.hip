@@ -4,6 +4,7 @@
 // 4 B/feature/frame out); the 3x3 covariance, its eigen-decomposition and the small
 // solves run per lane in fp64, so all 64 lanes stay busy for small molecules.
 #include "cvf_kabsch.hpp"
+#include "cvf_metric.hpp"
 
 namespace {
 
@@ -94,25 +95,6 @@ __device__ __forceinline__ void align_lane(const cvf_pp_desc& pp, const Tables& 
   CVF_STAMP(3);
   kabsch_from_H(H, ko);
   CVF_STAMP(4);
-}
-
-// x - c in fp32 with the centroid as a (hi, lo) pair of floats: two roundings of the result's own ulp, no
-// fp64 conversions in the per-atom loops (v_cvt_f64_f32 / v_cvt_f32_f64 are quarter-rate).
-struct Centre {
-  float hi[3], lo[3];
-};
-__device__ __forceinline__ Centre centre_of(const double (&c)[3]) {
-  Centre ce;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    ce.hi[i] = (float)c[i];
-    ce.lo[i] = (float)(c[i] - (double)ce.hi[i]);
-  }
-  return ce;
-}
-__device__ __forceinline__ Centre centre_of(float c0, float c1, float c2) { return Centre{{c0, c1, c2}, {0.0f, 0.0f, 0.0f}}; }
-__device__ __forceinline__ V3 centred(const float* my, int a, const Centre& c) {
-  return V3{(my[3 * a] - c.hi[0]) - c.lo[0], (my[3 * a + 1] - c.hi[1]) - c.lo[1], (my[3 * a + 2] - c.hi[2]) - c.lo[2]};
 }
 
 // TILED / ROWS: which of the two output layouts is written - compile-time, because a run-time `if (ft)` around
@@ -486,22 +468,6 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
 //   2  G_a = R g_a [+ Z ref_a - shift], E, u_a -> U, sums for the rotation's tangent   (LDS only)
 //   3  q_a = (u_a - ubar) R + xc_a dR                          (LDS -> global)
 // ------------------------------------------------------------------------------------
-constexpr int kGChunk = 8;   // atoms per prefetch chunk of pass 1
-
-// Fused first stage of K5: every block also reduces its tile's contribution to the batch sums of
-// EigenFunctionTask.loss_func into one row of `partial` (fp64, fixed DPP order); cvf_ef_stats_finish (stats.hip)
-// adds the rows in a fixed order - the separate pass over w, y and E and its launch are gone.
-// (A last-block-done epilogue that also finished the sum and the loss tail in this launch was measured and dropped:
-// 313 returning atomics on one counter serialise to ~7 us, more than the launch boundary it saves.)
-struct MetricFuse {
-  int on;
-  int ns;
-  const float* w;
-  const float* y_tiled;
-  double* partial;       // [T][ns]
-};
-constexpr int kFuseMaxTiles = 1024;   // above this the row sum of the finishing kernel would be too serial
-
 __global__ __launch_bounds__(512) void metric_pure_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
                                                            const float* __restrict__ aux_tiled,
                                                            const float* __restrict__ a, int k,
@@ -562,137 +528,7 @@ __global__ __launch_bounds__(512) void metric_pure_kernel(cvf_pp_desc pp, const 
   }
   for (int j = tid + 2 * nthreads; j < ntab; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : a[j - 3 * nal];
   __syncthreads();
-  const float* my = lds + lane * stride;
-  float R[9], Kinv[6];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = auxv[i];
-  const Centre c = centre_of(auxv[9], auxv[10], auxv[11]);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) Kinv[i] = auxv[12 + i];
-  CVF_STAMP(10);
-  // pass 1
-  V3 sump = v3(0, 0, 0);
-  float M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const int nchunk = (N + kGChunk - 1) / kGChunk;
-  for (int ch = 0; ch < nchunk; ++ch) {
-#pragma unroll
-    for (int i = 0; i < kGChunk; ++i) {   // next chunk: clamped, unconditional
-      const int an = kGChunk * (ch + 1) + i;
-      const int at = an < N ? an : N - 1;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) nxt[3 * i + d] = gt[(3 * at + d) * CVF_TILE];
-    }
-#pragma unroll
-    for (int i = 0; i < kGChunk; ++i) {
-      const int an = kGChunk * ch + i;
-      const int at = an < N ? an : N - 1;
-      const float m = an < N ? 1.0f : 0.0f;
-      const V3 g = v3(cur[3 * i], cur[3 * i + 1], cur[3 * i + 2]);
-      Ul[(3 * at) * CVF_TILE] = g.x;   // (a clamped atom rewrites atom N-1's own g)
-      Ul[(3 * at + 1) * CVF_TILE] = g.y;
-      Ul[(3 * at + 2) * CVF_TILE] = g.z;
-      const V3 gm = m * g;
-      sump = sump + mat_times(R, gm);
-      const V3 xc = centred(my, at, c);
-      M[0] += xc.x * gm.x; M[1] += xc.x * gm.y; M[2] += xc.x * gm.z;
-      M[3] += xc.y * gm.x; M[4] += xc.y * gm.y; M[5] += xc.y * gm.z;
-      M[6] += xc.z * gm.x; M[7] += xc.z * gm.y; M[8] += xc.z * gm.z;
-    }
-#pragma unroll
-    for (int i = 0; i < 3 * kGChunk; ++i) cur[i] = nxt[i];
-  }
-  CVF_STAMP(11);
-  float T[9], Z[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * M[j] + R[3 + i] * M[3 + j] + R[6 + i] * M[6 + j];
-  const V3 s = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    Z[3 * i + 0] = R[3 * i + 1] * s.z - R[3 * i + 2] * s.y;
-    Z[3 * i + 1] = -R[3 * i + 0] * s.z + R[3 * i + 2] * s.x;
-    Z[3 * i + 2] = R[3 * i + 0] * s.y - R[3 * i + 1] * s.x;
-  }
-  const float inv_nal = 1.0f / (float)nal;
-  const V3 shift = inv_nal * sump;
-  CVF_STAMP(12);
-  // pass 2: align atoms first (they carry the rotation's and the centroid's derivative), then the rest
-  float E = 0.0f;
-  V3 usum = v3(0, 0, 0), rsum = v3(0, 0, 0);
-  float dH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-  for (int at = 0; at < nal; ++at) {
-    const V3 g = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
-    const V3 rf = v3(refL[3 * at], refL[3 * at + 1], refL[3 * at + 2]);
-    const V3 G = mat_times(R, g) + (mat_times(Z, rf) - shift);
-    const V3 u = v3(aL[3 * at] * G.x, aL[3 * at + 1] * G.y, aL[3 * at + 2] * G.z);
-    E += u.x * G.x + u.y * G.y + u.z * G.z;
-    Ul[(3 * at) * CVF_TILE] = u.x;
-    Ul[(3 * at + 1) * CVF_TILE] = u.y;
-    Ul[(3 * at + 2) * CVF_TILE] = u.z;
-    usum = usum + u;
-    rsum = rsum + rf;
-    dH[0] += u.x * rf.x; dH[1] += u.x * rf.y; dH[2] += u.x * rf.z;
-    dH[3] += u.y * rf.x; dH[4] += u.y * rf.y; dH[5] += u.y * rf.z;
-    dH[6] += u.z * rf.x; dH[7] += u.z * rf.y; dH[8] += u.z * rf.z;
-  }
-#pragma unroll 4
-  for (int at = nal; at < N; ++at) {
-    const V3 g = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
-    const V3 G = mat_times(R, g);
-    const V3 u = v3(aL[3 * at] * G.x, aL[3 * at + 1] * G.y, aL[3 * at + 2] * G.z);
-    E += u.x * G.x + u.y * G.y + u.z * G.z;
-    Ul[(3 * at) * CVF_TILE] = u.x;
-    Ul[(3 * at + 1) * CVF_TILE] = u.y;
-    Ul[(3 * at + 2) * CVF_TILE] = u.z;
-  }
-  CVF_STAMP(13);
-  e_tiled[(tile * k + net) * CVF_TILE + lane] = E;
-  if (fuse.on) {
-    // this wave's slots of the tile's row: [W | S1(k) | S2(i<=j) | E(k)]  (include/cvf.h)
-    double* row = fuse.partial + tile * (int64_t)fuse.ns;
-    const double wb = (double)wv, yn = (double)yv[net];
-    auto put = [&](int slot, double v) {
-      const double sum = wave_sum(v);
-      if (lane == 0) row[slot] = sum;
-    };
-    if (net == 0) put(0, wb);
-    put(1 + net, wb * yn);
-    const int s2o = 1 + k + net * k - (net * (net - 1)) / 2 - net;   // + j : slot of S2[net][j], j >= net
-#pragma unroll
-    for (int j = 0; j < CVF_MAX_NETS; ++j)
-      if (j >= net && j < k) put(s2o + j, wb * yn * (double)yv[j]);
-    put(1 + k + CVF_NPAIR(k) + net, wb * (double)E);
-  }
-  const V3 ubar = inv_nal * usum;
-  // dH = sum_b (u_b - ubar) (x) ref_b = dH' - ubar (x) sum_b ref_b
-  dH[0] -= ubar.x * rsum.x; dH[1] -= ubar.x * rsum.y; dH[2] -= ubar.x * rsum.z;
-  dH[3] -= ubar.y * rsum.x; dH[4] -= ubar.y * rsum.y; dH[5] -= ubar.y * rsum.z;
-  dH[6] -= ubar.z * rsum.x; dH[7] -= ubar.z * rsum.y; dH[8] -= ubar.z * rsum.z;
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * dH[j] + R[3 + i] * dH[3 + j] + R[6 + i] * dH[6 + j];
-  const V3 w = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
-  float dR[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    dR[3 * i + 0] = R[3 * i + 1] * w.z - R[3 * i + 2] * w.y;
-    dR[3 * i + 1] = -R[3 * i + 0] * w.z + R[3 * i + 2] * w.x;
-    dR[3 * i + 2] = R[3 * i + 0] * w.y - R[3 * i + 1] * w.x;
-  }
-  CVF_STAMP(14);
-  // pass 3
-#pragma unroll 4
-  for (int at = 0; at < N; ++at) {
-    const V3 u = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
-    const V3 qa = row_times(u - ubar, R) + row_times(centred(my, at, c), dR);
-    qt[(3 * at) * CVF_TILE] = qa.x;
-    qt[(3 * at + 1) * CVF_TILE] = qa.y;
-    qt[(3 * at + 2) * CVF_TILE] = qa.z;
-  }
-  CVF_STAMP(15);
+  metric_pure_passes<false>(pp, lane, net, k, tile, B, lds + lane * stride, refL, aL, Ul, auxv, gt, qt, e_tiled, fuse, wv, yv, cur);
 }
 
 __global__ __launch_bounds__(64) void metric_identity_kernel(int d, const float* __restrict__ a, int k,

@@ -168,6 +168,16 @@ int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* pac
  * them.  Opaque layout; 0 floats = this shape has no hand-off, pass NULL to both calls. */
 int64_t cvf_ef_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles);
 
+/* --- K4a + K2/K3 + K5 in one go for the fast layout (pure position features on a contiguous align set, d_r <= 72):
+ * cvf_ef_mlp_fwd, cvf_metric_apply_stats fused per tile - g = dy/dfeat never leaves the chip.  Same outputs (y, saved,
+ * q, e, stats[, loss_vec, coef]) up to summation order; g_tiled is not produced.  Check cvf_ef_fwd_metric_supported()
+ * first; otherwise make the two calls.  scratch as for cvf_metric_apply_stats. */
+int cvf_ef_fwd_metric_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp);
+int cvf_ef_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, const float* packed, const float* feat_tiled,
+                            const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled, const float* a,
+                            float* y_tiled, float* saved, float* q_tiled, float* e_tiled, const cvf_ef_cfg* cfg,
+                            const float* w, double* scratch, double* stats, double* loss_vec, double* coef, void* stream);
+
 /* --- K5: batch statistics (core.py:406-416,426,428,446-452), fp64, fixed-order two
  * stage reduction.  w [B]; y_tiled [T][k][64]; generator: e_tiled [T][k][64];
  * transfer: y_lag_tiled, w_lag.  scratch: cvf_ef_stats_scratch_doubles() doubles. */

@@ -369,21 +369,29 @@ def test_fused_metric_stats_equals_two_launch_path(dev, n_atoms, n_pos, B, k):
     for _ in range(3):
         task.loss_func(X, wt, None, None)
         assert torch.equal(ws.stats, fused[0]) and torch.equal(ws.loss_vec, fused[1])
-    # the two-launch path on the same y / g
+    # the separate launches (nets forward, derivative kernel, two-stage sums) on the same features
     lib, P = _hip.lib(), _hip.ptr
     Xd, wd = X.to(dev).float().contiguous(), wt.to(dev).float().contiguous()
+    fl = task._flat
+    y2 = torch.empty_like(ws.y)
+    _hip.check(lib.cvf_ef_mlp_fwd(fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(y2), P(ws.g), None, _hip.stream()),
+               "cvf_ef_mlp_fwd")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y2.cpu().numpy(), ws.y.cpu().numpy(), rtol=1e-6, atol=1e-7)
     q2, e2 = torch.empty_like(ws.q), torch.empty_like(ws.e)
     stats2, lv2, cf2 = torch.empty_like(ws.stats), torch.empty_like(ws.loss_vec), torch.empty_like(ws.coef)
     scratch2 = torch.zeros(lib.cvf_ef_stats_scratch_doubles(k, 0), device=dev, dtype=torch.float64)
     _hip.check(lib.cvf_metric_apply(task._pp, P(Xd), B, P(ws.aux), P(task._diag_coeff), k, P(ws.g), P(q2), P(e2), None, None,
                                     _hip.stream()), "cvf_metric_apply")
-    _hip.check(lib.cvf_ef_stats(task._cfg, B, P(wd), P(ws.y), P(e2), None, None, P(scratch2), P(stats2), P(lv2), P(cf2),
+    _hip.check(lib.cvf_ef_stats(task._cfg, B, P(wd), P(y2), P(e2), None, None, P(scratch2), P(stats2), P(lv2), P(cf2),
                                 _hip.stream()), "cvf_ef_stats")
     torch.cuda.synchronize()
-    assert torch.equal(e2, fused[3]) and torch.equal(q2, fused[4])
-    np.testing.assert_allclose(fused[0].cpu().numpy(), stats2.cpu().numpy(), rtol=1e-13)
-    np.testing.assert_allclose(fused[1].cpu().numpy(), lv2.cpu().numpy(), rtol=1e-10)
-    np.testing.assert_allclose(fused[2].cpu().numpy(), cf2.cpu().numpy(), rtol=1e-8, atol=1e-10 * float(cf2.abs().max()))
+    qmax = float(q2.abs().max())
+    np.testing.assert_allclose(fused[3].cpu().numpy(), e2.cpu().numpy(), rtol=2e-5, atol=1e-6 * float(e2.abs().max()))
+    np.testing.assert_allclose(fused[4].cpu().numpy(), q2.cpu().numpy(), rtol=2e-5, atol=2e-6 * qmax)
+    np.testing.assert_allclose(fused[0].cpu().numpy(), stats2.cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(fused[1].cpu().numpy(), lv2.cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(fused[2].cpu().numpy(), cf2.cpu().numpy(), rtol=1e-3, atol=1e-4 * float(cf2.abs().max()))
 
 
 def test_save_model_exports_torchscript_cv(dev, tmp_path):
