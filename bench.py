@@ -40,6 +40,7 @@ FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector == fp32-input MF
 P_W = 66 * 20 + 20 * 20 + 20 * 20 + 20            # multiply-adds of one net's forward
 K1_BYTES = 12 * N_ATOMS + 4 + 4 * 66              # 532 B/frame
 FLOP_FWD = 2 * K_NETS * (P_W + (P_W - 66 * 20) + 66 * 20)            # forward + d-chain + g = W1^T d
+FLOP_METRIC = 2 * K_NETS * 33 * N_ATOMS          # three passes of q = J A J^T g: ~33 fused multiply-adds per atom and net
 FLOP_BWD = 2 * K_NETS * (P_W + 800 + 2 * P_W)  # tangent chain, zbar chain, outer products (h and the d chain come from the forward kernel)
 
 
@@ -197,6 +198,7 @@ def main():
     def pmc_traffic(call):
         """HBM bytes per launch of the kernel behind a C-ABI call, from the committed rocprofv3 PMC passes."""
         kernel = {"cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
+                  "cvf_ef_fwd_metric_stats": "ef_fwd_metric_kernel",
                   "cvf_align_feature_fwd": "k1_align_quad_kernel"}.get(call)
         path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
         if kernel is None or not os.path.exists(path) or B != 20000 or args.workload != "c3":
@@ -205,8 +207,8 @@ def main():
             c = json.load(fh)["kernels"].get(kernel)
         return None if c is None else (2.0 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024.0
 
-    if dom in ("cvf_ef_backward", "cvf_ef_mlp_fwd"):
-        flop = (FLOP_BWD if dom == "cvf_ef_backward" else FLOP_FWD) * B
+    if dom in ("cvf_ef_backward", "cvf_ef_mlp_fwd", "cvf_ef_fwd_metric_stats"):
+        flop = {"cvf_ef_backward": FLOP_BWD, "cvf_ef_mlp_fwd": FLOP_FWD, "cvf_ef_fwd_metric_stats": FLOP_FWD + FLOP_METRIC}[dom] * B
         ach = flop / (kern_ms[dom] * 1e-3) / 1e12
         roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS,
                     traffic=pmc_traffic(dom), avg_launch_us=kern_ms[dom] * 1e3,
