@@ -419,3 +419,39 @@ def test_save_model_exports_torchscript_cv(dev, tmp_path):
     got_gpu = torch.jit.load(str(out / "scripted_cv_gpu.pt"), map_location=dev)(X.to(dev)).detach().cpu().numpy()
     np.testing.assert_allclose(got_cpu, want, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(got_gpu, want, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,k", [(5, 1), (63, 2), (65, 4), (130, 3), (257, 8)])
+def test_generator_step_ragged_batches_vs_oracle(dev, B, k):
+    """Fast layout (pure positions, the fused forward + derivative launch, hand-off to the backward kernel) on batches
+    that do not fill their last 64-frame tile, and on 1..8 nets: loss, eigenvalues, ordering and parameter gradient
+    against the fp64 oracle (autograd through linalg.svd)."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    n_atoms = 9
+    traj, w, ref = make_molecule_traj(n_atoms, B, seed=1300 + B, scale=2.0, sigma=0.3)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_atoms)))], use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    dims = [layer.d_r, 12, 12, 1]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(3))
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    a = torch.tensor(diag_coeff_for(n_atoms, 3), dtype=torch.float32)
+    eig_w = [1.0 - 0.1 * i for i in range(k)]
+    task = core.EigenFunctionTask(Traj(traj, w, 1.0), layer, model, "/tmp/cvf_test", 12.0, eig_w, diag_coeff=a, beta=1.2, lag_tau=0,
+                                  k=k, device=dev, verbose=False, save_model_every_step=0)
+    loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+    X = torch.tensor(traj, dtype=torch.float64, requires_grad=True)
+    lo, eo, no, po, co = losses.ef_loss(sd, k, oracle_layer(spec), X, torch.tensor(w), alpha=12.0, eig_w=eig_w,
+                                        diag_coeff=a.double(), beta=1.2)
+    lo.backward()
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(float(npl), float(no.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=RTOL64)
+    assert list(cvec) == list(co)
+    want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
