@@ -195,10 +195,11 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
   } else if (slot_xyz != nullptr && tid >= 64) {
     // meanwhile the other waves write the compact copy of the feature atoms for the derivative kernels: the
     // workgroup's kGroup frames are one contiguous run of both the LDS image and slot_xyz (padded frame index)
-    const float4* src = reinterpret_cast<const float4*>(capL - (size_t)fi * nslot * 3);
-    float4* dst = reinterpret_cast<float4*>(slot_xyz + f0 * (int64_t)nslot * 3);
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    const nt4* src = reinterpret_cast<const nt4*>(capL - (size_t)fi * nslot * 3);
+    nt4* dst = reinterpret_cast<nt4*>(slot_xyz + f0 * (int64_t)nslot * 3);
     const int n4 = kGroup * nslot * 3 / 4;
-    for (int i = tid - 64; i < n4; i += 64 * (kGroup - 1)) dst[i] = src[i];
+    for (int i = tid - 64; i < n4; i += 64 * (kGroup - 1)) __builtin_nontemporal_store(src[i], dst + i);   // written once, read by a later kernel
   }
   __syncthreads();
   CVF_STAMP(5);

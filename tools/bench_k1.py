@@ -26,7 +26,7 @@ def big_features(n_atoms, rs):
     return feats
 
 
-def run(name, n_atoms, n_frames, feats, reps=20):
+def run(name, n_atoms, n_frames, feats, reps=20, slot_copy=True, with_aux=True):
     dev = torch.device("cuda")
     rs = np.random.RandomState(7)
     ref = rs.normal(scale=20.0 if n_atoms > 100 else 2.0, size=(n_atoms, 3))
@@ -38,10 +38,10 @@ def run(name, n_atoms, n_frames, feats, reps=20):
     feat = torch.empty(T * layer.d_r * 64, device=dev)
     aux = torch.empty(T * 18 * 64, device=dev)
     desc, lib = layer.pp_desc(), _hip.lib()
-    scratch = _hip.align_scratch(desc, n_frames, dev)
+    scratch = _hip.align_scratch(desc, n_frames, dev) if slot_copy else None
 
     def launch():
-        _hip.check(lib.cvf_align_feature_fwd(desc, _hip.ptr(x), n_frames, _hip.ptr(feat), None, _hip.ptr(aux), _hip.ptr(scratch),
+        _hip.check(lib.cvf_align_feature_fwd(desc, _hip.ptr(x), n_frames, _hip.ptr(feat), None, _hip.ptr(aux) if with_aux else None, _hip.ptr(scratch),
                                              _hip.stream()), "k1")
 
     for _ in range(3):
@@ -65,5 +65,11 @@ if __name__ == "__main__":
     if "--c5" not in sys.argv:
       run("config3-shape 100k frames", 22, 100_000, [("position", tuple(range(22)))])
       run("config3-shape 1M frames", 22, 1_000_000, [("position", tuple(range(22)))])
+      run("config3-shape 1M frames, features only (no rotation/centroid output)", 22, 1_000_000, [("position", tuple(range(22)))],
+          with_aux=False)
     run("config5-shape 20k frames", 5000, 20_000, big_features(5000, rs))
     run("config5-shape 100k frames", 5000, 100_000, big_features(5000, rs), reps=5)
+    # the same without the compact copy of the feature atoms (an extra OUTPUT of 12 n_slot B/frame that only the
+    # generator-mode derivative kernel consumes; AutoEncoderTask / transfer mode do not ask for it)
+    run("config5-shape 100k frames, features only (no slot copy)", 5000, 100_000, big_features(5000, rs), reps=5, slot_copy=False,
+        with_aux=False)
