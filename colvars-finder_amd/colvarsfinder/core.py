@@ -371,7 +371,7 @@ class EigenFunctionTask(TrainingTask):
         # CVF_PIPELINE=1: the next batch's alignment (independent of the parameters) runs on this stream beside the
         # current step's backward kernel.  Off by default: at 20 000 frames per step it measured 133 us/step against
         # 126 serial - the two-branch graph costs more at the fork/join than the 14 us kernel it hides.
-        self._fused_fm = None   # decided on first use: cvf_ef_fwd_metric_supported(nets, layer)
+        self._fused_fm = self._fused_k1 = None   # decided on first use: cvf_ef_[align_]fwd_metric_supported(nets, layer)
         self._side = torch.cuda.Stream(device=self.device)
         self._pipeline = os.environ.get("CVF_PIPELINE", "0") == "1"
 
@@ -421,14 +421,18 @@ class EigenFunctionTask(TrainingTask):
         if not ws.k1_scratch_checked:
             ws._k1_scratch = [_hip.align_scratch(self._pp, B, self.device) for _ in range(2)]
             ws.k1_scratch_checked = True
-        if not aligned:
+        if self._fused_fm is None:
+            self._fused_fm = lag == 0 and bool(lib.cvf_ef_fwd_metric_supported(fl.desc, self._pp))
+            self._fused_k1 = self._fused_fm and bool(lib.cvf_ef_align_fwd_metric_supported(fl.desc, self._pp))
+        with_k1 = self._fused_k1 and not aligned   # the alignment runs inside the fused launch
+        if not aligned and not with_k1:
             self._align(ws, slot, X, X_lag)
         single = not _dist.collectives()   # no cross-rank reduction: the loss tail runs inside the stats launch
         lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
-        if self._fused_fm is None:
-            self._fused_fm = lag == 0 and bool(lib.cvf_ef_fwd_metric_supported(fl.desc, self._pp))
-        if self._fused_fm:   # nets forward, q = J A J^T g, E and the batch sums in one launch: g never leaves the chip
-            self._call("cvf_ef_fwd_metric_stats", lib.cvf_ef_fwd_metric_stats, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat),
+        if self._fused_fm:   # [alignment,] nets forward, q = J A J^T g, E and the batch sums in one launch: g never leaves the chip
+            name, fn = (("cvf_ef_align_fwd_metric_stats", lib.cvf_ef_align_fwd_metric_stats) if with_k1 else
+                        ("cvf_ef_fwd_metric_stats", lib.cvf_ef_fwd_metric_stats))
+            self._call(name, fn, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat),
                        self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), P(ws.y), P(ws.saved), P(ws.q), P(ws.e), self._cfg,
                        P(w), P(ws.scratch), P(ws.stats), lv, cf, s)
             if not single:

@@ -564,12 +564,12 @@ __global__ __launch_bounds__(64) void ef_fwd_pre_kernel(cvf_mlp_desc mlp, const 
 // Against the two separate launches this removes the 16 MB g store, the 16 MB g load (at 20 000 frames both kernels
 // spend about half their time in those phases, which all waves enter together) and one launch boundary.
 // ------------------------------------------------------------------------------------------------------------------
-template <int H, int NH>
+template <int H, int NH, bool K1>
 __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                              const float* __restrict__ packed,
-                                                             const float* __restrict__ feat, cvf_pp_desc pp,
+                                                             float* __restrict__ feat, cvf_pp_desc pp,
                                                              const float* __restrict__ x, int64_t B,
-                                                             const float* __restrict__ aux_tiled,
+                                                             float* __restrict__ aux_tiled,
                                                              const float* __restrict__ a, float* __restrict__ y_tiled,
                                                              float* __restrict__ saved, float* __restrict__ q_tiled,
                                                              float* __restrict__ e_tiled, MetricFuse fuse) {
@@ -592,11 +592,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
   const float* pk = packed + (int64_t)net * L.per_net;
   const int fo = 4 * col;
   const float* in_lane = feat + tile * (int64_t)D * CVF_TILE + fo;
-  // ---- requests: derivative part (lane = frame) ...
-  const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
   float auxv[CVF_AUX_ROWS];
-#pragma unroll
-  for (int i = 0; i < CVF_AUX_ROWS; ++i) auxv[i] = ax[i * CVF_TILE];
   float wv = 0.0f;
   if (fuse.on) {
     const int64_t frame = tile * CVF_TILE + lane;
@@ -610,6 +606,86 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
     const int j = tid + nthreads * i;
     const int jc = j < ntab ? j : ntab - 1;
     tabv[i] = jc < 3 * nal ? pp.ref_c[jc] : a[jc - 3 * nal];
+  }
+  if constexpr (!K1) {
+    // the alignment kernel ran before: its rotation / centroid / K^-1 rows (lane = frame)
+    const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
+#pragma unroll
+    for (int i = 0; i < CVF_AUX_ROWS; ++i) auxv[i] = ax[i * CVF_TILE];
+  } else {
+    // ---- K1 inside: stage the tile, split the align atoms over the block's waves for centroid + covariance (fp64
+    // partial sums through the still unused g images), every wave solves the 64 rotations (lane = frame), then the
+    // waves split the atoms again for the aligned positions = features, which land in image 0 (the forward chain's
+    // B operand) and in feat_tiled (the backward kernel reads them)
+    load_x_tile(x, B, nc, tile, lds, tid, nthreads);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = tid + nthreads * i;
+      if (j < ntab) refL[j] = tabv[i];
+    }
+    for (int j = tid + 2 * nthreads; j < ntab; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : a[j - 3 * nal];
+    __syncthreads();
+    const float* my = lds + lane * stride;
+    const int nw = nthreads >> 6;
+    double acc[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) acc[i] = 0.0;
+    for (int b = wave; b < nal; b += nw) {
+      const double x0 = (double)my[3 * b], x1 = (double)my[3 * b + 1], x2 = (double)my[3 * b + 2];
+      const double r0 = (double)refL[3 * b], r1 = (double)refL[3 * b + 1], r2 = (double)refL[3 * b + 2];
+      acc[0] += x0; acc[1] += x1; acc[2] += x2;
+      acc[3] = fma(x0, r0, acc[3]); acc[4] = fma(x0, r1, acc[4]); acc[5] = fma(x0, r2, acc[5]);
+      acc[6] = fma(x1, r0, acc[6]); acc[7] = fma(x1, r1, acc[7]); acc[8] = fma(x1, r2, acc[8]);
+      acc[9] = fma(x2, r0, acc[9]); acc[10] = fma(x2, r1, acc[10]); acc[11] = fma(x2, r2, acc[11]);
+      acc[12] += r0; acc[13] += r1; acc[14] += r2;
+    }
+    if (nw > 1) {
+      double* P = reinterpret_cast<double*>(Uw);
+#pragma unroll
+      for (int i = 0; i < 15; ++i) P[i * CVF_TILE + lane] = acc[i];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 15; ++i) {
+        double t = 0.0;
+        for (int ww = 0; ww < nw; ++ww) t += reinterpret_cast<const double*>(Ub + (size_t)ww * nc * CVF_TILE)[i * CVF_TILE + lane];
+        acc[i] = t;
+      }
+      __syncthreads();   // every partial sum has been read: the images may be overwritten
+    }
+    const double inv = fast_rcp((double)nal);
+    double cd[3] = {acc[0] * inv, acc[1] * inv, acc[2] * inv};
+    double Hm[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Hm[i][j] = fma(-cd[i], acc[12 + j], acc[3 + 3 * i + j]);
+    KabschOut ko;
+    kabsch_from_H(Hm, ko);
+    const Centre c = centre_of(cd);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) auxv[i] = ko.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) auxv[9 + i] = c.hi[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) auxv[12 + i] = ko.Kinv[i];
+    if (wave == 0 && aux_tiled != nullptr) {
+      float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
+#pragma unroll
+      for (int i = 0; i < CVF_AUX_ROWS; ++i) ax[i * CVF_TILE] = auxv[i];
+    }
+    float* ft = feat + tile * (int64_t)D * CVF_TILE + lane;
+#pragma unroll 2
+    for (int at = wave; at < pp.n_rec; at += nw) {
+      const V3 al = row_times(centred(my, at, c), ko.R);
+      Ub[(3 * at) * CVF_TILE + lane] = al.x;
+      Ub[(3 * at + 1) * CVF_TILE + lane] = al.y;
+      Ub[(3 * at + 2) * CVF_TILE + lane] = al.z;
+      ft[(3 * at) * CVF_TILE] = al.x;
+      ft[(3 * at + 1) * CVF_TILE] = al.y;
+      ft[(3 * at + 2) * CVF_TILE] = al.z;
+    }
+    __syncthreads();   // the feature image is complete
+    in_lane = Ub + fo;
   }
   // ---- ... and forward part (matrix-core layout): every operand of the chain
   L0Chunk<H, FT, CH> c0, c1, c2;
@@ -625,13 +701,15 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
   float wl[RT][4];
   load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
   const float bL = theta[mlp.b_off[net][NH]];
-  load_x_tile(x, B, nc, tile, lds, tid, nthreads);
+  if constexpr (!K1) {
+    load_x_tile(x, B, nc, tile, lds, tid, nthreads);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int j = tid + nthreads * i;
-    if (j < ntab) refL[j] = tabv[i];
+    for (int i = 0; i < 2; ++i) {
+      const int j = tid + nthreads * i;
+      if (j < ntab) refL[j] = tabv[i];
+    }
+    for (int j = tid + 2 * nthreads; j < ntab; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : a[j - 3 * nal];
   }
-  for (int j = tid + 2 * nthreads; j < ntab; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : a[j - 3 * nal];
   // ---- forward chain
   Vec<H, FT> h[NH];
   set_const<H, FT>(h[0], bias[0]);
@@ -689,6 +767,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
       tangent_of<H, FT>(d, h[l - 1], e);
     }
     const float* pT0 = pk + L.t0();
+    if constexpr (K1) __syncthreads();   // every wave has consumed the feature image: wave 0's g may replace it
 #pragma unroll
     for (int rt = 0; rt < CTMAX; ++rt) {
       if (rt < CT) {  // wave-uniform
@@ -1434,14 +1513,14 @@ extern "C" int cvf_ef_fwd_metric_supported(const cvf_mlp_desc* mlp, const cvf_pp
   return fwd_metric_lds(pp, mlp->n_nets) <= 80 * 1024 && cvf_ef_saved_floats(mlp, 1) > 0;
 }
 
-extern "C" int cvf_ef_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, const float* packed, const float* feat_tiled,
-                                       const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled,
-                                       const float* a, float* y_tiled, float* saved, float* q_tiled, float* e_tiled,
-                                       const cvf_ef_cfg* cfg, const float* w, double* scratch, double* stats,
-                                       double* loss_vec, double* coef, void* stream) {
+static int fwd_metric_launch(bool with_k1, const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                             const cvf_pp_desc* pp, const float* x, int64_t B, float* aux_tiled, const float* a, float* y_tiled,
+                             float* saved, float* q_tiled, float* e_tiled, const cvf_ef_cfg* cfg, const float* w, double* scratch,
+                             double* stats, double* loss_vec, double* coef, void* stream) {
   CVF_REQUIRE(cvf_ef_fwd_metric_supported(mlp, pp), "cvf_ef_fwd_metric_stats: shape not covered (cvf_ef_fwd_metric_supported() == 0)");
-  CVF_REQUIRE(theta && packed && feat_tiled && x && aux_tiled && a && y_tiled && q_tiled && e_tiled && cfg && w && scratch && stats &&
-                  B > 0, "cvf_ef_fwd_metric_stats: bad argument");
+  CVF_REQUIRE(theta && packed && feat_tiled && x && a && y_tiled && q_tiled && e_tiled && cfg && w && scratch && stats && B > 0,
+              "cvf_ef_fwd_metric_stats: bad argument");
+  CVF_REQUIRE(with_k1 || aux_tiled, "cvf_ef_fwd_metric_stats: aux_tiled missing");
   CVF_REQUIRE(cfg->k == mlp->n_nets && cfg->lag_idx == 0, "cvf_ef_fwd_metric_stats: generator mode only, cfg.k must equal the number of nets");
   CVF_REQUIRE(loss_vec == nullptr || coef != nullptr, "cvf_ef_fwd_metric_stats: loss_vec without coef");
   int H, NH;
@@ -1458,15 +1537,43 @@ extern "C" int cvf_ef_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* the
   const size_t lds = fwd_metric_lds(pp, k);
   ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)ef_fwd_metric_kernel<kH, kNH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((ef_fwd_metric_kernel<kH, kNH>), dim3((unsigned)T), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed,
-                       feat_tiled, *pp, x, B, aux_tiled, a, y_tiled, saved, q_tiled, e_tiled, f);
+    auto go = [&](auto kernel) {
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)T), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, feat_tiled, *pp, x, B,
+                         aux_tiled, a, y_tiled, saved, q_tiled, e_tiled, f);
+    };
+    if (with_k1) go(ef_fwd_metric_kernel<kH, kNH, true>);
+    else go(ef_fwd_metric_kernel<kH, kNH, false>);
   });
   int rc = cvf_check_launch("ef_fwd_metric_kernel");
   if (rc) return rc;
   if (f.on) return cvf_ef_stats_finish(cfg, (int)T, scratch, stats, loss_vec, coef, (hipStream_t)stream);
   return cvf_ef_stats(cfg, B, w, y_tiled, e_tiled, nullptr, nullptr, scratch + T * ns, stats, loss_vec, coef, stream);
+}
+
+extern "C" int cvf_ef_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, const float* packed, const float* feat_tiled,
+                                       const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled,
+                                       const float* a, float* y_tiled, float* saved, float* q_tiled, float* e_tiled,
+                                       const cvf_ef_cfg* cfg, const float* w, double* scratch, double* stats,
+                                       double* loss_vec, double* coef, void* stream) {
+  return fwd_metric_launch(false, mlp, theta, packed, const_cast<float*>(feat_tiled), pp, x, B, const_cast<float*>(aux_tiled), a,
+                           y_tiled, saved, q_tiled, e_tiled, cfg, w, scratch, stats, loss_vec, coef, stream);
+}
+
+// the alignment kernel folded in as well: one launch from coordinates to q, E and the batch sums
+extern "C" int cvf_ef_align_fwd_metric_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp) {
+  // (the covariance partial sums pass through the g images: 15 doubles per frame must fit an image of n_coord floats)
+  return cvf_ef_fwd_metric_supported(mlp, pp) && pp->n_coord >= 30 && getenv("CVF_NO_ALIGN_FUSED") == nullptr;
+}
+
+extern "C" int cvf_ef_align_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                                             const cvf_pp_desc* pp, const float* x, int64_t B, float* aux_tiled, const float* a,
+                                             float* y_tiled, float* saved, float* q_tiled, float* e_tiled,
+                                             const cvf_ef_cfg* cfg, const float* w, double* scratch, double* stats,
+                                             double* loss_vec, double* coef, void* stream) {
+  CVF_REQUIRE(cvf_ef_align_fwd_metric_supported(mlp, pp), "cvf_ef_align_fwd_metric_stats: shape not covered");
+  return fwd_metric_launch(true, mlp, theta, packed, feat_tiled, pp, x, B, aux_tiled, a, y_tiled, saved, q_tiled, e_tiled, cfg, w,
+                           scratch, stats, loss_vec, coef, stream);
 }
 
 extern "C" int64_t cvf_ef_backward_slab_rows(int64_t n_tiles) { return bwd_grid(n_tiles); }

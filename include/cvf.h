@@ -178,6 +178,15 @@ int cvf_ef_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, const f
                             float* y_tiled, float* saved, float* q_tiled, float* e_tiled, const cvf_ef_cfg* cfg,
                             const float* w, double* scratch, double* stats, double* loss_vec, double* coef, void* stream);
 
+/* The same with K1 folded in: from the coordinates to q, E and the batch sums in one launch (feat_tiled and aux_tiled
+ * become outputs; aux_tiled may be NULL).  Replaces cvf_align_feature_fwd + cvf_ef_fwd_metric_stats. */
+int cvf_ef_align_fwd_metric_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp);
+int cvf_ef_align_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                                  const cvf_pp_desc* pp, const float* x, int64_t B, float* aux_tiled, const float* a,
+                                  float* y_tiled, float* saved, float* q_tiled, float* e_tiled, const cvf_ef_cfg* cfg,
+                                  const float* w, double* scratch, double* stats, double* loss_vec, double* coef,
+                                  void* stream);
+
 /* --- K5: batch statistics (core.py:406-416,426,428,446-452), fp64, fixed-order two
  * stage reduction.  w [B]; y_tiled [T][k][64]; generator: e_tiled [T][k][64];
  * transfer: y_lag_tiled, w_lag.  scratch: cvf_ef_stats_scratch_doubles() doubles. */
