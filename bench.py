@@ -40,6 +40,7 @@ FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 vector == fp32-input MF
 P_W = 66 * 20 + 20 * 20 + 20 * 20 + 20            # multiply-adds of one net's forward
 K1_BYTES = 12 * N_ATOMS + 4 + 4 * 66              # 532 B/frame
 FLOP_FWD = 2 * K_NETS * (P_W + (P_W - 66 * 20) + 66 * 20)            # forward + d-chain + g = W1^T d
+FLOP_K1 = 2 * (12 + 12) * N_ATOMS + 1500              # covariance + aligned positions per atom, 3x3 eigen-solve
 FLOP_METRIC = 2 * K_NETS * 33 * N_ATOMS          # three passes of q = J A J^T g: ~33 fused multiply-adds per atom and net
 FLOP_BWD = 2 * K_NETS * (P_W + 800 + 2 * P_W)  # tangent chain, zbar chain, outer products (h and the d chain come from the forward kernel)
 
@@ -209,7 +210,7 @@ def main():
 
     if dom in ("cvf_ef_backward", "cvf_ef_mlp_fwd", "cvf_ef_fwd_metric_stats", "cvf_ef_align_fwd_metric_stats"):
         flop = {"cvf_ef_backward": FLOP_BWD, "cvf_ef_mlp_fwd": FLOP_FWD, "cvf_ef_fwd_metric_stats": FLOP_FWD + FLOP_METRIC,
-                "cvf_ef_align_fwd_metric_stats": FLOP_FWD + FLOP_METRIC}[dom] * B
+                "cvf_ef_align_fwd_metric_stats": FLOP_FWD + FLOP_METRIC + FLOP_K1}[dom] * B
         ach = flop / (kern_ms[dom] * 1e-3) / 1e12
         roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS,
                     traffic=pmc_traffic(dom), avg_launch_us=kern_ms[dom] * 1e3,

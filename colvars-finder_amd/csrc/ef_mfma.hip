@@ -1518,8 +1518,10 @@ static int fwd_metric_launch(bool with_k1, const cvf_mlp_desc* mlp, const float*
                              float* saved, float* q_tiled, float* e_tiled, const cvf_ef_cfg* cfg, const float* w, double* scratch,
                              double* stats, double* loss_vec, double* coef, void* stream) {
   CVF_REQUIRE(cvf_ef_fwd_metric_supported(mlp, pp), "cvf_ef_fwd_metric_stats: shape not covered (cvf_ef_fwd_metric_supported() == 0)");
-  CVF_REQUIRE(theta && packed && feat_tiled && x && a && y_tiled && q_tiled && e_tiled && cfg && w && scratch && stats && B > 0,
+  CVF_REQUIRE(theta && packed && feat_tiled && x && a && y_tiled && q_tiled && e_tiled && cfg && w && scratch && B > 0,
               "cvf_ef_fwd_metric_stats: bad argument");
+  CVF_REQUIRE(stats != nullptr || cvf_ntiles(B) <= kFuseMaxTiles,
+              "cvf_ef_fwd_metric_stats: stats == NULL (rows left for cvf_ef_stats_finish_rows) needs cvf_ef_fused_stats_rows(B) > 0");
   CVF_REQUIRE(with_k1 || aux_tiled, "cvf_ef_fwd_metric_stats: aux_tiled missing");
   CVF_REQUIRE(cfg->k == mlp->n_nets && cfg->lag_idx == 0, "cvf_ef_fwd_metric_stats: generator mode only, cfg.k must equal the number of nets");
   CVF_REQUIRE(loss_vec == nullptr || coef != nullptr, "cvf_ef_fwd_metric_stats: loss_vec without coef");
@@ -1546,7 +1548,7 @@ static int fwd_metric_launch(bool with_k1, const cvf_mlp_desc* mlp, const float*
     else go(ef_fwd_metric_kernel<kH, kNH, false>);
   });
   int rc = cvf_check_launch("ef_fwd_metric_kernel");
-  if (rc) return rc;
+  if (rc || stats == nullptr) return rc;   // stats == NULL: the caller finishes the rows itself (cvf_ef_stats_finish_rows)
   if (f.on) return cvf_ef_stats_finish(cfg, (int)T, scratch, stats, loss_vec, coef, (hipStream_t)stream);
   return cvf_ef_stats(cfg, B, w, y_tiled, e_tiled, nullptr, nullptr, scratch + T * ns, stats, loss_vec, coef, stream);
 }
@@ -1558,6 +1560,16 @@ extern "C" int cvf_ef_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* the
                                        double* loss_vec, double* coef, void* stream) {
   return fwd_metric_launch(false, mlp, theta, packed, const_cast<float*>(feat_tiled), pp, x, B, const_cast<float*>(aux_tiled), a,
                            y_tiled, saved, q_tiled, e_tiled, cfg, w, scratch, stats, loss_vec, coef, stream);
+}
+
+// Rows of per-tile partial sums the fused launches leave in `scratch` (0: the batch is too large for the fused sums and
+// the launch must be given `stats` so that it runs the two-stage reduction itself), and the launch that adds them.
+extern "C" int64_t cvf_ef_fused_stats_rows(int64_t B) { return cvf_ntiles(B) <= kFuseMaxTiles ? cvf_ntiles(B) : 0; }
+extern "C" int cvf_ef_stats_finish_rows(const cvf_ef_cfg* cfg, int64_t n_rows, const double* partial, double* stats,
+                                        double* loss_vec, double* coef, void* stream) {
+  CVF_REQUIRE(cfg && partial && stats && n_rows > 0, "cvf_ef_stats_finish_rows: bad argument");
+  CVF_REQUIRE(loss_vec == nullptr || coef != nullptr, "cvf_ef_stats_finish_rows: loss_vec without coef");
+  return cvf_ef_stats_finish(cfg, (int)n_rows, partial, stats, loss_vec, coef, (hipStream_t)stream);
 }
 
 // the alignment kernel folded in as well: one launch from coordinates to q, E and the batch sums
