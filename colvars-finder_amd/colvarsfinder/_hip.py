@@ -68,7 +68,7 @@ _SIGNATURES = {
                                  C.c_void_p, C.c_void_p]),
     "cvf_ef_saved_floats": (C.c_int64, [C.POINTER(MLPDesc), C.c_int64]),
     "cvf_ef_fwd_metric_supported": (C.c_int, [C.POINTER(MLPDesc), C.POINTER(PPDesc)]),
-    "cvf_ef_fused_stats_rows": (C.c_int64, [C.c_int64]),
+    "cvf_ef_fused_stats_rows": (C.c_int64, [C.POINTER(MLPDesc), C.POINTER(PPDesc), C.c_int64, C.c_int]),
     "cvf_ef_stats_finish_rows": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_align_fwd_metric_supported": (C.c_int, [C.POINTER(MLPDesc), C.POINTER(PPDesc)]),
     "cvf_ef_align_fwd_metric_stats": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PPDesc), C.c_void_p,

@@ -432,7 +432,7 @@ class EigenFunctionTask(TrainingTask):
         if self._fused_fm:   # [alignment,] nets forward, q = J A J^T g, E and the batch sums in one launch: g never leaves the chip
             name, fn = (("cvf_ef_align_fwd_metric_stats", lib.cvf_ef_align_fwd_metric_stats) if with_k1 else
                         ("cvf_ef_fwd_metric_stats", lib.cvf_ef_fwd_metric_stats))
-            rows = lib.cvf_ef_fused_stats_rows(B)   # > 0: the launch leaves per-tile sums, a second short launch adds them
+            rows = lib.cvf_ef_fused_stats_rows(fl.desc, self._pp, B, int(with_k1))   # > 0: per-tile sums left for a short second launch
             self._call(name, fn, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat),
                        self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), P(ws.y), P(ws.saved), P(ws.q), P(ws.e), self._cfg,
                        P(w), P(ws.scratch), None if rows > 0 else P(ws.stats), lv, cf, s)

@@ -196,3 +196,4 @@ __device__ __forceinline__ void metric_pure_passes(const cvf_pp_desc& pp, int la
   }
   CVF_STAMP(15);
 }
+

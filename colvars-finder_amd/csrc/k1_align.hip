@@ -684,7 +684,7 @@ extern "C" int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B
 }
 
 extern "C" int64_t cvf_metric_stats_scratch_doubles(int64_t B, int k) {
-  return cvf_ntiles(B) * (int64_t)cvf_ef_nstats(k, 0) + cvf_ef_stats_scratch_doubles(k, 0);
+  return 2 * cvf_ntiles(B) * (int64_t)cvf_ef_nstats(k, 0) + cvf_ef_stats_scratch_doubles(k, 0);   // (up to two rows per tile)
 }
 
 extern "C" int cvf_metric_apply_stats(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled,

@@ -178,9 +178,9 @@ int cvf_ef_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, const f
                             float* y_tiled, float* saved, float* q_tiled, float* e_tiled, const cvf_ef_cfg* cfg,
                             const float* w, double* scratch, double* stats, double* loss_vec, double* coef, void* stream);
 
-/* With stats == NULL the fused launches stop after leaving cvf_ef_fused_stats_rows(B) (> 0 required) rows of per-tile
+/* With stats == NULL the fused launches stop after leaving cvf_ef_fused_stats_rows() (> 0 required) rows of per-tile
  * sums in `scratch`; cvf_ef_stats_finish_rows adds them in a fixed order (and evaluates cvf_ef_loss when loss_vec != NULL). */
-int64_t cvf_ef_fused_stats_rows(int64_t B);
+int64_t cvf_ef_fused_stats_rows(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp, int64_t B, int with_align);
 int cvf_ef_stats_finish_rows(const cvf_ef_cfg* cfg, int64_t n_rows, const double* partial, double* stats, double* loss_vec,
                              double* coef, void* stream);
 /* The same with K1 folded in: from the coordinates to q, E and the batch sums in one launch (feat_tiled and aux_tiled
