@@ -577,6 +577,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int col = lane & 15, q = lane >> 4;
+  CVF_STAMP(50);
   const int64_t tile = blockIdx.x;
   const int net = wave;                         // the host launches one wave per net
   const int k = mlp.n_nets, D = mlp.dims[0];
@@ -625,12 +626,14 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
     }
     for (int j = tid + 2 * nthreads; j < ntab; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : a[j - 3 * nal];
     __syncthreads();
+    CVF_STAMP(51);
     const float* my = lds + lane * stride;
     const int nw = nthreads >> 6;
     double acc[15];
 #pragma unroll
     for (int i = 0; i < 15; ++i) acc[i] = 0.0;
-    for (int b = wave; b < nal; b += nw) {
+#pragma unroll 2
+    for (int b = 0; b < nal; ++b) {   // every wave over all align atoms: splitting them cost more in the exchange than it saved
       const double x0 = (double)my[3 * b], x1 = (double)my[3 * b + 1], x2 = (double)my[3 * b + 2];
       const double r0 = (double)refL[3 * b], r1 = (double)refL[3 * b + 1], r2 = (double)refL[3 * b + 2];
       acc[0] += x0; acc[1] += x1; acc[2] += x2;
@@ -639,19 +642,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
       acc[9] = fma(x2, r0, acc[9]); acc[10] = fma(x2, r1, acc[10]); acc[11] = fma(x2, r2, acc[11]);
       acc[12] += r0; acc[13] += r1; acc[14] += r2;
     }
-    if (nw > 1) {
-      double* P = reinterpret_cast<double*>(Uw);
-#pragma unroll
-      for (int i = 0; i < 15; ++i) P[i * CVF_TILE + lane] = acc[i];
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 15; ++i) {
-        double t = 0.0;
-        for (int ww = 0; ww < nw; ++ww) t += reinterpret_cast<const double*>(Ub + (size_t)ww * nc * CVF_TILE)[i * CVF_TILE + lane];
-        acc[i] = t;
-      }
-      __syncthreads();   // every partial sum has been read: the images may be overwritten
-    }
+    CVF_STAMP(52);
     const double inv = fast_rcp((double)nal);
     double cd[3] = {acc[0] * inv, acc[1] * inv, acc[2] * inv};
     double Hm[3][3];
@@ -662,6 +653,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
     KabschOut ko;
     kabsch_from_H(Hm, ko);
     const Centre c = centre_of(cd);
+    CVF_STAMP(53);
 #pragma unroll
     for (int i = 0; i < 9; ++i) auxv[i] = ko.R[i];
 #pragma unroll
@@ -685,6 +677,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
       ft[(3 * at + 2) * CVF_TILE] = al.z;
     }
     __syncthreads();   // the feature image is complete
+    CVF_STAMP(54);
     in_lane = Ub + fo;
   }
   // ---- ... and forward part (matrix-core layout): every operand of the chain
@@ -710,12 +703,14 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
     }
     for (int j = tid + 2 * nthreads; j < ntab; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : a[j - 3 * nal];
   }
+  CVF_STAMP(55);
   // ---- forward chain
   Vec<H, FT> h[NH];
   set_const<H, FT>(h[0], bias[0]);
   mul_l0chunk<H, FT, CH>(h[0], c0);
   mul_l0chunk<H, FT, CH>(h[0], c1);
   mul_l0chunk<H, FT, CH>(h[0], c2);
+  CVF_STAMP(56);
   tanh_inplace<H, FT>(h[0]);
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
@@ -744,6 +739,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
 #pragma unroll
     for (int l = 0; l < NH; ++l) save_vec<H>(sv + l * saved_per_vec<H>(), h[l], lane);
   }
+  CVF_STAMP(57);
   // ---- d chain and g = W_1^T d_1 -> this wave's LDS image [feature][frame]
   {
     HFrag<H> tf[NH > 1 ? NH - 1 : 1];
@@ -767,20 +763,23 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
       tangent_of<H, FT>(d, h[l - 1], e);
     }
     const float* pT0 = pk + L.t0();
+    float t0[CTMAX][NG];   // requested before the barrier: five dependent round trips otherwise
+#pragma unroll
+    for (int rt = 0; rt < CTMAX; ++rt)
+#pragma unroll
+      for (int s = 0; s < NG; ++s) t0[rt][s] = pT0[((rt < CT ? rt : CT - 1) * NG + s) * 64 + lane];
+    CVF_STAMP(58);
     if constexpr (K1) __syncthreads();   // every wave has consumed the feature image: wave 0's g may replace it
 #pragma unroll
     for (int rt = 0; rt < CTMAX; ++rt) {
       if (rt < CT) {  // wave-uniform
-        float t0[NG];
-#pragma unroll
-        for (int s = 0; s < NG; ++s) t0[s] = pT0[(rt * NG + s) * 64 + lane];
         f32x4 acc[FT];
 #pragma unroll
         for (int ft = 0; ft < FT; ++ft) acc[ft] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int s = 0; s < NG; ++s)
 #pragma unroll
-          for (int ft = 0; ft < FT; ++ft) acc[ft] = mfma4(t0[s], d.v[s >> 2][ft][s & 3], acc[ft]);
+          for (int ft = 0; ft < FT; ++ft) acc[ft] = mfma4(t0[rt][s], d.v[s >> 2][ft][s & 3], acc[ft]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * rt + 4 * q + r;
@@ -789,6 +788,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
       }
     }
   }
+  CVF_STAMP(59);
   __syncthreads();   // coordinate tile, tables and every net's y are in LDS; the g images are wave-private
   float yv[CVF_MAX_NETS];
 #pragma unroll
