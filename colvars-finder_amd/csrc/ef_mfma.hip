@@ -1294,6 +1294,14 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
           // (no MFMA under lane-divergent control flow: operand values are selected per lane, the MFMAs are uniform)
           const float pad1 = i == D ? 1.0f : 0.0f;   // bias column; columns past it stay 0
           f32x4 acc[RTO];
+          // the q half's operands are requested together with the feature half's (SAVED: the registers the forward
+          // recompute used to hold are free): one memory round trip per column tile instead of two
+          float4 bq[4];
+          if (SAVED && tangent) {
+            const float4* qb = reinterpret_cast<const float4*>(q_tile + (int64_t)ic * CVF_TILE + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bq[j] = qb[4 * j];
+          }
           {
             const float4* fb = reinterpret_cast<const float4*>(f_tile + (int64_t)ic * CVF_TILE + 4 * q);
             float4 b[4];
@@ -1318,10 +1326,12 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
             }
           }
           if (tangent) {
-            const float4* qb = reinterpret_cast<const float4*>(q_tile + (int64_t)ic * CVF_TILE + 4 * q);
-            float4 b[4];
+            if (!SAVED) {
+              const float4* qb = reinterpret_cast<const float4*>(q_tile + (int64_t)ic * CVF_TILE + 4 * q);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = qb[4 * j];
+              for (int j = 0; j < 4; ++j) bq[j] = qb[4 * j];
+            }
+            const float4 (&b)[4] = bq;
 #pragma unroll
             for (int rt = 0; rt < RTO; ++rt) {
               if (rt >= rt0 && (rt - rt0) % rstep == 0) {
