@@ -1161,6 +1161,16 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
     }
     CVF_STAMP(10);
     if (tangent) {
+      // SAVED: the hidden layers' fragments (W^T for the d chain, W for the tangent chain) are requested here, ahead of
+      // the first-layer product, instead of just in time at each layer (registers are free without the recompute)
+      HFrag<H> tfr[NH > 1 ? NH - 1 : 1], ffr[NH > 1 ? NH - 1 : 1];
+      if (SAVED) {
+#pragma unroll
+        for (int l = 1; l < NH; ++l) {
+          load_hfrag<H>(tfr[l - 1], pk + L.th(l), lane);
+          load_hfrag<H>(ffr[l - 1], pk + L.fh(l), lane);
+        }
+      }
       {
         Vec<H, FT> d;
 #pragma unroll
@@ -1175,7 +1185,8 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
 #pragma unroll
         for (int l = NH - 1; l >= 1; --l) {
           init_bias<H, FT>(e[l - 1], nullptr, q);
-          hidden_apply<H, FT>(e[l - 1], pk + L.th(l), d, lane);
+          if (SAVED) hidden_mul<H, FT>(e[l - 1], tfr[l - 1], d);
+          else hidden_apply<H, FT>(e[l - 1], pk + L.th(l), d, lane);
           tangent_of<H, FT>(d, h[l - 1], e[l - 1]);   // d_{l-1} = (1 - h^2) .* e_{l-1}
         }
       }
@@ -1192,7 +1203,8 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
         Vec<H, FT> td;
         tangent_of<H, FT>(td, h[l - 1], t[l - 1]);
         init_bias<H, FT>(t[l], nullptr, q);
-        hidden_apply<H, FT>(t[l], pk + L.fh(l), td, lane);
+        if (SAVED) hidden_mul<H, FT>(t[l], ffr[l - 1], td);
+        else hidden_apply<H, FT>(t[l], pk + L.fh(l), td, lane);
       }
     }
 
