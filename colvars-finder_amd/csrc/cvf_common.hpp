@@ -18,6 +18,15 @@ int cvf_check_launch(const char* what);
   } while (0)
 
 static inline int64_t cvf_ntiles(int64_t B) { return (B + CVF_TILE - 1) / CVF_TILE; }
+// compute units of the current device (256 on MI355X), asked once
+static inline int cvf_cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    return v;
+  }();
+  return n;
+}
 
 // ------------------------------------------------------------------------------------
 // wave helpers

@@ -44,19 +44,19 @@ __device__ __forceinline__ double rsqrt_1step(double x) {
 //   cos(2 phi) = |d| / r   ->   c^2 = (1 + |d|/r) / 2,   s = sgn(d) b / (2 r c),   t = s / c
 // evaluated with two reciprocal square roots (1/r, 1/c) and no division: the usual
 // t = sgn(d) b / (|d| + r), c = 1/sqrt(1 + t^2) needs a square root, a reciprocal and a reciprocal square root,
-// and these dependent fp64 sequences are what the solve's time consists of.  d = b = 0 gives the identity.
+// and these dependent fp64 sequences are what the solve's time consists of.
 template <int P, int Q>
 __device__ __forceinline__ void jacobi_rot(double (&A)[3][3], double (&V)[3][3]) {
   const double apq = A[P][Q];
   const double app = A[P][P], aqq = A[Q][Q];
   const double d = aqq - app, b = 2.0 * apq;
-  const double rr = fma(d, d, b * b);
-  const bool live = rr > 1e-290;
-  const double inv_r = rsqrt_1step(live ? rr : 1.0);
-  const double c2 = fma(0.5 * fabs(d), inv_r, 0.5);   // in [1/2, 1]
+  // |d| + tiny keeps r > 0: d = b = 0 gives c = 1, s = 0 (the identity) without a guard on every quantity
+  const double ad = fabs(d) + 1e-150;
+  const double inv_r = rsqrt_1step(fma(ad, ad, b * b));
+  const double c2 = fma(0.5 * ad, inv_r, 0.5);   // in [1/2, 1]
   const double inv_c = rsqrt_1step(c2);
-  const double c = live ? c2 * inv_c : 1.0;
-  const double s = live ? (d < 0.0 ? -0.5 : 0.5) * b * inv_r * inv_c : 0.0;
+  const double c = c2 * inv_c;
+  const double s = (d < 0.0 ? -0.5 : 0.5) * b * inv_r * inv_c;
   const double t = s * inv_c;
   constexpr int R = 3 - P - Q;  // the remaining index
   A[P][P] = app - t * apq;
@@ -94,19 +94,20 @@ __device__ __forceinline__ void kabsch_from_H(const double (&H)[3][3], KabschOut
     jacobi_rot<0, 2>(A, V);
     jacobi_rot<1, 2>(A, V);
   }
-  // pick the two largest eigenvalues (columns of V)
-  double l0 = A[0][0], l1 = A[1][1], l2 = A[2][2];
-  int i1 = 0;
-  if (l1 > l0) i1 = 1;
-  if (l2 > (i1 == 0 ? l0 : l1)) i1 = 2;
-  int ia = (i1 + 1) % 3, ib = (i1 + 2) % 3;
-  const double la = (ia == 0 ? l0 : (ia == 1 ? l1 : l2)), lb = (ib == 0 ? l0 : (ib == 1 ? l1 : l2));
-  const int i2 = (la >= lb) ? ia : ib;
+  // v1, v2: eigenvectors of the largest and the second eigenvalue.  Written as selects on three flags (the
+  // index arithmetic this replaces compiled to a tree of exec-mask branches, a third of the solve's instructions).
+  const double l0 = A[0][0], l1 = A[1][1], l2 = A[2][2];
+  const bool min0 = l0 <= l1 && l0 <= l2;   // column 0 belongs to the smallest eigenvalue
+  const bool min1 = !min0 && l1 <= l2;      // column 1 does
+  const bool min01 = min0 || min1;
+  const double la = min0 ? l1 : l0, lb = min01 ? l2 : l1;   // the two that remain: columns (1,2), (0,2) or (0,1)
+  const bool a_first = la >= lb;
   double v1[3], v2[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    v1[i] = (i1 == 0) ? V[i][0] : ((i1 == 1) ? V[i][1] : V[i][2]);
-    v2[i] = (i2 == 0) ? V[i][0] : ((i2 == 1) ? V[i][1] : V[i][2]);
+    const double ca = min0 ? V[i][1] : V[i][0], cb = min01 ? V[i][2] : V[i][1];
+    v1[i] = a_first ? ca : cb;
+    v2[i] = a_first ? cb : ca;
   }
   double u1[3], u2[3];
 #pragma unroll
@@ -115,14 +116,14 @@ __device__ __forceinline__ void kabsch_from_H(const double (&H)[3][3], KabschOut
     u2[i] = H[i][0] * v2[0] + H[i][1] * v2[1] + H[i][2] * v2[2];
   }
   double n1 = u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2];
-  n1 = n1 > 1e-300 ? fast_rsqrt(n1) : 0.0;
+  n1 = fast_rsqrt(n1 + 1e-300);   // u1 = 0 stays 0 (no branch around the Newton steps)
 #pragma unroll
   for (int i = 0; i < 3; ++i) u1[i] *= n1;
   const double pr = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
 #pragma unroll
   for (int i = 0; i < 3; ++i) u2[i] -= pr * u1[i];
   double n2 = u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2];
-  n2 = n2 > 1e-300 ? fast_rsqrt(n2) : 0.0;
+  n2 = fast_rsqrt(n2 + 1e-300);
 #pragma unroll
   for (int i = 0; i < 3; ++i) u2[i] *= n2;
   const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
@@ -146,7 +147,9 @@ __device__ __forceinline__ void kabsch_from_H(const double (&H)[3][3], KabschOut
   const double c00 = k11 * k22 - k12 * k12, c01 = k02 * k12 - k01 * k22, c02 = k01 * k12 - k02 * k11;
   const double c11 = k00 * k22 - k02 * k02, c12 = k01 * k02 - k00 * k12, c22 = k00 * k11 - k01 * k01;
   double det = k00 * c00 + k01 * c01 + k02 * c02;
-  det = fabs(det) > 1e-300 ? fast_rcp(det) : 0.0;
+  const bool regular = fabs(det) > 1e-300;
+  det = fast_rcp(regular ? det : 1.0);
+  det = regular ? det : 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll

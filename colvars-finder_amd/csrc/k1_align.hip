@@ -174,6 +174,182 @@ __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const floa
 }
 
 // ------------------------------------------------------------------------------------
+// K1, fast layouts, large launches: persistent waves streaming whole 64-frame tiles (lane = frame).
+//  * the tile is copied to LDS as it lies in memory (16-byte loads -> 16-byte LDS writes, no index arithmetic): a
+//    lane's frame starts at dword lane * nc, and for nc = 2 (mod 4) the lanes' 8-byte reads of one instruction
+//    cover each bank exactly once - so the per-lane loops read atom PAIRS (three 8-byte reads);
+//  * the wave walks tiles blockIdx, blockIdx + grid, ...; the NEXT tile's loads are issued into NV x 4 registers
+//    before the current tile is worked on and land in LDS at the top of the next iteration, so every resident
+//    wave always has 64 * nc * 4 bytes in flight (the one-tile-per-wave kernel spent half its time waiting for
+//    its own loads: 16 k of 32 k cycles at one million frames);
+//  * the reference is converted to fp64 once per wave and kept in LDS;
+//  * the row-major output (ROWS) is written over the tile in LDS and leaves as it came, in 16-byte stores.
+// Frames past the last whole tile are left to k1_align_kernel.
+// ------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int NV, bool TILED, bool ROWS>
+__global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t n_tiles,
+                                                        float* __restrict__ feat_tiled, float* __restrict__ feat_rows,
+                                                        float* __restrict__ aux_tiled) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int nc = pp.n_coord;
+  const int nvec = 16 * nc;   // 16-byte vectors per tile
+  float4* tile4 = reinterpret_cast<float4*>(lds);
+  float4* ref4 = reinterpret_cast<float4*>(lds + CVF_TILE * nc);   // (r0, r1, r2, 0) per align atom: one broadcast read
+  for (int b = lane; b < pp.n_align; b += CVF_WAVE)
+    ref4[b] = float4{pp.ref_c[3 * b], pp.ref_c[3 * b + 1], pp.ref_c[3 * b + 2], 0.0f};
+  float4 pre[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) pre[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+  auto fetch = [&](int64_t tile) {
+    const float4* src = reinterpret_cast<const float4*>(x + tile * CVF_TILE * nc);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = i * CVF_WAVE + lane;
+      if (v < nvec) pre[i] = src[v];
+    }
+  };
+  int64_t tile = blockIdx.x;
+  if (tile < n_tiles) fetch(tile);
+  __syncthreads();
+  // sum of the (centred) reference: the fp32 rounding residue of its mean, see align_lane
+  double rs[3] = {0, 0, 0};
+  for (int b = 0; b < pp.n_align; ++b) {
+    const float4 r = ref4[b];
+    rs[0] += (double)r.x;
+    rs[1] += (double)r.y;
+    rs[2] += (double)r.z;
+  }
+  const double inv_n = fast_rcp((double)pp.n_align);
+  float* my = lds + lane * nc;
+  f2* my2 = reinterpret_cast<f2*>(my);
+  for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+    if (it == 2) CVF_STAMP(0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = i * CVF_WAVE + lane;
+      if (v < nvec) tile4[v] = pre[i];
+    }
+    if (it == 2) CVF_STAMP(1);
+    if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+    if (it == 2) CVF_STAMP(2);
+    // ---- centroid + covariance in one pass over d = x - (atom 0 of the frame): the differences are molecule-sized
+    // whatever the frame's distance from the origin, so fp32 products and sums (packed, two per instruction) carry
+    // the reference's own fp32 accuracy without the 3 N quarter-rate fp32 -> fp64 conversions of the fp64 pass.
+    // Register pairs follow the tile: [x y] [z x'] [y' z'] per atom pair.
+    const f2 P0 = my2[0];
+    const float pz = my[2];
+    const f2 P1 = f2{pz, P0.x}, P2 = f2{P0.y, pz};
+    f2 sA = {0, 0}, sB = {0, 0}, sC = {0, 0};
+    f2 H01[3] = {{0, 0}, {0, 0}, {0, 0}};   // H[i][0], H[i][1]
+    float H2[3] = {0, 0, 0};                // H[i][2]
+    auto acc = [&](float d0, float d1, float d2, const float4 r) {
+      const f2 r01 = f2{r.x, r.y};
+      H01[0] = fma2(splat2(d0), r01, H01[0]); H2[0] = fmaf(d0, r.z, H2[0]);
+      H01[1] = fma2(splat2(d1), r01, H01[1]); H2[1] = fmaf(d1, r.z, H2[1]);
+      H01[2] = fma2(splat2(d2), r01, H01[2]); H2[2] = fmaf(d2, r.z, H2[2]);
+    };
+    const int npa = pp.n_align >> 1;
+#pragma unroll 2
+    for (int m = 0; m < npa; ++m) {
+      const f2 d0 = my2[3 * m] - P0, d1 = my2[3 * m + 1] - P1, d2 = my2[3 * m + 2] - P2;
+      sA += d0; sB += d1; sC += d2;
+      acc(d0.x, d0.y, d1.x, ref4[2 * m]);
+      acc(d1.y, d2.x, d2.y, ref4[2 * m + 1]);
+    }
+    float sx = sA.x + sB.y, sy = sA.y + sC.x, sz = sB.x + sC.y;
+    if (pp.n_align & 1) {
+      const int a = pp.n_align - 1;
+      const float d0 = my[3 * a] - P0.x, d1 = my[3 * a + 1] - P0.y, d2 = my[3 * a + 2] - pz;
+      sx += d0; sy += d1; sz += d2;
+      acc(d0, d1, d2, ref4[a]);
+    }
+    // centroid relative to the pivot (fp64 -> fp32), absolute centroid for the aux rows
+    const double cr[3] = {(double)sx * inv_n, (double)sy * inv_n, (double)sz * inv_n};
+    const float cf[3] = {(float)cr[0], (float)cr[1], (float)cr[2]};
+    double H[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      H[i][0] = fma(-cr[i], rs[0], (double)H01[i].x);
+      H[i][1] = fma(-cr[i], rs[1], (double)H01[i].y);
+      H[i][2] = fma(-cr[i], rs[2], (double)H2[i]);
+    }
+    if (it == 2) CVF_STAMP(3);
+    KabschOut ko;
+#if defined(CVF_K1_EXP) && CVF_K1_EXP == 2
+    for (int i = 0; i < 9; ++i) ko.R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+    for (int i = 0; i < 6; ++i) ko.Kinv[i] = (float)H[i % 3][i / 3];
+#else
+    kabsch_from_H(H, ko);
+#endif
+    if (it == 2) CVF_STAMP(4);
+    if (aux_tiled) {
+      float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) ax[i * CVF_TILE] = ko.R[i];
+      ax[9 * CVF_TILE] = (float)((double)P0.x + cr[0]);
+      ax[10 * CVF_TILE] = (float)((double)P0.y + cr[1]);
+      ax[11 * CVF_TILE] = (float)((double)pz + cr[2]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ax[(12 + i) * CVF_TILE] = ko.Kinv[i];
+    }
+    if (it == 2) CVF_STAMP(5);
+    // ---- features: aligned positions of atoms 0 .. n_rec-1, (x - pivot) - (centroid - pivot) in two fp32 steps
+    float* ft = TILED ? feat_tiled + tile * pp.d_r * CVF_TILE + lane : nullptr;
+    const f2 C0 = f2{cf[0], cf[1]}, C1 = f2{cf[2], cf[0]}, C2 = f2{cf[1], cf[2]};
+    const f2 R01 = f2{ko.R[0], ko.R[1]}, R34 = f2{ko.R[3], ko.R[4]}, R67 = f2{ko.R[6], ko.R[7]};
+    auto rot_xy = [&](float a0, float a1, float a2) { return fma2(splat2(a0), R01, fma2(splat2(a1), R34, splat2(a2) * R67)); };
+    auto rot_z = [&](float a0, float a1, float a2) { return fmaf(a0, ko.R[2], fmaf(a1, ko.R[5], a2 * ko.R[8])); };
+    const int npr = pp.n_rec >> 1;
+#pragma unroll 2
+    for (int m = 0; m < npr; ++m) {
+      const f2 d0 = (my2[3 * m] - P0) - C0, d1 = (my2[3 * m + 1] - P1) - C1, d2 = (my2[3 * m + 2] - P2) - C2;
+      const f2 axy = rot_xy(d0.x, d0.y, d1.x), bxy = rot_xy(d1.y, d2.x, d2.y);
+      const float az = rot_z(d0.x, d0.y, d1.x), bz = rot_z(d1.y, d2.x, d2.y);
+#if defined(CVF_K1_EXP) && CVF_K1_EXP == 1
+      if (TILED && az == 1.2345e30f) {
+#else
+      if (TILED) {
+#endif
+        float* f = ft + 6 * m * CVF_TILE;
+        f[0] = axy.x; f[CVF_TILE] = axy.y; f[2 * CVF_TILE] = az;
+        f[3 * CVF_TILE] = bxy.x; f[4 * CVF_TILE] = bxy.y; f[5 * CVF_TILE] = bz;
+      }
+      if (ROWS) {
+        my2[3 * m] = axy;
+        my2[3 * m + 1] = f2{az, bxy.x};
+        my2[3 * m + 2] = f2{bxy.y, bz};
+      }
+    }
+    if (pp.n_rec & 1) {
+      const int a = pp.n_rec - 1;
+      const float d0 = (my[3 * a] - P0.x) - cf[0], d1 = (my[3 * a + 1] - P0.y) - cf[1], d2 = (my[3 * a + 2] - pz) - cf[2];
+      const f2 axy = rot_xy(d0, d1, d2);
+      const float az = rot_z(d0, d1, d2);
+      if (TILED) {
+        ft[3 * a * CVF_TILE] = axy.x; ft[(3 * a + 1) * CVF_TILE] = axy.y; ft[(3 * a + 2) * CVF_TILE] = az;
+      }
+      if (ROWS) {
+        my[3 * a] = axy.x; my[3 * a + 1] = axy.y; my[3 * a + 2] = az;
+      }
+    }
+    if (ROWS) {   // d_r == nc (host check): the tile of rows leaves as the coordinates came
+      float4* dst = reinterpret_cast<float4*>(feat_rows + tile * CVF_TILE * nc);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = i * CVF_WAVE + lane;
+        if (v < nvec) dst[v] = tile4[v];
+      }
+    }
+    if (it == 2) CVF_STAMP(6);
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // K1, fast layouts, small launches: FOUR lanes per frame (lane = 4 f + p; a wave covers 16 frames).
 // With one lane per frame a 20 000-frame batch is 313 waves on a chip with 1024 SIMDs and each wave walks all
 // N atoms three times: the kernel's time is one wave's serial latency.  Here lane p takes the atoms a = p (mod 4)
@@ -607,6 +783,39 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
     else if (feat_tiled) launchq(k1_align_quad_kernel<true, false>);
     else launchq(k1_align_quad_kernel<false, true>);
     return cvf_check_launch("k1_align_quad_kernel");
+  }
+  // large launches of the fast layout whose tile can sit in LDS as it lies in memory: persistent streaming waves
+  // over the whole tiles, the remainder (B mod 64 frames) below
+  static const bool no_stream = getenv("CVF_K1_NOSTREAM") != nullptr;
+  const int nc = pp->n_coord;
+  const int64_t T_full = B / CVF_TILE;
+  if (fast && !no_stream && nc % 4 == 2 && nc <= 4 * 26 && T_full > kSplitMaxTiles && (!feat_rows || pp->d_r == nc)) {
+    const size_t ldss = (size_t)CVF_TILE * nc * sizeof(float) + (size_t)pp->n_align * sizeof(float4);
+    auto launchs = [&](auto kernel) {
+      if (ldss > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss);
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, ldss) != hipSuccess || per_cu < 1) per_cu = 4;
+      const int64_t resident = (int64_t)per_cu * cvf_cu_count();
+      hipLaunchKernelGGL(kernel, dim3((unsigned)(T_full < resident ? T_full : resident)), dim3(64), ldss, s, *pp, x, T_full,
+                         feat_tiled, feat_rows, aux_tiled);
+    };
+    const int nv = (nc + 3) / 4;
+#define CVF_K1_STREAM(NV)                                                                \
+    do {                                                                                 \
+      if (feat_tiled && feat_rows) launchs(k1_stream_kernel<NV, true, true>);            \
+      else if (feat_tiled) launchs(k1_stream_kernel<NV, true, false>);                   \
+      else launchs(k1_stream_kernel<NV, false, true>);                                   \
+    } while (0)
+    if (nv <= 8) CVF_K1_STREAM(8);
+    else if (nv <= 17) CVF_K1_STREAM(17);
+    else CVF_K1_STREAM(26);
+#undef CVF_K1_STREAM
+    const int rc = cvf_check_launch("k1_stream_kernel");
+    const int64_t done = T_full * CVF_TILE;
+    if (rc || done == B) return rc;
+    return cvf_align_feature_fwd(pp, x + done * nc, B - done, feat_tiled ? feat_tiled + T_full * pp->d_r * CVF_TILE : nullptr,
+                                 feat_rows ? feat_rows + done * pp->d_r : nullptr,
+                                 aux_tiled ? aux_tiled + T_full * CVF_AUX_ROWS * CVF_TILE : nullptr, scratch, stream);
   }
   auto launch = [&](auto kernel) {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -84,6 +84,45 @@ def test_k1_rigid_motion_invariance_full_size(dev):
     assert float(f0.reshape(B, n_atoms, 3).sum(1).abs().max()) < 1e-4 * float(f0.abs().max()) * n_atoms
 
 
+@pytest.mark.parametrize("n_atoms,n_align,B", [(22, 22, 64 * 1100 + 37), (10, 7, 64 * 1030 + 5), (22, 22, 64 * 1025)])
+def test_k1_streaming_tiles_large_launch(dev, n_atoms, n_align, B):
+    """Launches of more than 1024 tiles take the persistent streaming kernel (whole tiles) + the remainder launch:
+    rows vs the oracle, tiled == rows bit for bit, rotation / centroid / K^-1 rows vs the small-launch kernel."""
+    from colvarsfinder import _hip
+    traj, _, ref = make_molecule_traj(n_atoms, B, seed=900 + n_atoms)
+    align = list(range(n_align))
+    spec = dict(align_idx=align, ref_pos=ref[align], features=[("position", tuple(range(n_atoms)))], use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    x = torch.tensor(traj, device=dev)
+    d_r, T = 3 * n_atoms, (B + 63) // 64
+    desc = layer.pp_desc()
+
+    def run(xs, n):
+        t = (n + 63) // 64
+        rows = torch.zeros(n, d_r, device=dev)
+        tiled = torch.zeros(t, d_r, 64, device=dev)
+        aux = torch.zeros(t, 18, 64, device=dev)
+        _hip.check(_hip.lib().cvf_align_feature_fwd(desc, _hip.ptr(xs), n, _hip.ptr(tiled), _hip.ptr(rows), _hip.ptr(aux), None,
+                                                    _hip.stream()), "cvf_align_feature_fwd")
+        return rows, tiled, aux
+
+    rows, tiled, aux = run(x, B)
+    assert torch.equal(tiled.permute(0, 2, 1).reshape(T * 64, d_r)[:B], rows)
+    assert torch.equal(layer(x), rows)                       # rows-only variant of the same kernel
+    # the same frames through launches of at most 1024 tiles (four-lanes-per-frame kernel): same arithmetic, other order
+    n0 = 64 * 700
+    rows0, _, aux0 = run(x[:n0].contiguous(), n0)
+    scale = float(rows.abs().max())
+    assert float((rows[:n0] - rows0).abs().max()) < 2e-6 * scale
+    a, a0 = aux[:700], aux0[:700]
+    assert float((a[:, :12] - a0[:, :12]).abs().max()) < 2e-6 * max(1.0, float(a0[:, 9:12].abs().max()))
+    assert float((a[:, 12:] - a0[:, 12:]).abs().max()) < 1e-5 * float(a0[:, 12:].abs().max())
+    sel = np.r_[0:200, B - 300:B]
+    torch.set_default_dtype(torch.float64)
+    want = oracle_layer(spec)(torch.tensor(traj[sel], dtype=torch.float64)).numpy()
+    np.testing.assert_allclose(rows.cpu().numpy()[sel], want, rtol=1e-5, atol=2e-6 * np.abs(want).max())
+
+
 def test_k1_identity_and_reference_frame(dev):
     n_atoms = 12
     _, _, ref = make_molecule_traj(n_atoms, 4, seed=3)

@@ -1,7 +1,7 @@
 // Developer tool (not part of the library): phase timing of k1_align_kernel<true, true, false> with s_memtime stamps and
 // event-timed throughput at config-3 shape.  Build+run on the GPU box:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCVF_STAMPS -Iinclude -Icolvars-finder_amd/csrc -Wno-pass-failed \
-//       tools/k1_probe.hip colvars-finder_amd/csrc/stats.hip colvars-finder_amd/csrc/k1_large.hip -o /tmp/k1_probe
+//       tools/k1_probe.hip colvars-finder_amd/csrc/stats.hip colvars-finder_amd/csrc/k1_large.hip colvars-finder_amd/csrc/metric_large.hip -o /tmp/k1_probe
 #include "../colvars-finder_amd/csrc/k1_align.hip"
 #include <cstdio>
 #include <random>
@@ -51,6 +51,22 @@ int main(int argc, char** argv) {
     (void)hipEventElapsedTime(&ms, e0, e1);
     const double us = 1e3 * ms / reps;
     printf("B=%lld: %.1f us/launch (back-to-back), %.0f GB/s algorithmic (532 B/frame)\n", (long long)B, us, 532.0 * B / us * 1e-3);
+    {   // features only (no rotation / centroid / K^-1 rows)
+      (void)hipEventRecord(e0, nullptr);
+      for (int it = 0; it < reps; ++it) cvf_align_feature_fwd(&pp, dx, B, dfeat, nullptr, nullptr, nullptr, nullptr);
+      (void)hipEventRecord(e1, nullptr);
+      (void)hipDeviceSynchronize();
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      printf("   features only: %.1f us/launch, %.0f GB/s algorithmic\n", 1e3 * ms / reps, 532.0 * B / (1e3 * ms / reps) * 1e-3);
+      (void)hipEventRecord(e0, nullptr);
+      for (int it = 0; it < reps; ++it) cvf_align_feature_fwd(&pp, dx, B, nullptr, dfeat, nullptr, nullptr, nullptr);
+      (void)hipEventRecord(e1, nullptr);
+      (void)hipDeviceSynchronize();
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      printf("   row-major features only: %.1f us/launch, %.0f GB/s algorithmic\n", 1e3 * ms / reps, 532.0 * B / (1e3 * ms / reps) * 1e-3);
+      cvf_align_feature_fwd(&pp, dx, B, dfeat, nullptr, daux, nullptr, nullptr);
+      (void)hipDeviceSynchronize();
+    }
     std::vector<unsigned long long> st(64 * 4096);
     (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
     const char* nm[7] = {"", "tile staged", "tables+barrier", "centroid+covariance", "rotation solve", "(align end)", "aux+features"};

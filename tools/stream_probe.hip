@@ -2,6 +2,7 @@
 // (sets the achievable ceiling for the align+feature kernel of large molecules).  hipcc -O3 --offload-arch=gfx950
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -110,6 +111,39 @@ __global__ __launch_bounds__(256) void transpose_kernel(const f4* __restrict__ x
   if (acc == 1.2345f) out[0] = acc;
 }
 
+// copy: the read:write = 1:1 mix of the small-molecule align+feature kernel (coordinates in, features out)
+template <int NLOAD, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void copy_kernel(const f4* __restrict__ x, f4* __restrict__ y, size_t n_vec) {
+  const size_t chunk = (size_t)256 * NLOAD;
+  for (size_t c = blockIdx.x; (c + 1) * chunk <= n_vec; c += gridDim.x) {
+    const f4* p = x + c * chunk + threadIdx.x;
+    f4* q = y + c * chunk + threadIdx.x;
+    f4 v[NLOAD];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) v[i] = NTL ? __builtin_nontemporal_load(p + 256 * i) : p[256 * i];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      if (NTS) __builtin_nontemporal_store(v[i], q + 256 * i);
+      else q[256 * i] = v[i];
+    }
+  }
+}
+template <int NLOAD, bool NTL, bool NTS>
+void run_copy(const f4* x, f4* y, size_t n_vec, int blocks, const char* tag) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((copy_kernel<NLOAD, NTL, NTS>), dim3(blocks), dim3(256), 0, 0, x, y, n_vec);
+  (void)hipEventRecord(e0, 0);
+  const int reps = 10;
+  for (int it = 0; it < reps; ++it) hipLaunchKernelGGL((copy_kernel<NLOAD, NTL, NTS>), dim3(blocks), dim3(256), 0, 0, x, y, n_vec);
+  (void)hipEventRecord(e1, 0);
+  (void)hipDeviceSynchronize();
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("copy %-22s %5zu MB blocks=%6d loads/thread=%2d  %7.0f GB/s (read + write)\n", tag, n_vec * 16 >> 20, blocks, NLOAD,
+         2.0 * n_vec * 16.0 * reps / (ms * 1e-3) * 1e-9);
+}
+
 template <int NLOAD, bool NT>
 void run(const f4* x, size_t n_vec, float* out, int blocks, const char* tag) {
   hipEvent_t e0, e1;
@@ -131,6 +165,22 @@ int main() {
   f4* x; float* out;
   (void)hipMalloc(&x, bytes); (void)hipMalloc(&out, 4);
   (void)hipMemset(x, 0, bytes);
+  {
+    f4* y;
+    (void)hipMalloc(&y, (size_t)3 << 30);
+    for (size_t mb : {264, 3072}) {
+      const size_t nv = (mb << 20) / 16;
+      run_copy<4, false, false>(x, y, nv, 256 * 8, "plain");
+      run_copy<8, false, false>(x, y, nv, 256 * 8, "plain");
+      run_copy<8, false, false>(x, y, nv, 256 * 16, "plain");
+      run_copy<8, true, false>(x, y, nv, 256 * 8, "nt load");
+      run_copy<8, false, true>(x, y, nv, 256 * 8, "nt store");
+      run_copy<8, true, true>(x, y, nv, 256 * 8, "nt load+store");
+      run_copy<16, true, true>(x, y, nv, 256 * 8, "nt load+store");
+    }
+    (void)hipFree(y);
+    if (getenv("COPY_ONLY")) return 0;
+  }
   const int grids[] = {256 * 8};
   for (int g : grids) {
     run<4, false>(x, n_vec, out, g, "plain");
