@@ -158,6 +158,16 @@ __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int64_t
 // ------------------------------------------------------------------------------------
 // 3x3 helpers (per lane, registers)
 // ------------------------------------------------------------------------------------
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not for its global
+// stores (__syncthreads() also drains vmcnt - with stores of a few KB per wave in flight that is 2-3 k cycles of a
+// kernel whose time is one wave's chain).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// two floats in a register pair: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 do two fp32 operations per instruction
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 struct V3 {
   float x, y, z;
 };

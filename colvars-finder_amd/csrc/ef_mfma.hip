@@ -629,27 +629,35 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
     CVF_STAMP(51);
     const float* my = lds + lane * stride;
     const int nw = nthreads >> 6;
-    double acc[15];
-#pragma unroll
-    for (int i = 0; i < 15; ++i) acc[i] = 0.0;
+    // centroid + covariance over d = x - (atom 0 of the frame), fp32 (as k1_stream_kernel: the differences are
+    // molecule-sized, packed products, no per-atom fp32 -> fp64 conversions); every wave over all align atoms -
+    // splitting them cost more in the exchange than it saved
+    const float p0 = my[0], p1 = my[1], p2 = my[2];
+    f2 H01[3] = {{0, 0}, {0, 0}, {0, 0}};
+    float H2[3] = {0, 0, 0}, sd[3] = {0, 0, 0};
 #pragma unroll 2
-    for (int b = 0; b < nal; ++b) {   // every wave over all align atoms: splitting them cost more in the exchange than it saved
-      const double x0 = (double)my[3 * b], x1 = (double)my[3 * b + 1], x2 = (double)my[3 * b + 2];
-      const double r0 = (double)refL[3 * b], r1 = (double)refL[3 * b + 1], r2 = (double)refL[3 * b + 2];
-      acc[0] += x0; acc[1] += x1; acc[2] += x2;
-      acc[3] = fma(x0, r0, acc[3]); acc[4] = fma(x0, r1, acc[4]); acc[5] = fma(x0, r2, acc[5]);
-      acc[6] = fma(x1, r0, acc[6]); acc[7] = fma(x1, r1, acc[7]); acc[8] = fma(x1, r2, acc[8]);
-      acc[9] = fma(x2, r0, acc[9]); acc[10] = fma(x2, r1, acc[10]); acc[11] = fma(x2, r2, acc[11]);
-      acc[12] += r0; acc[13] += r1; acc[14] += r2;
+    for (int b = 0; b < nal; ++b) {
+      const float d0 = my[3 * b] - p0, d1 = my[3 * b + 1] - p1, d2 = my[3 * b + 2] - p2;
+      const f2 r01 = f2{refL[3 * b], refL[3 * b + 1]};
+      const float r2 = refL[3 * b + 2];
+      sd[0] += d0; sd[1] += d1; sd[2] += d2;
+      H01[0] = fma2(splat2(d0), r01, H01[0]); H2[0] = fmaf(d0, r2, H2[0]);
+      H01[1] = fma2(splat2(d1), r01, H01[1]); H2[1] = fmaf(d1, r2, H2[1]);
+      H01[2] = fma2(splat2(d2), r01, H01[2]); H2[2] = fmaf(d2, r2, H2[2]);
     }
     CVF_STAMP(52);
     const double inv = fast_rcp((double)nal);
-    double cd[3] = {acc[0] * inv, acc[1] * inv, acc[2] * inv};
+    const double cr[3] = {(double)sd[0] * inv, (double)sd[1] * inv, (double)sd[2] * inv};
+    double cd[3] = {(double)p0 + cr[0], (double)p1 + cr[1], (double)p2 + cr[2]};
+    // (the term -(centroid - pivot) x sum(ref) is dropped: the reference is stored centred, its sum is the fp32
+    // rounding residue of its mean, and against a molecule-sized factor that is 1e-8 of H - below the fp32 sums)
     double Hm[3][3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) Hm[i][j] = fma(-cd[i], acc[12 + j], acc[3 + 3 * i + j]);
+    for (int i = 0; i < 3; ++i) {
+      Hm[i][0] = (double)H01[i].x;
+      Hm[i][1] = (double)H01[i].y;
+      Hm[i][2] = (double)H2[i];
+    }
     KabschOut ko;
     kabsch_from_H(Hm, ko);
     const Centre c = centre_of(cd);
@@ -676,7 +684,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
       ft[(3 * at + 1) * CVF_TILE] = al.y;
       ft[(3 * at + 2) * CVF_TILE] = al.z;
     }
-    __syncthreads();   // the feature image is complete
+    lds_barrier();   // the feature image is complete
     CVF_STAMP(54);
     in_lane = Ub + fo;
   }
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
 #pragma unroll
       for (int s = 0; s < NG; ++s) t0[rt][s] = pT0[((rt < CT ? rt : CT - 1) * NG + s) * 64 + lane];
     CVF_STAMP(58);
-    if constexpr (K1) __syncthreads();   // every wave has consumed the feature image: wave 0's g may replace it
+    if constexpr (K1) lds_barrier();   // every wave has consumed the feature image: wave 0's g may replace it
 #pragma unroll
     for (int rt = 0; rt < CTMAX; ++rt) {
       if (rt < CT) {  // wave-uniform
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
     }
   }
   CVF_STAMP(59);
-  __syncthreads();   // coordinate tile, tables and every net's y are in LDS; the g images are wave-private
+  lds_barrier();   // coordinate tile, tables and every net's y are in LDS; the g images are wave-private
   float yv[CVF_MAX_NETS];
 #pragma unroll
   for (int j = 0; j < CVF_MAX_NETS; ++j) yv[j] = yL[(j < k ? j : k - 1) * CVF_TILE + lane];

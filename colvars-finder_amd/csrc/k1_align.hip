@@ -186,10 +186,6 @@ __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const floa
 //  * the row-major output (ROWS) is written over the tile in LDS and leaves as it came, in 16-byte stores.
 // Frames past the last whole tile are left to k1_align_kernel.
 // ------------------------------------------------------------------------------------
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
 template <int NV, bool TILED, bool ROWS>
 __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t n_tiles,
                                                         float* __restrict__ feat_tiled, float* __restrict__ feat_rows,

@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
   pp.mode = CVF_PP_ALIGN; pp.n_coord = nc; pp.n_align = N; pp.n_rec = N; pp.d_r = nc; pp.has_position = 1;
   pp.flags = CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION;
   pp.align_idx = dal; pp.ref_c = dref; pp.rec = drec;
-  const int64_t sizes[3] = {20000, 100000, 1000000};
+  const int64_t sizes[6] = {20000, 100000, 150000, 250000, 500000, 1000000};
   for (int64_t B : sizes) {
     const int64_t T = (B + 63) / 64;
     std::vector<float> x((size_t)B * nc);
