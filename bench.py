@@ -200,7 +200,7 @@ def main():
         """HBM bytes per launch of the kernel behind a C-ABI call, from the committed rocprofv3 PMC passes."""
         kernel = {"cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
                   "cvf_ef_fwd_metric_stats": "ef_fwd_metric_kernel", "cvf_ef_align_fwd_metric_stats": "ef_fwd_metric_kernel",
-                  "cvf_align_feature_fwd": "k1_align_quad_kernel"}.get(call)
+                  "cvf_align_feature_fwd": "k1_align_quad_kernel", "cvf_align_feature_fwd@1M": "k1_stream_kernel"}.get(call)
         path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
         if kernel is None or not os.path.exists(path) or B != 20000 or args.workload != "c3":
             return None
@@ -219,27 +219,36 @@ def main():
         ach = K1_BYTES * B / (kern_ms[dom] * 1e-3) / 1e9
         roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                     traffic=pmc_traffic(dom), avg_launch_us=kern_ms[dom] * 1e3)
-    if "cvf_align_feature_fwd" in kern_ms:
-        k1, k1_note = kern_ms["cvf_align_feature_fwd"], "launch inside the step"
-    else:
-        # the step runs the alignment inside the fused launch: time the stand-alone kernel on the same batch
-        from colvarsfinder import _hip
-        lib, P = _hip.lib(), _hip.ptr
-        T_ = _hip.ntiles(B)
+    # The align+feature kernel alone.  Inside the step it is part of the fused launch (and at 20 000 frames any
+    # stand-alone launch is latency-bound), so its HBM roofline is taken where BASELINE.json's north star puts it: one
+    # launch over a 1 M-frame dipeptide trajectory resident in HBM (the shard repeated), HIP events per launch.
+    from colvarsfinder import _hip
+    lib, P = _hip.lib(), _hip.ptr
+
+    def time_k1(xs, n, with_aux, reps):
+        T_ = _hip.ntiles(n)
         f_tmp = torch.empty(T_ * 66 * 64, device=dev)
-        a_tmp = torch.empty(T_ * 18 * 64, device=dev)
+        a_tmp = torch.empty(T_ * 18 * 64, device=dev) if with_aux else None
         evs = []
-        for _ in range(30):
+        for _ in range(reps):
             torch.cuda._sleep(200_000)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            _hip.check(lib.cvf_align_feature_fwd(task._pp, P(X[:B]), B, P(f_tmp), None, P(a_tmp), None, _hip.stream()), "k1")
+            _hip.check(lib.cvf_align_feature_fwd(task._pp, P(xs), n, P(f_tmp), None, P(a_tmp), None, _hip.stream()), "k1")
             e1.record()
             evs.append((e0, e1))
         torch.cuda.synchronize()
-        k1 = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs[5:]]))
-        k1_note = "stand-alone launch on the step's batch (inside the step the alignment is part of the fused launch)"
-    k1_gbs = K1_BYTES * B / (k1 * 1e-3) / 1e9
+        return float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs[5:]]))
+
+    k1_step = kern_ms["cvf_align_feature_fwd"] if "cvf_align_feature_fwd" in kern_ms else time_k1(X[:B].contiguous(), B, True, 30)
+    N1M = 1_000_000
+    x1m = X.repeat((N1M + X.shape[0] - 1) // X.shape[0], 1, 1)[:N1M].contiguous()
+    k1 = time_k1(x1m, N1M, True, 25)
+    k1_feat_only = time_k1(x1m, N1M, False, 25)
+    del x1m
+    k1_note = ("one launch over 1 000 000 frames (22 atoms) resident in HBM, features + the rotation/centroid/K^-1 rows of "
+               "generator mode (72 B/frame that the 532 B/frame count leaves out); features_only = the same without those rows")
+    k1_gbs = K1_BYTES * N1M / (k1 * 1e-3) / 1e9
     out = {
         "metric": "MD frames/sec through EigenFunctionTask train step",
         "value": world * B * args.steps / elapsed,
@@ -259,9 +268,17 @@ def main():
                    "parallelism": f"dp{world} (frames sharded; all-reduce of batch sums + flat gradient)"},
         "roofline": roof,
         "roofline_align_feature": {"kernel": "cvf_align_feature_fwd", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("cvf_align_feature_fwd"),
+                                   "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("cvf_align_feature_fwd@1M"),
                                    "avg_launch_us": k1 * 1e3,
-                                   "bytes_per_frame": K1_BYTES, "frames_per_launch": B, "note": k1_note},
+                                   "bytes_per_frame": K1_BYTES, "frames_per_launch": N1M, "note": k1_note,
+                                   "features_only": {"avg_launch_us": k1_feat_only * 1e3,
+                                                     "achieved": K1_BYTES * N1M / (k1_feat_only * 1e-3) / 1e9,
+                                                     "frac": K1_BYTES * N1M / (k1_feat_only * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                   "copy_ceiling_note": "a plain 16-byte copy kernel (tools/stream_probe.hip, 3 GB) moves 5.5 TB/s "
+                                                        "read+write on this GPU: 1:1 read/write traffic cannot exceed ~69 % of 8 TB/s",
+                                   "at_step_batch": {"frames_per_launch": B, "avg_launch_us": k1_step * 1e3,
+                                                     "achieved": K1_BYTES * B / (k1_step * 1e-3) / 1e9,
+                                                     "traffic": pmc_traffic("cvf_align_feature_fwd")}},
         "kernel_avg_us": {n: v * 1e3 for n, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
         "kernel_timing": ("HIP events around each C-ABI call over a second, eager pass of the same steps (the timed region "
                           "replays one hipGraph per step)") if graphs else "HIP events around each C-ABI call in the timed region",

@@ -785,3 +785,331 @@ class AutoEncoderTask(TrainingTask):
                                           columns=['loss'])
         self.test_loss_df = pd.DataFrame(torch.cat([e[1].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
                                          columns=['loss'])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# RegAutoEncoderTask (core.py:746-1217)
+# ----------------------------------------------------------------------------------------------------------------------
+class _RegFlatParams:
+    """A :class:`RegAutoEncoder` as ONE chain over a flat fp32 buffer: the encoder's layers, then the decoder and
+    the K regulariser nets side by side.  Merged layer m maps ``[dec_m | reg_1,m | .. | reg_K,m]`` to the same of
+    m + 1 with a block-structured matrix (the first one: every block reads the whole latent vector), so the last
+    layer emits ``[reconstruction | y_1..y_K]`` and one pass of the chain kernel serves ``forward_ae`` and
+    ``forward_reg`` (nn.py:174-198).  Every module parameter aliases its block of the buffer (a strided view for the
+    block-diagonal layers); ``mask`` is 1 on real parameters, 0 on structural zeros and frozen (encoder) entries.
+    """
+
+    def __init__(self, model, device, freeze_encoder=False):
+        from .nn import _chain_layers
+        model.to(device=device, dtype=torch.float32)
+        enc, dec = _chain_layers(model.encoder), _chain_layers(model.decoder)
+        regs = [_chain_layers(r) for r in model.reg] if model.num_reg > 0 else []
+        K, Ld = len(regs), len(dec)
+        for r in regs:
+            if len(r) != Ld or any(ra != da for (_, ra), (_, da) in zip(r, dec)):
+                raise NotImplementedError("the MI355X path runs decoder and regulariser nets side by side: they must have the "
+                                          "same number of layers (as in the reference's notebooks)")
+            if r[-1][0].out_features != 1:
+                raise NotImplementedError("regulariser nets must be scalar-valued")
+        assert len(enc) + Ld <= _hip.MAX_LAYERS, f"at most {_hip.MAX_LAYERS} layers (encoder + decoder)"
+        # sizes
+        shapes = [(lin.out_features, lin.in_features, act) for lin, act in enc]
+        for m in range(Ld):
+            fin = dec[m][0].in_features if m == 0 else dec[m][0].in_features + sum(r[m][0].in_features for r in regs)
+            fout = dec[m][0].out_features + sum(r[m][0].out_features for r in regs)
+            shapes.append((fout, fin, dec[m][1]))
+        self.n = sum(fo * fi + fo for fo, fi, _ in shapes)
+        self.theta = torch.zeros(self.n, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.n, device=device, dtype=torch.float32)
+        self.mask = torch.zeros(self.n, device=device, dtype=torch.float32)
+        self.packed = None
+        self.K = K
+        d = _hip.MLPDesc()
+        d.n_nets, d.n_layers, d.n_params = 1, len(shapes), self.n
+        self.views = []   # (parameter, view of theta, view of grad)
+
+        def alias(p, region, r0, r1, c0=None, c1=None, frozen=False):
+            tv = region(self.theta)[r0:r1] if c0 is None else region(self.theta)[r0:r1, c0:c1]
+            gv = region(self.grad)[r0:r1] if c0 is None else region(self.grad)[r0:r1, c0:c1]
+            mv = region(self.mask)[r0:r1] if c0 is None else region(self.mask)[r0:r1, c0:c1]
+            tv.copy_(p.data)
+            mv.fill_(0.0 if frozen else 1.0)
+            p.data = tv
+            self.views.append((p, tv, gv))
+
+        pos = 0
+        for l, (fo, fi, act) in enumerate(shapes):
+            d.dims[l], d.dims[l + 1], d.act[l] = fi, fo, int(act)
+            d.w_off[0][l], d.b_off[0][l] = pos, pos + fo * fi
+            wreg = (lambda t, a=pos, fo=fo, fi=fi: t[a:a + fo * fi].view(fo, fi))
+            breg = (lambda t, a=pos + fo * fi, fo=fo: t[a:a + fo])
+            if l < len(enc):
+                lin = enc[l][0]
+                alias(lin.weight, wreg, 0, fo, 0, fi, frozen=freeze_encoder)
+                alias(lin.bias, breg, 0, fo, frozen=freeze_encoder)
+            else:
+                m = l - len(enc)
+                r0 = c0 = 0
+                for chain in [dec] + regs:
+                    lin = chain[m][0]
+                    cw = lin.in_features
+                    if m == 0:
+                        alias(lin.weight, wreg, r0, r0 + lin.out_features, 0, cw)       # every block reads the latent vector
+                    else:
+                        alias(lin.weight, wreg, r0, r0 + lin.out_features, c0, c0 + cw)
+                        c0 += cw
+                    alias(lin.bias, breg, r0, r0 + lin.out_features)
+                    r0 += lin.out_features
+            pos += fo * fi + fo
+        self.desc = d
+
+    def repack(self):
+        pass
+
+
+class RegAutoEncoderTask(TrainingTask):
+    """Regularised autoencoder (arguments, defaults and attributes as core.py:792-816).
+
+    Built on the MI355X path: the time-lagged reconstruction loss (``alpha``, ``lag_tau_ae``, core.py:883-885) and the
+    transfer-operator eigenfunction regulariser (``gamma``, ``lag_tau_reg > 0``, core.py:973-1036) - the configurations
+    of the reference's notebooks (2d.ipynb:743-760, main.ipynb:452-458) - with ``freeze_encoder``.  Not built (the
+    constructor raises ``NotImplementedError``): the generator-mode regulariser (``lag_tau_reg = 0`` with ``gamma``) and
+    the encoder regularisers ``eta`` (core.py:887-971).
+
+    A step is three launches + the reduction: ``cvf_regae_forward`` (one chain: encoder, then decoder and regulariser
+    nets side by side; y on the batch's frames and on their lagged partners, reconstruction error), ``cvf_ef_stats``
+    (batch sums, loss tail, d loss / d sum - the eigenfunction task's own kernel), ``cvf_regae_backward`` (forward
+    again, output gradients, parameter gradient on the matrix cores, fixed-order reduction, Adam).
+    """
+
+    def __init__(self, traj_obj, pp_layer, model, model_path, eig_weights=[], learning_rate=0.01, load_model_filename=None,
+                 save_model_every_step=10, batch_size=1000, num_epochs=10, test_ratio=0.2, optimizer_name='Adam', alpha=1.0,
+                 gamma=[0.0, 0.0], eta=[0.0, 0.0, 0.0], lag_tau_ae=0, lag_tau_reg=0, beta=1.0, device=torch.device('cuda'),
+                 plot_class=None, plot_frequency=0, freeze_encoder=False, verbose=True, debug_mode=True):
+        super().__init__(traj_obj, pp_layer, model, model_path, learning_rate, load_model_filename, save_model_every_step,
+                         model.encoded_dim, batch_size, num_epochs, test_ratio, optimizer_name, device, plot_class,
+                         plot_frequency, verbose, debug_mode)
+        assert isinstance(model, RegAutoEncoder), 'model must be an object of the class RegAutoEncoder'
+        assert model.num_reg == len(eig_weights), 'number of weights does not match the number of eigenfunctions!'
+        self.alpha, self.gamma, self.eta = alpha, gamma, eta
+        self.num_reg = model.num_reg
+        self._eps = 1e-5
+        self._eig_w = eig_weights
+        self._cvec = None
+        self.freeze_encoder = freeze_encoder
+        self.traj_dt = traj_obj.dt
+        lag_ae_idx, lag_idx = lag_tau_ae / self.traj_dt, lag_tau_reg / self.traj_dt
+        assert abs(lag_ae_idx - int(lag_ae_idx)) < 1e-6 and abs(lag_idx - int(lag_idx)) < 1e-6, \
+            f'lag-times ({lag_tau_ae}, {lag_tau_reg}) not divisable by the timestep {self.traj_dt} of the trajectory'
+        self.lag_ae_idx, self.lag_idx = int(lag_ae_idx), int(lag_idx)
+        self._use_reg = self.gamma[0] + self.gamma[1] > self._eps
+        if self._use_reg:
+            assert self.num_reg > 0, 'number of eigenfunctions must be positive!'
+            if self.lag_idx == 0:
+                raise NotImplementedError("RegAutoEncoderTask on MI355X: the generator-mode regulariser (lag_tau_reg = 0) is not "
+                                          "built; use lag_tau_reg > 0 (transfer operator) or EigenFunctionTask")
+            if self.gamma[0] <= self._eps:
+                raise NotImplementedError("RegAutoEncoderTask on MI355X: gamma[0] must be positive when gamma[1] is")
+            self._beta = beta
+        if max(self.eta) > self._eps:
+            raise NotImplementedError("RegAutoEncoderTask on MI355X: the encoder regularisers eta (core.py:887-971) are not built")
+        assert _dist.world() == 1, "RegAutoEncoderTask runs in one process per model in this round"
+        self.init_model_and_optimizer()
+        # --- data: the feature trajectory r(x) of every frame, once (the layer has no parameters), resident in HBM
+        traj = np.asarray(traj_obj.trajectory)
+        self.tot_dim = int(traj[0, ...].size)
+        self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
+        self._pp = self._pp_desc(self.tot_dim)
+        self._feature_traj = self._features(torch.as_tensor(traj))
+        d = self._flat.desc
+        assert self._pp.d_r == d.dims[0] and d.dims[d.n_layers] == d.dims[0] + self.num_reg, \
+            'encoder input / decoder output width must equal the feature dimension'
+        if self.verbose:
+            print('\nShape of trajectory data array:\n {}'.format(tuple(traj.shape)), flush=True)
+        cfg = _hip.EFCfg()
+        K = max(self.num_reg, 1)
+        cfg.k, cfg.lag_idx, cfg.sort_eigvals = K, max(self.lag_idx, 1), 1          # cvec = argsort always (core.py:1016)
+        cfg.alpha = float(self.gamma[1] / self.gamma[0]) if self._use_reg else 0.0  # gamma_0 (npl + gamma_1/gamma_0 pen)
+        cfg.beta, cfg.dt = float(beta), float(self.traj_dt)
+        for i in range(self.num_reg):
+            cfg.eig_w[i] = float(eig_weights[i])
+        self._cfg = cfg
+        self._ws = {}
+
+    # -- the base class builds the flat buffer from mlp_layout(); this model needs the side-by-side chain
+    def init_model_and_optimizer(self):
+        if self.load_model_filename:
+            if os.path.isfile(self.load_model_filename):
+                self.model.load_state_dict(torch.load(self.load_model_filename, map_location="cpu"), strict=False)
+                if self.verbose:
+                    print(f'model parameters loaded from: {self.load_model_filename}')
+            elif self.verbose:
+                print(f'model file not found: {self.load_model_filename}')
+        self._flat = _RegFlatParams(self.model, self.device, self.freeze_encoder)
+        self.optimizer = _FusedOptimizer(self._flat, self.optimizer_name, self.learning_rate)
+
+    def _features(self, X):
+        X = torch.as_tensor(X).detach().to(device=self.device, dtype=torch.float32).contiguous()
+        n = X.shape[0]
+        out = torch.empty(n, self._pp.d_r, device=self.device, dtype=torch.float32)
+        _hip.check(_hip.lib().cvf_align_feature_fwd(self._pp, _hip.ptr(X), n, None, _hip.ptr(out), None,
+                                                    _hip.ptr(_hip.align_scratch(self._pp, n, self.device)), _hip.stream()),
+                   "cvf_align_feature_fwd")
+        return out
+
+    def colvar_model(self):
+        """core.py:855-863."""
+        return torch.nn.Sequential(self.preprocessing_layer, self.model.encoder)
+
+    def reg_model(self):
+        """core.py:865-877."""
+        if self._cvec is None:
+            self._cvec = torch.arange(self.model.num_reg)
+        return torch.nn.Sequential(self.preprocessing_layer, RegModel(self.model, self._cvec))
+
+    def _workspace(self, B):
+        ws = self._ws.get(B)
+        if ws is None:
+            lib, K, dev = _hip.lib(), max(self.num_reg, 1), self.device
+            T = _hip.ntiles(B)
+            ws = dict(
+                scratch=torch.empty(lib.cvf_regae_scratch_floats(self._flat.desc, B), device=dev, dtype=torch.float32),
+                y=torch.zeros(2 * T * K * 64, device=dev, dtype=torch.float32),
+                out2=torch.zeros(2, device=dev, dtype=torch.float64),
+                stats=torch.zeros(lib.cvf_ef_nstats(K, 1), device=dev, dtype=torch.float64),
+                sscratch=torch.zeros(lib.cvf_ef_stats_scratch_doubles(K, 1), device=dev, dtype=torch.float64),
+                loss_vec=torch.zeros(3 + 2 * K, device=dev, dtype=torch.float64),
+                coef=torch.zeros(4 * K + K * K, device=dev, dtype=torch.float64), T=T)
+            self._ws[B] = ws
+        return ws
+
+    def _step(self, feat, idx, w, w_lag, lag_ae, lag_reg, with_grad, advance=False):
+        """Loss terms (and, with ``with_grad``, gradient + optimizer step) of one batch: rows ``idx`` of ``feat``
+        (``None``: rows 0..B-1), targets at ``+lag_ae``, lagged partners at ``+lag_reg``.
+        Returns the device vector [loss, ae, npl, pen, eig_1..K] (fp64)."""
+        lib, fl, P = _hip.lib(), self._flat, _hip.ptr
+        B, K = int(w.shape[0]), self.num_reg
+        ws = self._workspace(B)
+        use_reg = self._use_reg and K > 0
+        Kc = K if use_reg or K > 0 else 0
+        self._call("cvf_regae_forward", lib.cvf_regae_forward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
+                   lag_reg if use_reg else 0, Kc, P(w), P(ws["scratch"]), P(ws["y"]), P(ws["out2"]), _hip.stream())
+        if use_reg:
+            y_lag = ws["y"][ws["T"] * K * 64:]
+            self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws["y"]), None, P(w_lag), P(y_lag),
+                       P(ws["sscratch"]), P(ws["stats"]), P(ws["loss_vec"]), P(ws["coef"]), _hip.stream())
+        out = torch.zeros(4 + K, device=self.device, dtype=torch.float64)
+        out[1] = ws["out2"][0] / ws["out2"][1] if self.alpha > self._eps else 0.0
+        if use_reg:
+            out[2], out[3] = ws["loss_vec"][1], ws["loss_vec"][2]
+            out[4:4 + K] = ws["loss_vec"][3:3 + K]
+            self._cvec_dev = ws["loss_vec"][3 + K:3 + 2 * K]
+        out[0] = self.alpha * out[1] + self.gamma[0] * out[2] + self.gamma[1] * out[3]
+        if with_grad:
+            mse_scale = (float(self.alpha) / ws["out2"][1].item()) if self.alpha > self._eps else 0.0
+            adam = self.optimizer.fused_args() if advance else None
+            self._call("cvf_regae_backward", lib.cvf_regae_backward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
+                       lag_reg if use_reg else 0, Kc, P(w), P(w_lag) if use_reg else None, mse_scale,
+                       float(self.gamma[0]) if use_reg else 0.0, P(ws["y"]) if use_reg else None,
+                       P(ws["coef"]) if use_reg else None, P(ws["scratch"]), P(fl.grad), P(fl.mask),
+                       P(self.optimizer.step_count) if advance else None, adam, _hip.stream())
+            if advance and adam is None:
+                self.optimizer.step(advance=False)
+        return out
+
+    # -- the reference's public loss functions, evaluated on raw coordinate batches (forward values; the training
+    #    loop below uses the resident feature trajectory instead)
+    def _dev(self, t):
+        return torch.as_tensor(t).detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def weighted_MSE_loss(self, X, X_lagged, weight):
+        """core.py:879-885."""
+        B = int(torch.as_tensor(X).shape[0])
+        feat = torch.cat([self._features(X), self._features(X_lagged)])
+        w = self._dev(weight)
+        keep = (self.alpha, self._use_reg)
+        self.alpha, self._use_reg = 1.0, False
+        try:
+            out = self._step(feat, None, w, None, B, 0, with_grad=False)
+        finally:
+            self.alpha, self._use_reg = keep
+        return out[1].to(torch.get_default_dtype())
+
+    def reg_eigen_loss(self, X, weight, X_lagged, weight_lagged):
+        """core.py:973-1036 (transfer operator): ``(eig_vals, non_penalty_loss, penalty, cvec)``."""
+        assert self._use_reg, 'the regulariser is switched off (gamma = [0, 0])'
+        B = int(torch.as_tensor(X).shape[0])
+        feat = torch.cat([self._features(X), self._features(X_lagged)])
+        out = self._step(feat, None, self._dev(weight), self._dev(weight_lagged), 0, B, with_grad=False)
+        dt = torch.get_default_dtype()
+        cvec = self._cvec_dev.cpu().to(torch.long).numpy()
+        return out[4:].to(dt).cpu(), out[2].to(dt), out[3].to(dt), cvec
+
+    def backward(self):
+        """Fill ``p.grad`` of the module's parameters from the flat gradient of the last ``_step(..., with_grad=True)``."""
+        for p, _, gv in self._flat.views:
+            p.grad = gv.clone()
+
+    def reg_enc_grad_loss(self, X, weight):
+        raise NotImplementedError("encoder regularisers (eta) are not built on the MI355X path")
+
+    reg_enc_norm_loss = reg_enc_orthognal_loss = reg_enc_grad_loss
+
+    def train(self):
+        """core.py:1038-1217."""
+        n = self._feature_traj.shape[0]
+        ll = n - max(self.lag_idx, self.lag_ae_idx)                      # core.py:1042
+        idx_train, idx_test = _split(ll, self.test_ratio)                # core.py:1044 (one draw)
+        bs_train, bs_test = min(self.batch_size, len(idx_train)), min(self.batch_size, len(idx_test))
+        itr = torch.as_tensor(idx_train, device=self.device, dtype=torch.long)
+        ite = torch.as_tensor(idx_test, device=self.device, dtype=torch.long)
+        wtr, wte = self._weights[itr].contiguous(), self._weights[ite].contiguous()
+        wtr_lag, wte_lag = self._weights[itr + self.lag_idx].contiguous(), self._weights[ite + self.lag_idx].contiguous()
+        tr_batches = [(s, s + bs_train) for s in range(0, len(idx_train) - bs_train + 1, bs_train)] if bs_train > 0 else []
+        te_batches = [(s, s + bs_test) for s in range(0, len(idx_test) - bs_test + 1, bs_test)] if bs_test > 0 else []
+        self.loss_list = []
+        min_loss = float("inf")
+        print("\nTraining starts.\n%d epochs in total, batch sizes (train/test): %d/%d" % (self.num_epochs, bs_train, bs_test))
+        print("\nTrain set:\n\t%d data, %d iterations per epoch, %d iterations in total." %
+              (len(idx_train), len(tr_batches), len(tr_batches) * self.num_epochs), flush=True)
+        print("Test set:\n\t%d data, %d iterations per epoch, %d iterations in total." %
+              (len(idx_test), len(te_batches), len(te_batches) * self.num_epochs), flush=True)
+        K = self.num_reg
+        loss_names = ['loss', 'ae_loss', 'eigen_non_penalty', 'eigen_penalty'] + ['eig_%d' % i for i in range(K)] + \
+                     ['encoder_gradient', 'encoder_norm', 'encoder_orthogonality']
+        ncol = len(loss_names)
+        log_tr = torch.zeros(max(len(tr_batches), 1), ncol, device=self.device, dtype=torch.float64)
+        log_te = torch.zeros(max(len(te_batches), 1), ncol, device=self.device, dtype=torch.float64)
+        for epoch in _tqdm(range(self.num_epochs)):
+            self.model.train()
+            for it, (a, b) in enumerate(tr_batches):
+                log_tr[it, :4 + K] = self._step(self._feature_traj, itr[a:b], wtr[a:b], wtr_lag[a:b], self.lag_ae_idx,
+                                                self.lag_idx, with_grad=True, advance=True)
+            if self._use_reg and tr_batches:
+                self._cvec = self._cvec_dev.cpu().to(torch.long)
+            if self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1:
+                self.save_model(epoch)
+                last = float(log_tr[len(tr_batches) - 1, 0]) if tr_batches else float("inf")
+                if last < min_loss:
+                    min_loss = last
+                    self.save_model(epoch, 'best')
+            if self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1:
+                if self.plot_class is not None:
+                    self.plot_class.plot(self.colvar_model(), self.reg_model(), epoch=epoch)
+            for it, (a, b) in enumerate(te_batches):
+                log_te[it, :4 + K] = self._step(self._feature_traj, ite[a:b], wte[a:b], wte_lag[a:b], self.lag_ae_idx,
+                                                self.lag_idx, with_grad=False)
+            if self._use_reg and te_batches:
+                self._cvec = self._cvec_dev.cpu().to(torch.long)
+            dt = torch.get_default_dtype()
+            tr, te = log_tr[:len(tr_batches)].cpu().to(dt), log_te[:len(te_batches)].cpu().to(dt)
+            self.loss_list.append([tr, te])                                                       # core.py:1202
+            mean_tr = tr.mean(0) if len(tr) else torch.full((ncol,), float("nan"))
+            mean_te = te.mean(0) if len(te) else torch.full((ncol,), float("nan"))
+            for i, name in enumerate(loss_names):                                                 # core.py:1208-1212
+                self.writer.add_scalar('%s/train' % name, mean_tr[i], epoch)
+                self.writer.add_scalar('%s/test' % name, mean_te[i], epoch)
+        self.train_loss_df = pd.DataFrame(torch.cat([e[0].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
+                                          columns=loss_names)
+        self.test_loss_df = pd.DataFrame(torch.cat([e[1].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
+                                         columns=loss_names)

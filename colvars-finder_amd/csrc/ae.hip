@@ -62,133 +62,6 @@ __device__ __forceinline__ void dense_fwd(const float* __restrict__ W, const flo
   }
 }
 
-// out[i] = sum_o W[o][i] z[o]
-__device__ __forceinline__ void dense_bwd_data(const float* __restrict__ W, int din, int dout, const float* z, float* out,
-                                               int lane) {
-  for (int i0 = 0; i0 < din; i0 += 8) {
-    float acc[8];
-    int ci[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ci[j] = i0 + j < din ? i0 + j : din - 1;
-      acc[j] = 0.0f;
-    }
-    for (int o = 0; o < dout; ++o) {
-      const float zo = z[o * P + lane];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(W[o * din + ci[j]], zo, acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (i0 + j < din) out[(i0 + j) * P + lane] = acc[j];
-  }
-}
-
-__global__ __launch_bounds__(64) void ae_step_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
-                                                      const float* __restrict__ feat_rows,
-                                                      const int64_t* __restrict__ idx, int64_t B,
-                                                      const float* __restrict__ w, double inv_wsum, int with_grad,
-                                                      float* __restrict__ slab, double* __restrict__ partial,
-                                                      int32_t* __restrict__ step) {
-  extern __shared__ float lds[];
-  const int lane = threadIdx.x;
-  const int L = mlp.n_layers;
-  const int d0 = mlp.dims[0], dL = mlp.dims[L];
-  const AeLayout lay = ae_layout(mlp, with_grad != 0);
-  float* ZB = lds + lay.zb_off;
-  float* AB = lds + lay.ab_off;
-  float* GI = lds + lay.gi_off;
-  const int row16 = lane & 15, kq = lane >> 4;
-  // ones rows (bias columns) and a clean gradient image
-  for (int l = 0; l < L; ++l) {
-    float* a = lds + lay.act_off[l];
-    const int rows = up16(mlp.dims[l] + 1);
-    for (int r = mlp.dims[l]; r < rows; ++r) a[r * P + lane] = r == mlp.dims[l] ? 1.0f : 0.0f;
-  }
-  if (with_grad)
-    for (int p = lane; p < mlp.n_params; p += 64) GI[p] = 0.0f;
-  __syncthreads();
-  const int64_t T = (B + CVF_TILE - 1) / CVF_TILE;
-  double loss_acc = 0.0, w_acc = 0.0;
-  for (int64_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
-    const int64_t b = tile * CVF_TILE + lane;
-    const bool valid = b < B;
-    const int64_t bb = valid ? b : B - 1;
-    const int64_t frame = idx ? idx[bb] : bb;
-    const float wb = valid ? w[bb] : 0.0f;
-    const float* __restrict__ frow = feat_rows + frame * d0;
-    float* a0 = lds + lay.act_off[0];
-    for (int j = 0; j < d0; ++j) a0[j * P + lane] = frow[j];
-    // forward
-    for (int l = 0; l < L - 1; ++l)
-      dense_fwd(theta + mlp.w_off[0][l], theta + mlp.b_off[0][l], mlp.dims[l], mlp.dims[l + 1], lds + lay.act_off[l],
-                lds + lay.act_off[l + 1], mlp.act[l] != 0, lane);
-    dense_fwd(theta + mlp.w_off[0][L - 1], theta + mlp.b_off[0][L - 1], mlp.dims[L - 1], dL, lds + lay.act_off[L - 1], ZB,
-              mlp.act[L - 1] != 0, lane);
-    // weighted squared error and zbar_L = 2 w (out - f) / sum(w)     (core.py:666)
-    float err2 = 0.0f;
-    const float scale = (float)(2.0 * (double)wb * inv_wsum);
-    for (int j = 0; j < dL; ++j) {
-      const float out = ZB[j * P + lane];
-      const float df = out - a0[j * P + lane];
-      err2 = fmaf(df, df, err2);
-      float zb = scale * df;
-      if (mlp.act[L - 1]) zb *= 1.0f - out * out;
-      ZB[j * P + lane] = zb;
-    }
-    loss_acc += (double)wb * (double)err2;
-    w_acc += (double)wb;
-    if (!with_grad) continue;
-    // backward
-    for (int l = L - 1; l >= 0; --l) {
-      const int din = mlp.dims[l], dout = mlp.dims[l + 1];
-      const float* Ain = lds + lay.act_off[l];
-      const int wo = mlp.w_off[0][l], bo = mlp.b_off[0][l];
-      __syncthreads();
-      for (int rt = 0; rt * 16 < dout; ++rt)
-        for (int ct = 0; ct * 16 < din + 1; ++ct) {
-          f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-          for (int s = 0; s < 16; ++s)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ZB[(16 * rt + row16) * P + 4 * s + kq],
-                                                       Ain[(16 * ct + row16) * P + 4 * s + kq], acc, 0, 0, 0);
-          const int i = 16 * ct + row16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int o = 16 * rt + 4 * kq + r;
-            if (o < dout) {
-              if (i < din) GI[wo + o * din + i] += acc[r];
-              else if (i == din) GI[bo + o] += acc[r];
-            }
-          }
-        }
-      __syncthreads();
-      if (l > 0) {
-        dense_bwd_data(theta + wo, din, dout, ZB, AB, lane);
-        for (int i = 0; i < din; ++i) {
-          float v = AB[i * P + lane];
-          if (mlp.act[l - 1]) {
-            const float a = Ain[i * P + lane];
-            v *= 1.0f - a * a;
-          }
-          ZB[i * P + lane] = v;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const double ls = wave_sum(loss_acc), wsum = wave_sum(w_acc);
-  if (lane == 0) {
-    partial[2 * blockIdx.x] = ls;
-    partial[2 * blockIdx.x + 1] = wsum;
-  }
-  if (with_grad) {
-    float* out = slab + (int64_t)blockIdx.x * mlp.n_params;
-    for (int p = lane; p < mlp.n_params; p += 64) out[p] = GI[p];
-    if (step != nullptr && blockIdx.x == 0 && lane == 0) *step += 1;  // one gradient per optimiser step
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // The training step on the matrix cores.  Block = one 64-frame tile, four waves; wave v owns the frames 16 v .. 16 v + 15
 // (the N = 16 columns of v_mfma_f32_16x16x4_f32).  The activations a_1 .. a_{L-1} stay in LDS as [row][frame] images;
@@ -232,11 +105,30 @@ __host__ __device__ inline AeMLayout ae_mlayout(const cvf_mlp_desc& m) {
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// RegAutoEncoderTask (core.py:746-1217) runs the same chain with K extra outputs: the encoder, then the decoder and the
+// K regulariser nets side by side (block-structured layers built by the host), so the last layer yields
+// [reconstruction (n_mse = d_0 rows) | y_1..y_K].  Tiles 0..T-1 take the rows idx (+ reconstruction error against the rows
+// idx + lag_t: the time-lagged autoencoder), tiles T..2T-1 the rows idx + lag_in (the lagged arguments of the
+// transfer-operator loss, no reconstruction error).  The heads' output gradients are those of EigenFunctionTask's transfer
+// loss: coefficients from cvf_ef_loss, partner values from the forward pass's y_tiled.  K = 0: plain autoencoder.
+struct AeReg {
+  int K;                 // regulariser heads (last K outputs)
+  int write_y;           // forward pass: store the heads' outputs in y_tiled
+  int64_t T;             // tiles of the direct pass
+  int64_t n_tiles;       // T or 2 T
+  int64_t lag_t;         // reconstruction target row = idx + lag_t
+  int64_t lag_in;        // input rows of the second pass = idx + lag_in
+  double head_scale;     // gamma_0
+  const double* coef;    // [gS1(K), gS2(K*K), gT(K), gS1'(K), gS2'_ii(K)]  (CVF_COEF_LEN)
+  const float* w_lag;    // [B] weights of the lagged frames
+  float* y_tiled;        // [n_tiles][K][64]
+};
+
 __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                        const float* __restrict__ feat_rows, const int64_t* __restrict__ idx,
                                                        int64_t B, const float* __restrict__ w, double inv_wsum, int with_grad,
                                                        float* __restrict__ slab, double* __restrict__ partial,
-                                                       int32_t* __restrict__ step) {
+                                                       int32_t* __restrict__ step, AeReg reg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   CVF_STAMP(18);
@@ -279,18 +171,23 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
     if (tid < 64) lds[s_img[l] + s_dims[l] * AP + tid] = 1.0f;
   __syncthreads();
   CVF_STAMP(19);
-  const int64_t T = (B + CVF_TILE - 1) / CVF_TILE;
+  const int n_mse = dL - reg.K;   // reconstruction rows of the last layer
   double loss_acc = 0.0, w_acc = 0.0;
   float* out_row = slab + (int64_t)blockIdx.x * mlp.n_params;
-  for (int64_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
+  for (int64_t tile = blockIdx.x; tile < reg.n_tiles; tile += gridDim.x) {
     const bool first = tile == (int64_t)blockIdx.x;
+    const bool lagged = tile >= reg.T;            // second pass: rows idx + lag_in, heads only
+    const int64_t t0 = lagged ? tile - reg.T : tile;
+    const int64_t in_shift = lagged ? reg.lag_in : 0;
     // ---- this lane's frame (forward layout) and the tile's 64 frames (outer-product layout)
-    const int64_t b = tile * CVF_TILE + fcol;
+    const int64_t b = t0 * CVF_TILE + fcol;
     const bool valid = b < B;
     const int64_t bb = valid ? b : B - 1;
     const int64_t frame = idx ? idx[bb] : bb;
-    const float wb = valid ? w[bb] : 0.0f;
-    const float* __restrict__ frow = feat_rows + frame * d0;
+    const float wraw = valid ? w[bb] : 0.0f;
+    const float wb = lagged ? 0.0f : wraw;        // weight of the reconstruction error
+    const float* __restrict__ frow = feat_rows + (frame + in_shift) * d0;
+    const float* __restrict__ frow_t = feat_rows + (frame + reg.lag_t) * d0;
     CVF_STAMP(20);
     // ---- forward
     for (int l = 0; l < L; ++l) {
@@ -367,17 +264,46 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           const int o = 16 * (rt0 + (u >> 2)) + 4 * kq + (u & 3);
-          fv[u] = frow[o < dL ? o : dL - 1];
+          fv[u] = frow_t[o < n_mse ? o : n_mse - 1];
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           const int o = 16 * (rt0 + (u >> 2)) + 4 * kq + (u & 3);
-          if (o < dL) {
+          if (o < n_mse) {
             const float out = ZB[o * AP + fcol];
             const float df = out - fv[u];
             err2 = fmaf(df, df, err2);
             float zb = scale * df;
             if (act_last) zb *= 1.0f - out * out;
+            ZB[o * AP + fcol] = zb;
+          } else if (o < dL) {
+            // regulariser head i: output gradient of the transfer-operator loss (as ef_bwd_mfma_kernel, lag_idx > 0)
+            const int i = o - n_mse, K = reg.K;
+            const float out = ZB[o * AP + fcol];
+            if (reg.write_y) reg.y_tiled[(tile * K + i) * CVF_TILE + fcol] = out;
+            float zb = 0.0f;
+            if (with_grad && reg.coef != nullptr) {   // (no coefficients: the regulariser is switched off, gamma = 0)
+              const float* yb = reg.y_tiled + t0 * K * CVF_TILE + fcol;
+              const float* yl = reg.y_tiled + (reg.T + t0) * K * CVF_TILE + fcol;
+              const double* gS1 = reg.coef;
+              const double* gS2 = reg.coef + K;
+              const double* gT = reg.coef + K + K * K;
+              const double* gS1l = reg.coef + 2 * K + K * K;
+              const double* gS2l = reg.coef + 3 * K + K * K;
+              const double diff = (double)yl[i * CVF_TILE] - (double)yb[i * CVF_TILE];
+              const double tterm = 2.0 * (double)wraw * gT[i] * diff;
+              double g;
+              if (!lagged) {
+                double a = gS1[i];
+                for (int j = 0; j < K; ++j) a += (j == i ? 2.0 : 1.0) * gS2[i * K + j] * (double)yb[j * CVF_TILE];
+                g = (double)wraw * a - tterm;
+              } else {
+                const float wl = valid ? reg.w_lag[bb] : 0.0f;
+                g = (double)wl * (gS1l[i] + 2.0 * gS2l[i] * (double)yl[i * CVF_TILE]) + tterm;
+              }
+              zb = (float)(reg.head_scale * g);
+              if (act_last) zb *= 1.0f - out * out;
+            }
             ZB[o * AP + fcol] = zb;
           }
         }
@@ -401,9 +327,9 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
       if (l == 0) {
 #pragma unroll
         for (int jc = 0; jc < 16; ++jc) {
-          const int64_t fb = tile * CVF_TILE + 16 * (jc >> 2) + 4 * kq + (jc & 3);
+          const int64_t fb = t0 * CVF_TILE + 16 * (jc >> 2) + 4 * kq + (jc & 3);
           const int64_t fbc = fb < B ? fb : B - 1;
-          foff[jc] = (idx ? idx[fbc] : fbc) * d0;
+          foff[jc] = ((idx ? idx[fbc] : fbc) + in_shift) * d0;
         }
       }
       for (int pr = wv; pr < nrt * nct; pr += 4) {
@@ -539,22 +465,6 @@ __global__ __launch_bounds__(64) void ae_loss_sum_kernel(const double* __restric
   }
 }
 
-__global__ void ae_reduce_kernel(const float* __restrict__ slab, const double* __restrict__ partial, int nblocks, int Pn,
-                                 float* __restrict__ grad, double* __restrict__ out2, int use_adam, AdamDev adam) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (grad && p < Pn) {
-    float acc = 0.0f;
-    for (int g = 0; g < nblocks; ++g) acc += slab[(int64_t)g * Pn + p];
-    grad[p] = acc;
-    if (use_adam) adam_apply(adam, adam_scalars(adam), cvf_mlp_desc{}, p, acc);
-  }
-  if (p < 2) {
-    double acc = 0.0;
-    for (int g = 0; g < nblocks; ++g) acc += partial[2 * g + p];
-    out2[p] = acc;
-  }
-}
-
 // inference on row-major features: every net of the model, optionally stopping after `upto` layers
 __global__ __launch_bounds__(64) void mlp_eval_rows_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                             const float* __restrict__ feat_rows, int64_t B, int upto,
@@ -610,8 +520,10 @@ extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const fl
   double* partial = reinterpret_cast<double*>(scratch + (((int64_t)G * Pn + 1) & ~(int64_t)1));
   hipStream_t s = (hipStream_t)stream;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ae_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  AeReg none = {};
+  none.T = none.n_tiles = cvf_ntiles(B);
   hipLaunchKernelGGL(ae_mfma_kernel, dim3(G), dim3(256), lds, s, *mlp, theta, feat_rows, idx, B, w, inv_wsum, grad ? 1 : 0, slab,
-                     partial, grad ? step_count : nullptr);
+                     partial, grad ? step_count : nullptr, none);
   int rc = cvf_check_launch("ae_mfma_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(ae_loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, G, out2);
@@ -625,6 +537,87 @@ extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const fl
     ad.packed = nullptr;
   }
   return cvf_slab_reduce(slab, G, Pn, grad, adam != nullptr ? &ad : nullptr, stream);
+}
+
+// ---- RegAutoEncoderTask (time-lagged autoencoder + transfer-operator regulariser heads)
+static int regae_grid(int64_t n_tiles) { return (int)(n_tiles < kAeMaxBlocks ? n_tiles : kAeMaxBlocks); }
+
+extern "C" int64_t cvf_regae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B) {
+  const int64_t G = regae_grid(2 * cvf_ntiles(B));
+  return G * mlp->n_params + 4 * G + 4;
+}
+
+static int regae_launch(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx, int64_t B,
+                        const float* w, double mse_scale, bool with_grad, float* scratch, int32_t* step_count, AeReg reg,
+                        int* grid_out, hipStream_t s) {
+  CVF_REQUIRE(mlp->n_nets == 1 && mlp->n_layers >= 2 && mlp->n_layers <= CVF_MAX_LAYERS, "cvf_regae: one chain expected");
+  CVF_REQUIRE(reg.K >= 0 && reg.K <= CVF_MAX_NETS && mlp->dims[mlp->n_layers] == mlp->dims[0] + reg.K,
+              "cvf_regae: the chain must end in d_0 = %d reconstruction rows + K = %d heads (it has %d outputs)", mlp->dims[0],
+              reg.K, mlp->dims[mlp->n_layers]);
+  CVF_REQUIRE(reg.lag_t >= 0 && reg.lag_in >= 0 && (reg.coef == nullptr || reg.lag_in > 0),
+              "cvf_regae: the regulariser needs lag_input > 0 (transfer-operator loss; the generator loss is not built for this task)");
+  const AeMLayout lay = ae_mlayout(*mlp);
+  const size_t lds = (size_t)lay.total * sizeof(float);
+  CVF_REQUIRE(lds <= 160 * 1024, "cvf_regae: the chain needs %zu B of LDS per workgroup (> 160 KiB)", lds);
+  reg.T = cvf_ntiles(B);
+  reg.n_tiles = (reg.K > 0 && reg.lag_in > 0) ? 2 * reg.T : reg.T;
+  const int G = regae_grid(reg.n_tiles);
+  *grid_out = G;
+  float* slab = scratch;
+  double* partial = reinterpret_cast<double*>(scratch + (((int64_t)G * mlp->n_params + 1) & ~(int64_t)1));
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ae_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ae_mfma_kernel, dim3(G), dim3(256), lds, s, *mlp, theta, feat_rows, idx, B, w, mse_scale, with_grad ? 1 : 0, slab,
+                     partial, with_grad ? step_count : nullptr, reg);
+  return cvf_check_launch("ae_mfma_kernel");
+}
+
+extern "C" int cvf_regae_forward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
+                                 int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, float* scratch,
+                                 float* y_tiled, double* out2, void* stream) {
+  CVF_REQUIRE(mlp && theta && feat_rows && w && scratch && out2 && B > 0 && (K == 0 || y_tiled), "cvf_regae_forward: bad argument");
+  AeReg reg = {};
+  reg.K = K;
+  reg.write_y = K > 0;
+  reg.lag_t = lag_target;
+  reg.lag_in = lag_input;
+  reg.y_tiled = y_tiled;
+  int G = 0;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = regae_launch(mlp, theta, feat_rows, idx, B, w, 0.0, false, scratch, nullptr, reg, &G, s);
+  if (rc) return rc;
+  double* partial = reinterpret_cast<double*>(scratch + (((int64_t)G * mlp->n_params + 1) & ~(int64_t)1));
+  hipLaunchKernelGGL(ae_loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, G, out2);
+  return cvf_check_launch("ae_loss_sum_kernel");
+}
+
+int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
+                         const cvf_adam_args* adam, void* stream);
+
+extern "C" int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
+                                  int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, const float* w_lag,
+                                  double mse_scale, double head_scale, const float* y_tiled, const double* coef, float* scratch,
+                                  float* grad, const float* mask, int32_t* step_count, const cvf_adam_args* adam, void* stream) {
+  CVF_REQUIRE(mlp && theta && feat_rows && w && scratch && grad && B > 0, "cvf_regae_backward: bad argument");
+  CVF_REQUIRE(coef == nullptr || (K > 0 && w_lag && y_tiled), "cvf_regae_backward: the regulariser needs heads, w_lag and y_tiled");
+  CVF_REQUIRE(adam == nullptr || (adam->theta && adam->m && adam->v && adam->step_count), "cvf_regae_backward: incomplete adam arguments");
+  AeReg reg = {};
+  reg.K = K;
+  reg.lag_t = lag_target;
+  reg.lag_in = lag_input;
+  reg.head_scale = head_scale;
+  reg.coef = coef;
+  reg.w_lag = w_lag;
+  reg.y_tiled = const_cast<float*>(y_tiled);
+  int G = 0;
+  int rc = regae_launch(mlp, theta, feat_rows, idx, B, w, mse_scale, true, scratch, step_count, reg, &G, (hipStream_t)stream);
+  if (rc) return rc;
+  cvf_adam_args ad;
+  if (adam != nullptr) {
+    ad = *adam;
+    ad.mlp = nullptr;
+    ad.packed = nullptr;
+  }
+  return cvf_slab_reduce_impl(scratch, G, mlp->n_params, grad, mask, adam != nullptr ? &ad : nullptr, stream);
 }
 
 extern "C" int cvf_mlp_eval_rows(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, int64_t B,

@@ -1395,8 +1395,8 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
 // sub-sums in sequence -> bitwise reproducible without atomics.  With `adam` set (single-process runs:
 // no cross-rank reduction of the gradient in between) the same thread applies the Adam update.
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nrows, int P,
-                                                            float* __restrict__ grad, int use_adam, AdamDev adam,
-                                                            cvf_mlp_desc mlp) {
+                                                            float* __restrict__ grad, const float* __restrict__ mask,
+                                                            int use_adam, AdamDev adam, cvf_mlp_desc mlp) {
   __shared__ float sub[16][64];
   const int px = threadIdx.x, gy = threadIdx.y;
   const int p = blockIdx.x * 64 + px;
@@ -1415,6 +1415,7 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
     float s = 0.0f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) s += sub[t][px];
+    if (mask != nullptr) s *= mask[p];   // structural zeros of block-structured layers / frozen parameters
     grad[p] = s;
     if (use_adam) adam_apply(adam, adam_scalars(adam), mlp, p, s);
   }
@@ -1669,8 +1670,14 @@ extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, c
   return cvf_check_launch("ef_bwd_mfma_kernel");
 }
 
+int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
+                         const cvf_adam_args* adam, void* stream);
 extern "C" int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,
                                void* stream) {
+  return cvf_slab_reduce_impl(slab, n_rows, n_params, grad, nullptr, adam, stream);
+}
+int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
+                         const cvf_adam_args* adam, void* stream) {
   CVF_REQUIRE(slab && grad && n_rows > 0 && n_params > 0, "cvf_slab_reduce: bad argument");
   AdamDev ad{};
   cvf_mlp_desc md = {};
@@ -1683,6 +1690,6 @@ extern "C" int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_para
     if (adam->packed) md = *adam->mlp;
   }
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n_params + 63) / 64)), dim3(64, 16), 0, (hipStream_t)stream, slab,
-                     n_rows, (int)n_params, grad, adam != nullptr ? 1 : 0, ad, md);
+                     n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md);
   return cvf_check_launch("slab_reduce_kernel");
 }

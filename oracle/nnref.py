@@ -43,6 +43,16 @@ def init_autoencoder(e_dims, d_dims, generator=None, dtype=torch.float32):
     return sd
 
 
+def init_regautoencoder(e_dims, d_dims, r_dims, K, generator=None, dtype=torch.float32):
+    """``RegAutoEncoder`` (nn.py:116-198): ``encoder.`` / ``decoder.`` / ``reg.<i>.`` prefixes, in module order."""
+    assert e_dims[-1] == d_dims[0] and (K == 0 or e_dims[-1] == r_dims[0])
+    sd = init_sequential(e_dims, "encoder.", generator, dtype)
+    sd.update(init_sequential(d_dims, "decoder.", generator, dtype))
+    for i in range(K):
+        sd.update(init_sequential(r_dims, f"reg.{i}.", generator, dtype))
+    return sd
+
+
 def n_layers(sd, prefix):
     l = 0
     while f"{prefix}{l + 1}.weight" in sd:
@@ -84,3 +94,14 @@ def reorder_eigenfunctions(sd, cvec):
             if key.startswith(pre):
                 out[f"eigen_funcs.{j}." + key[len(pre):]] = val.clone()
     return out
+
+
+def regautoencoder_forward_ae(sd, x, activation=torch.tanh):
+    """``RegAutoEncoder.forward_ae`` (nn.py:164-172)."""
+    return sequential_forward(sd, "decoder.", sequential_forward(sd, "encoder.", x, activation), activation)
+
+
+def regautoencoder_forward_reg(sd, K, x, activation=torch.tanh):
+    """``RegAutoEncoder.forward_reg`` (nn.py:174-186)."""
+    z = sequential_forward(sd, "encoder.", x, activation)
+    return torch.cat([sequential_forward(sd, f"reg.{i}.", z, activation) for i in range(K)], dim=1)

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from tests import goldens
-from tests.synth import Traj, diag_coeff_for, make_molecule_traj, random_rotations
+from tests.synth import Traj, diag_coeff_for, make_2d_traj, make_molecule_traj, random_rotations
 
 pytestmark = pytest.mark.gpu
 
@@ -315,6 +315,94 @@ def _large_spec(n_atoms, rs):
         feats.append(("angle", (a0 + i, a0 + i + 1, a0 + i + 2)))
         feats.append(("bond", (a0, a0 + i + 1)))
     return feats
+
+
+@pytest.mark.parametrize("tag,rtol", [("f64", 5 * RTOL64), ("f32", RTOL32)])
+@pytest.mark.parametrize("name", goldens.REGAE_TRAIN_CASES)
+def test_regae_train_trace(dev, name, tag, rtol):
+    """RegAutoEncoderTask (core.py:746-1217): time-lagged reconstruction + transfer-operator regulariser.
+    Loss terms and every parameter gradient at the initial weights, then the training trace, against the reference."""
+    from colvarsfinder import core, nn
+    g = goldens.load(name, tag)
+    e_dims, d_dims, r_dims = ([int(d) for d in g[k_]] for k_ in ("e_dims", "d_dims", "r_dims"))
+    K, lag_ae, lag_reg, dt = int(g["K"]), int(g["lag_ae"]), int(g["lag_reg"]), float(g["dt"])
+    frozen = bool(g["freeze"])
+    model = nn.RegAutoEncoder(e_dims, d_dims, r_dims, K)
+    model.load_state_dict(goldens.state_dict(g, dtype=torch.float32))
+    traj = np.array(g["traj"])
+    layer = make_layer(goldens.pp_spec(g), traj.shape[1] if traj.ndim == 3 else 0, dev)
+    task = core.RegAutoEncoderTask(Traj(traj, np.array(g["w"]), dt), layer, model, "/tmp/cvf_test", eig_weights=[float(v) for v in g["eig_w"]],
+                                   learning_rate=float(g["lr"]), batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]),
+                                   alpha=float(g["alpha"]), gamma=[float(v) for v in g["gamma"]], lag_tau_ae=lag_ae * dt,
+                                   lag_tau_reg=lag_reg * dt, freeze_encoder=frozen, device=dev, verbose=False, save_model_every_step=0)
+    # the module's parameters alias the flat chain buffer (strided blocks for the side-by-side layers): values unchanged
+    for n, p in model.state_dict().items():
+        np.testing.assert_array_equal(p.cpu().numpy(), np.array(g["sd/" + n], dtype=np.float32), err_msg=n)
+    nb = int(g["kat_n"])
+    idx = torch.arange(nb, device=dev)
+    reg_last_bias = f".{len(r_dims) - 1}.bias"
+    out = task._step(task._feature_traj, idx, task._weights[:nb].contiguous(), task._weights[lag_reg:lag_reg + nb].contiguous(),
+                     lag_ae, lag_reg, with_grad=True).cpu().numpy()
+    task.backward()
+    # (the fp32 fixtures carry the reference's own cancellation noise in sum w (y' - y)^2: 1e-3 against its fp64 run here)
+    rtol_kat = rtol if tag == "f64" else 10 * rtol
+    np.testing.assert_allclose(out, g["kat"], rtol=rtol_kat)
+    np.testing.assert_array_equal(task._cvec_dev.cpu().numpy().astype(np.int64), g["kat_cvec"])
+    # absolute tolerance on the scale of the whole gradient (as for the loss_func fixtures above)
+    gmax = max(float(np.abs(g["grad/" + n]).max()) for n, _ in model.named_parameters())
+    g64 = goldens.load(name, "f64")
+    for n, p in model.named_parameters():
+        ref = g["grad/" + n]
+        if frozen and n.startswith("encoder."):
+            assert float(p.grad.abs().max()) == 0.0      # frozen parameters: masked gradient, no update
+            continue
+        if n.startswith("reg.") and n.endswith(reg_last_bias):
+            continue   # exact gradient 0 (shift invariance of the regulariser): rounding noise, as for EigenFunctionTask above
+        # fp32 fixture: allow the reference's own fp32 noise on this entry (its distance from its fp64 run - up to 15 % of
+        # the gradient for the cancellation-heavy second regulariser of the frozen-encoder fixture)
+        noise = 0.0 if tag == "f64" else 2.0 * float(np.abs(ref - g64["grad/" + n]).max())
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=20 * rtol, atol=20 * rtol * gmax + noise, err_msg=n)
+    # the public loss functions on raw coordinate batches (core.py:879-885, 973-1036)
+    X = torch.tensor(traj)
+    ae = task.weighted_MSE_loss(X[:nb], X[lag_ae:lag_ae + nb], task._weights[:nb])
+    eig, npl, pen, cvec = task.reg_eigen_loss(X[:nb], task._weights[:nb], X[lag_reg:lag_reg + nb], task._weights[lag_reg:lag_reg + nb])
+    np.testing.assert_allclose([float(ae), float(npl), float(pen)] + [float(e) for e in eig], g["kat"][1:], rtol=rtol_kat)
+    np.testing.assert_array_equal(np.asarray(cvec), g["kat_cvec"])
+    np.random.seed(int(g["seed"]))
+    task.train()
+    tr, te = np.stack([e[0].numpy() for e in task.loss_list]), np.stack([e[1].numpy() for e in task.loss_list])
+    if tag == "f32" and K > 1:
+        # With two regularisers the reference's own fp32 and fp64 traces part ways during training (the ordering of two
+        # close eigenvalues flips at different steps: up to 90 % apart in single steps of these fixtures), so the fp32
+        # fixture pins the first step only; the fp64 fixture (the exact answer) pins the whole trace.
+        first32, first64 = g["train_loss"][0, 0], g64["train_loss"][0, 0]
+        np.testing.assert_allclose(tr[0, 0], first32, rtol=rtol_kat, atol=rtol + 2.0 * np.abs(first32 - first64).max())
+        np.testing.assert_allclose(tr[0, 0], first64, rtol=rtol_kat, atol=rtol)     # ... and the exact first step
+        return
+    np.testing.assert_allclose(tr, g["train_loss"], rtol=rtol, atol=rtol)
+    np.testing.assert_allclose(te, g["test_loss"], rtol=rtol, atol=rtol)
+    for n, p in model.state_dict().items():
+        if n.startswith("reg.") and n.endswith(reg_last_bias):
+            continue   # Adam turns that bias's rounding-noise gradient into +-lr steps; it does not affect the loss
+        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=50 * rtol, atol=50 * rtol, err_msg=n)
+    np.testing.assert_array_equal(np.asarray(task._cvec), g["cvec"])
+    probe = torch.tensor(traj[:64], device=dev, dtype=torch.float32)
+    np.testing.assert_allclose(task.colvar_model()(probe).detach().cpu().numpy(), g["colvar_probe"], rtol=50 * rtol, atol=50 * rtol)
+    rp, rp_ref = task.reg_model()(probe).detach().cpu().numpy(), np.array(g["reg_probe"])
+    np.testing.assert_allclose(rp - rp.mean(0), rp_ref - rp_ref.mean(0), rtol=50 * rtol, atol=50 * rtol)   # (up to that bias)
+    assert list(task.train_loss_df.columns)[:4] == ['loss', 'ae_loss', 'eigen_non_penalty', 'eigen_penalty']
+
+
+def test_regae_unbuilt_options_fail_loudly(dev):
+    from colvarsfinder import core, nn
+    traj, w = make_2d_traj(200, seed=3)
+    model = nn.RegAutoEncoder([2, 8, 1], [1, 8, 2], [1, 8, 1], 1)
+    kw = dict(eig_weights=[1.0], device=dev, verbose=False)
+    with pytest.raises(NotImplementedError):   # generator-mode regulariser
+        core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), model, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0, **kw)
+    with pytest.raises(NotImplementedError):   # encoder regularisers
+        core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), model, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0.5,
+                                eta=[1.0, 0.0, 0.0], **kw)
 
 
 @pytest.mark.parametrize("n_atoms,B,contig", [(257, 70, True), (257, 33, False), (1200, 130, True)])

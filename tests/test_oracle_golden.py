@@ -132,6 +132,50 @@ def test_ae_train_trace(name, tag):
     np.testing.assert_allclose(cv, g["colvar_probe"], rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
 
 
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("name", goldens.REGAE_TRAIN_CASES)
+def test_regae_train_trace(name, tag):
+    """RegAutoEncoderTask (core.py:746-1217): loss terms + gradients at the initial weights, then the training trace."""
+    g = goldens.load(name, tag)
+    dtype = DT[tag]
+    torch.set_default_dtype(dtype)
+    sd0 = goldens.state_dict(g, dtype=dtype)
+    pp = build_pp(g)
+    K, lag_ae, lag_reg, dt = int(g["K"]), int(g["lag_ae"]), int(g["lag_reg"]), float(g["dt"])
+    alpha, gamma, eig_w = float(g["alpha"]), [float(v) for v in g["gamma"]], [float(v) for v in g["eig_w"]]
+    F = pp(torch.tensor(np.array(g["traj"])).to(dtype))
+    W = torch.tensor(np.array(g["w"])).to(dtype)
+    nb = int(g["kat_n"])
+    sd = {n: p.clone().requires_grad_(True) for n, p in sd0.items()}
+    ae = losses.regae_mse(sd, F[:nb], F[lag_ae:lag_ae + nb], W[:nb])
+    eig, npl, pen, cvec = losses.regae_eigen_loss(sd, K, F[:nb], W[:nb], F[lag_reg:lag_reg + nb], W[lag_reg:lag_reg + nb],
+                                                  eig_w=eig_w, lag_idx=lag_reg, dt=dt)
+    l0 = alpha * ae + gamma[0] * npl + gamma[1] * pen
+    l0.backward()
+    tol = TOL[tag]
+    got = np.asarray([float(l0), float(ae), float(npl), float(pen)] + [float(e) for e in eig])
+    np.testing.assert_allclose(got, g["kat"], **tol)
+    np.testing.assert_array_equal(np.asarray(cvec), g["kat_cvec"])
+    for n, p in sd.items():
+        np.testing.assert_allclose(p.grad.numpy(), g["grad/" + n], rtol=tol["rtol"] * 10, atol=tol["atol"] * 10, err_msg=n)
+    np.random.seed(int(g["seed"]))
+    res = train.train_regae(sd0, K, pp, np.array(g["traj"]), np.array(g["w"]), eig_w=eig_w, alpha=alpha, gamma=gamma,
+                            lag_ae_idx=lag_ae, lag_idx=lag_reg, dt=dt, learning_rate=float(g["lr"]),
+                            batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]), freeze_encoder=bool(g["freeze"]))
+    np.testing.assert_array_equal(res["train_idx"], g["train_idx"])
+    np.testing.assert_array_equal(res["test_idx"], g["test_idx"])
+    np.testing.assert_allclose(np.stack([e[0].numpy() for e in res["loss_list"]]), g["train_loss"], **tol)
+    np.testing.assert_allclose(np.stack([e[1].numpy() for e in res["loss_list"]]), g["test_loss"], **tol)
+    for n, p in res["state_dict"].items():
+        np.testing.assert_allclose(p.numpy(), g["final/" + n], rtol=tol["rtol"] * 10, atol=tol["atol"] * 10, err_msg=n)
+    np.testing.assert_array_equal(res["cvec"], g["cvec"])
+    probe = pp(torch.tensor(np.array(g["traj"])[:64]).to(dtype))
+    np.testing.assert_allclose(nnref.encoder_forward(res["state_dict"], probe).detach().numpy(), g["colvar_probe"],
+                               rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+    reg = nnref.regautoencoder_forward_reg(res["state_dict"], K, probe).detach().numpy()[:, np.asarray(g["cvec"])]
+    np.testing.assert_allclose(reg, g["reg_probe"], rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+
+
 def test_nn_structure():
     g = np.load(goldens.GOLDEN + "/nn_structure.npz")
     sd_ef = goldens.state_dict(g, "ef/")

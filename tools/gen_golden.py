@@ -14,6 +14,7 @@ Cases:
   G2  EigenFunctionTask.train traces (core.py:459-566)
   G3  AutoEncoderTask.train traces   (core.py:668-744)
   G4  colvarsfinder.nn structure     (nn.py:29-114,242-293)
+  G7  RegAutoEncoderTask.train traces (core.py:746-1217: time-lagged reconstruction + transfer-operator regulariser)
 Every case is emitted for torch default dtype float32 and float64 with identical
 initial weights (drawn in fp32, then cast).
 
@@ -244,6 +245,70 @@ def run_ae_train(core, rnn, name, case, e_dims, d_dims, dtype, lr, bs, epochs, s
     print(f"  {name}_{tag}: loss0={float(l0):.9g} last train {out['train_loss'][-1, -1]:.9g}")
 
 
+def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alpha, gamma, eig_w, lag_ae, lag_reg, dt, lr, bs,
+                    epochs, seed, freeze=False):
+    torch.set_default_dtype(dtype)
+    g = torch.Generator().manual_seed(seed)
+    sd0 = nnref.init_regautoencoder(e_dims, d_dims, r_dims, K, g, dtype)
+    model = rnn.RegAutoEncoder(e_dims, d_dims, r_dims, K)
+    model.load_state_dict(sd0)
+    pp = build_pp(case)
+    traj, w = case["traj"], case["w"]
+    with tempfile.TemporaryDirectory() as tmp:
+        task = core.RegAutoEncoderTask(Traj(traj, w, dt), pp, model, tmp, eig_weights=eig_w, learning_rate=lr, batch_size=bs,
+                                       num_epochs=epochs, test_ratio=0.2, alpha=alpha, gamma=gamma, eta=[0.0, 0.0, 0.0],
+                                       lag_tau_ae=lag_ae * dt, lag_tau_reg=lag_reg * dt, freeze_encoder=freeze, verbose=False,
+                                       save_model_every_step=0)
+        # known answer at the initial weights: the loss terms of the first 200 frames + all parameter gradients
+        nb = min(200, traj.shape[0] - max(lag_ae, lag_reg))
+        X, wb = task._traj[:nb], task._weights[:nb]
+        ae0 = task.weighted_MSE_loss(X, task._traj[lag_ae:lag_ae + nb], wb)
+        eig0, npl0, pen0, cvec0 = task.reg_eigen_loss(X, wb, task._traj[lag_reg:lag_reg + nb], task._weights[lag_reg:lag_reg + nb])
+        l0 = alpha * ae0 + gamma[0] * npl0 + gamma[1] * pen0
+        l0.backward()
+        grads0 = {f"grad/{n}": p.grad.detach().numpy().copy() for n, p in model.named_parameters()}
+        model.zero_grad(set_to_none=True)
+        np.random.seed(seed)
+        task.train()
+    np.random.seed(seed)
+    ll = traj.shape[0] - max(lag_ae, lag_reg)
+    n_test = int(np.ceil(0.2 * ll))
+    perm = np.random.permutation(ll)
+    probe = torch.tensor(traj[:64]).to(dtype)
+    out = dict(kind="regae_train", e_dims=np.asarray(e_dims), d_dims=np.asarray(d_dims), r_dims=np.asarray(r_dims), K=K, lr=lr,
+               batch_size=bs, num_epochs=epochs, seed=seed, alpha=alpha, gamma=np.asarray(gamma, dtype=np.float64),
+               eig_w=np.asarray(eig_w, dtype=np.float64), lag_ae=lag_ae, lag_reg=lag_reg, dt=dt, freeze=freeze, traj=traj, w=w,
+               train_idx=perm[n_test:], test_idx=perm[:n_test], kat_n=nb,
+               kat=np.asarray([float(l0), float(ae0), float(npl0), float(pen0)] + [float(e) for e in eig0]),
+               kat_cvec=np.asarray(cvec0),
+               train_loss=np.stack([e[0].numpy() for e in task.loss_list]),
+               test_loss=np.stack([e[1].numpy() for e in task.loss_list]),
+               cvec=np.asarray(task._cvec), colvar_probe=task.colvar_model()(probe).detach().numpy(),
+               reg_probe=task.reg_model()(probe).detach().numpy(),
+               train_loss_df=task.train_loss_df.to_numpy(), test_loss_df=task.test_loss_df.to_numpy())
+    out.update(sd_np(sd0))
+    out.update(grads0)
+    out.update({f"final/{n}": p.detach().numpy() for n, p in model.state_dict().items()})
+    out.update(pp_meta(case))
+    tag = "f32" if dtype == torch.float32 else "f64"
+    np.savez_compressed(os.path.join(OUT, f"{name}_{tag}.npz"), **out)
+    print(f"  {name}_{tag}: kat={out['kat'][:4]} last train {out['train_loss'][-1, -1, :4]}")
+
+
+def run_regae_cases(core, rnn, id2, mol10):
+    for dtype in (torch.float32, torch.float64):
+        # 2d.ipynb:743-760 shape: K = 1, both lags equal
+        run_regae_train(core, rnn, "train_regae_id2_k1", id2, [2, 20, 20, 20, 1], [1, 20, 20, 2], [1, 20, 20, 1], 1, dtype, 1.0,
+                        [1.0, 20.0], [1.0], 2, 2, 0.5, 5e-3, 100, 3, 701)
+        # main.ipynb:452-458 shape: K = 2, lag_tau_ae = 0
+        run_regae_train(core, rnn, "train_regae_mol10_k2", mol10, [30, 20, 20, 20, 2], [2, 10, 10, 30], [2, 10, 10, 1], 2, dtype, 1.0,
+                        [1.0, 10.0], [1.0, 0.5], 0, 1, 0.5, 2e-3, 64, 3, 702)
+        # frozen encoder, different lags, alpha != 1
+        run_regae_train(core, rnn, "train_regae_id2_k2_frozen", id2, [2, 12, 12, 2], [2, 12, 2], [2, 12, 1], 2, dtype, 0.5,
+                        [2.0, 8.0], [1.0, 0.3], 1, 3, 0.5, 5e-3, 100, 2, 703, freeze=True)
+    torch.set_default_dtype(torch.float32)
+
+
 def run_nn_structure(rnn):
     torch.set_default_dtype(torch.float32)
     ef = rnn.EigenFunctions([30, 20, 20, 20, 1], 3)
@@ -308,6 +373,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     core, rnn = import_reference()
     print("reference imported from", core.__file__)
+    if "--regae-only" in sys.argv:   # add the G7 cases without rewriting the other fixtures
+        t2, w2 = make_2d_traj(600, seed=11)
+        run_regae_cases(core, rnn, dict(pp="identity", traj=t2, w=w2), molecule_case(10, 300, seed=21))
+        return
     run_nn_structure(rnn)
     run_utils()
     if "--utils-only" in sys.argv:
@@ -337,6 +406,7 @@ def main():
         run_ae_train(core, rnn, "train_ae_id2", id2, [2, 20, 20, 20, 1], [1, 20, 20, 2], dtype, 5e-3, 100, 4, 301)
         run_ae_train(core, rnn, "train_ae_mol22", mol22, [66, 20, 20, 20, 2], [2, 10, 10, 66], dtype, 1e-3, 64, 3, 302)
     torch.set_default_dtype(torch.float32)
+    run_regae_cases(core, rnn, id2, mol10)
 
 
 if __name__ == "__main__":
