@@ -107,11 +107,13 @@ def main():
     ap.add_argument("--batch", type=int, default=20000, help="frames per GPU per step (reference notebook: 20000)")
     ap.add_argument("--frames", type=int, default=100000, help="frames per GPU shard (config 3: 100k)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 disables it)")
-    ap.add_argument("--workload", choices=["c3", "c5", "c2"], default="c3",
+    ap.add_argument("--workload", choices=["c3", "c5", "c2", "regae"], default="c3",
                     help="c3 = the benchmark line; c5 = config-5 shape, c2 = config-2 AutoEncoderTask (extra measurements)")
     args = ap.parse_args()
     if args.workload == "c5":
         return main_c5(args)
+    if args.workload == "regae":
+        return main_regae(args)
     if args.workload == "c2":
         return main_c2(args)
 
@@ -386,6 +388,52 @@ def main_c2(args):
         print(json.dumps({"workload": "config 2: AutoEncoderTask [66,20,20,20,2]/[2,10,10,66], 22 atoms, B=20000", "n_gpus": world,
                           "value": world * B * args.steps / elapsed, "unit": "frames/s", "ms_per_step": elapsed / args.steps * 1e3,
                           "final_loss": float(loss), "init_seconds_incl_feature_trajectory": t_init}))
+
+
+def main_regae(args):
+    """RegAutoEncoderTask at the dipeptide shape of main.ipynb:452-458 scaled to 22 atoms: encoder
+    [66,20,20,20,2], decoder [2,10,10,66], two regularisers [2,10,10,1], time-lagged reconstruction (lag 1 frame) +
+    transfer-operator regulariser (lag 1 frame), B = 20 000, one GPU.  Extra measurement, not the benchmark line."""
+    from colvarsfinder import core, nn, pp
+    from tests.synth import Traj
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    x, w, ref = make_shard(args.frames, 0)
+    torch.manual_seed(SEED)
+    model = nn.RegAutoEncoder([66, 20, 20, 20, 2], [2, 10, 10, 66], [2, 10, 10, 1], 2)
+    layer = pp.AlignFeatureLayer(N_ATOMS, list(range(N_ATOMS)), ref, [("position", tuple(range(N_ATOMS)))])
+    task = core.RegAutoEncoderTask(Traj(x, w, 1.0), layer, model, "/tmp/cvf_bench", eig_weights=[1.0, 0.5], learning_rate=LR,
+                                   batch_size=args.batch, alpha=1.0, gamma=[1.0, 10.0], lag_tau_ae=1.0, lag_tau_reg=1.0, device=dev,
+                                   verbose=False, save_model_every_step=0)
+    B = min(args.batch, args.frames - 1)
+    n_batches = (args.frames - 1) // B
+    idx = torch.arange(args.frames - 1, device=dev, dtype=torch.long)
+    Wt = task._weights
+    wl = Wt[1:].contiguous()
+    wsum = [float(Wt[b * B:(b + 1) * B].sum(dtype=torch.float64)) for b in range(n_batches)]
+    log = torch.zeros(n_batches, 4 + 2 + 3, device=dev, dtype=torch.float64)
+
+    def step(i):
+        b = i % n_batches
+        sl = slice(b * B, (b + 1) * B)
+        return task._step(task._feature_traj, idx[sl], Wt[sl], wl[sl], 1, 1, with_grad=True, advance=True, wsum=wsum[b], out=log[b])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        row = step(args.warmup + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    task._events = {}
+    for i in range(20):
+        step(i)
+    torch.cuda.synchronize()
+    kern = {n: float(np.mean([a.elapsed_time(b) for a, b in ev[3:]])) * 1e3 for n, ev in task._events.items()}
+    print(json.dumps({"workload": "RegAutoEncoderTask [66,20,20,20,2]/[2,10,10,66]/2x[2,10,10,1], 22 atoms, B=20000, lag 1/1", "n_gpus": 1,
+                      "value": B * args.steps / elapsed, "unit": "frames/s", "ms_per_step": elapsed / args.steps * 1e3,
+                      "call_avg_us": kern, "final_row": [float(v) for v in row.cpu()]}))
 
 
 if __name__ == "__main__":

@@ -983,33 +983,33 @@ class RegAutoEncoderTask(TrainingTask):
             self._ws[B] = ws
         return ws
 
-    def _step(self, feat, idx, w, w_lag, lag_ae, lag_reg, with_grad, advance=False):
+    def _step(self, feat, idx, w, w_lag, lag_ae, lag_reg, with_grad, advance=False, wsum=None, out=None):
         """Loss terms (and, with ``with_grad``, gradient + optimizer step) of one batch: rows ``idx`` of ``feat``
-        (``None``: rows 0..B-1), targets at ``+lag_ae``, lagged partners at ``+lag_reg``.
-        Returns the device vector [loss, ae, npl, pen, eig_1..K] (fp64)."""
+        (``None``: rows 0..B-1), targets at ``+lag_ae``, lagged partners at ``+lag_reg``.  ``wsum``: the batch's weight
+        sum when the caller knows it (static batches), else one host read.  Returns (or fills ``out`` with) the device
+        vector [loss, ae, npl, pen, eig_1..K] (fp64)."""
         lib, fl, P = _hip.lib(), self._flat, _hip.ptr
         B, K = int(w.shape[0]), self.num_reg
         ws = self._workspace(B)
         use_reg = self._use_reg and K > 0
-        Kc = K if use_reg or K > 0 else 0
+        alpha = float(self.alpha) if self.alpha > self._eps else 0.0
         self._call("cvf_regae_forward", lib.cvf_regae_forward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
-                   lag_reg if use_reg else 0, Kc, P(w), P(ws["scratch"]), P(ws["y"]), P(ws["out2"]), _hip.stream())
+                   lag_reg if use_reg else 0, K, P(w), P(ws["scratch"]), P(ws["y"]), P(ws["out2"]), _hip.stream())
         if use_reg:
             y_lag = ws["y"][ws["T"] * K * 64:]
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws["y"]), None, P(w_lag), P(y_lag),
                        P(ws["sscratch"]), P(ws["stats"]), P(ws["loss_vec"]), P(ws["coef"]), _hip.stream())
-        out = torch.zeros(4 + K, device=self.device, dtype=torch.float64)
-        out[1] = ws["out2"][0] / ws["out2"][1] if self.alpha > self._eps else 0.0
-        if use_reg:
-            out[2], out[3] = ws["loss_vec"][1], ws["loss_vec"][2]
-            out[4:4 + K] = ws["loss_vec"][3:3 + K]
             self._cvec_dev = ws["loss_vec"][3 + K:3 + 2 * K]
-        out[0] = self.alpha * out[1] + self.gamma[0] * out[2] + self.gamma[1] * out[3]
+        if out is None:
+            out = torch.zeros(4 + K, device=self.device, dtype=torch.float64)
+        self._call("cvf_regae_loss_row", lib.cvf_regae_loss_row, P(ws["out2"]), P(ws["loss_vec"]) if use_reg else None, alpha,
+                   float(self.gamma[0]) if use_reg else 0.0, float(self.gamma[1]) if use_reg else 0.0, K, P(out), _hip.stream())
         if with_grad:
-            mse_scale = (float(self.alpha) / ws["out2"][1].item()) if self.alpha > self._eps else 0.0
+            if wsum is None:
+                wsum = float(w.sum(dtype=torch.float64))
             adam = self.optimizer.fused_args() if advance else None
             self._call("cvf_regae_backward", lib.cvf_regae_backward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
-                       lag_reg if use_reg else 0, Kc, P(w), P(w_lag) if use_reg else None, mse_scale,
+                       lag_reg if use_reg else 0, K, P(w), P(w_lag) if use_reg else None, alpha / wsum,
                        float(self.gamma[0]) if use_reg else 0.0, P(ws["y"]) if use_reg else None,
                        P(ws["coef"]) if use_reg else None, P(ws["scratch"]), P(fl.grad), P(fl.mask),
                        P(self.optimizer.step_count) if advance else None, adam, _hip.stream())
@@ -1067,6 +1067,8 @@ class RegAutoEncoderTask(TrainingTask):
         wtr_lag, wte_lag = self._weights[itr + self.lag_idx].contiguous(), self._weights[ite + self.lag_idx].contiguous()
         tr_batches = [(s, s + bs_train) for s in range(0, len(idx_train) - bs_train + 1, bs_train)] if bs_train > 0 else []
         te_batches = [(s, s + bs_test) for s in range(0, len(idx_test) - bs_test + 1, bs_test)] if bs_test > 0 else []
+        # batches are static (shuffle=False): their weight sums are known before the first step
+        wsum_tr = [float(wtr[a:b].sum(dtype=torch.float64)) for a, b in tr_batches]
         self.loss_list = []
         min_loss = float("inf")
         print("\nTraining starts.\n%d epochs in total, batch sizes (train/test): %d/%d" % (self.num_epochs, bs_train, bs_test))
@@ -1083,8 +1085,8 @@ class RegAutoEncoderTask(TrainingTask):
         for epoch in _tqdm(range(self.num_epochs)):
             self.model.train()
             for it, (a, b) in enumerate(tr_batches):
-                log_tr[it, :4 + K] = self._step(self._feature_traj, itr[a:b], wtr[a:b], wtr_lag[a:b], self.lag_ae_idx,
-                                                self.lag_idx, with_grad=True, advance=True)
+                self._step(self._feature_traj, itr[a:b], wtr[a:b], wtr_lag[a:b], self.lag_ae_idx, self.lag_idx, with_grad=True,
+                           advance=True, wsum=wsum_tr[it], out=log_tr[it])
             if self._use_reg and tr_batches:
                 self._cvec = self._cvec_dev.cpu().to(torch.long)
             if self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1:
@@ -1097,8 +1099,8 @@ class RegAutoEncoderTask(TrainingTask):
                 if self.plot_class is not None:
                     self.plot_class.plot(self.colvar_model(), self.reg_model(), epoch=epoch)
             for it, (a, b) in enumerate(te_batches):
-                log_te[it, :4 + K] = self._step(self._feature_traj, ite[a:b], wte[a:b], wte_lag[a:b], self.lag_ae_idx,
-                                                self.lag_idx, with_grad=False)
+                self._step(self._feature_traj, ite[a:b], wte[a:b], wte_lag[a:b], self.lag_ae_idx, self.lag_idx, with_grad=False,
+                           out=log_te[it])
             if self._use_reg and te_batches:
                 self._cvec = self._cvec_dev.cpu().to(torch.long)
             dt = torch.get_default_dtype()

@@ -620,6 +620,26 @@ extern "C" int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, c
   return cvf_slab_reduce_impl(scratch, G, mlp->n_params, grad, mask, adam != nullptr ? &ad : nullptr, stream);
 }
 
+// row of RegAutoEncoderTask's loss list (core.py:1112-1124): [loss, ae, npl, pen, eig_1..K]
+__global__ void regae_loss_row_kernel(const double* __restrict__ out2, const double* __restrict__ loss_vec, double alpha, double g0,
+                                      double g1, int K, double* __restrict__ row) {
+  if (threadIdx.x != 0) return;
+  const double ae = alpha != 0.0 ? out2[0] / out2[1] : 0.0;
+  const double npl = loss_vec ? loss_vec[1] : 0.0, pen = loss_vec ? loss_vec[2] : 0.0;
+  row[0] = alpha * ae + g0 * npl + g1 * pen;
+  row[1] = ae;
+  row[2] = npl;
+  row[3] = pen;
+  for (int i = 0; i < K; ++i) row[4 + i] = loss_vec ? loss_vec[3 + i] : 0.0;
+}
+
+extern "C" int cvf_regae_loss_row(const double* out2, const double* loss_vec, double alpha, double gamma0, double gamma1, int K,
+                                  double* row, void* stream) {
+  CVF_REQUIRE(out2 && row && K >= 0 && K <= CVF_MAX_NETS, "cvf_regae_loss_row: bad argument");
+  hipLaunchKernelGGL(regae_loss_row_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out2, loss_vec, alpha, gamma0, gamma1, K, row);
+  return cvf_check_launch("regae_loss_row_kernel");
+}
+
 extern "C" int cvf_mlp_eval_rows(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, int64_t B,
                                  int upto_layer, float* out, void* stream) {
   CVF_REQUIRE(mlp && theta && feat_rows && out && B > 0, "cvf_mlp_eval_rows: bad argument");

@@ -255,6 +255,11 @@ int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, const float*
                        double head_scale, const float* y_tiled, const double* coef, float* scratch, float* grad,
                        const float* mask, int32_t* step_count, const cvf_adam_args* adam, void* stream);
 
+/* row [4 + K] of the task's loss list (core.py:1112-1124): [alpha ae + gamma_0 npl + gamma_1 pen, ae, npl, pen, eig_1..K]
+ * from out2 (cvf_regae_forward) and loss_vec (cvf_ef_stats; NULL: regulariser off); alpha = 0 leaves ae = 0 (core.py:1090). */
+int cvf_regae_loss_row(const double* out2, const double* loss_vec, double alpha, double gamma0, double gamma1, int K,
+                       double* row, void* stream);
+
 /* --- nets forward on row-major features (inference: colvar_model(), core.py:372-382,
  * 640-647).  out [B][n_out] where n_out = n_nets * d_L; upto_layer < n_layers stops a
  * single chain early (AutoEncoder encoder). */
