@@ -1400,15 +1400,22 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
   __shared__ float sub[16][64];
   const int px = threadIdx.x, gy = threadIdx.y;
   const int p = blockIdx.x * 64 + px;
-  float acc0 = 0.0f, acc1 = 0.0f;
+  // eight independent loads in flight per thread (two left every thread with ~10 dependent round trips at 313 rows);
+  // rows past the end re-read the last row of the group with weight 0: no branch around the loads
+  float a8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   if (p < P) {
-    int64_t g = gy;
-    for (; g + 16 < nrows; g += 32) {   // two independent loads in flight
-      acc0 += slab[g * P + p];
-      acc1 += slab[(g + 16) * P + p];
+    for (int64_t g0 = gy; g0 < nrows; g0 += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t g = g0 + 16 * u;
+        v[u] = slab[(g < nrows ? g : g0) * P + p];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += (g0 + 16 * u < nrows) ? v[u] : 0.0f;
     }
-    if (g < nrows) acc0 += slab[g * P + p];
   }
+  const float acc0 = (a8[0] + a8[1]) + (a8[2] + a8[3]), acc1 = (a8[4] + a8[5]) + (a8[6] + a8[7]);
   sub[gy][px] = acc0 + acc1;
   __syncthreads();
   if (gy == 0 && p < P) {
