@@ -81,10 +81,14 @@ constexpr int kAeMaxBlocks = 2048;
 
 struct AeMLayout {
   int img_off[CVF_MAX_LAYERS + 1];   // dword offset of image a_l, l = 1..L-1 (rows d_l + 1, the last one all ones)
-  int zb_off, ab_off, w_off, total;
+  int zb_off, ab_off, w_off, tail_off, total;
   int zb_rows, ab_rows;
 };
-__host__ __device__ inline AeMLayout ae_mlayout(const cvf_mlp_desc& m) {
+// Operand tiles read up to 15 rows past an image / past zbar: those rows belong to the next region (next image, zbar, the
+// second zbar buffer, the weights), which always holds finite numbers (everything is zeroed once, then activations and
+// weights), and they meet A values forced to 0 or land in output rows that are discarded - no padding rows needed.
+// The forward-only pass (test loop, RegAutoEncoderTask's statistics pass) has no second zbar buffer.
+__host__ __device__ inline AeMLayout ae_mlayout(const cvf_mlp_desc& m, bool with_grad) {
   AeMLayout lay;
   int rows = 0, dh = 1, dall = 1;
   for (int l = 1; l < m.n_layers; ++l) {
@@ -92,14 +96,16 @@ __host__ __device__ inline AeMLayout ae_mlayout(const cvf_mlp_desc& m) {
     rows += m.dims[l] + 1;
     dh = m.dims[l] > dh ? m.dims[l] : dh;
   }
-  rows += 16;   // an operand tile may read up to 15 rows past the last image: keep them inside the zeroed area
   for (int l = 1; l <= m.n_layers; ++l) dall = m.dims[l] > dall ? m.dims[l] : dall;
-  lay.zb_rows = up16(dall) + 16;
-  lay.ab_rows = up16(dh) + 16;
+  lay.zb_rows = up16(dall);
+  lay.ab_rows = with_grad ? up16(dh) : 0;
   lay.zb_off = rows * AP;
   lay.ab_off = lay.zb_off + lay.zb_rows * AP;
   lay.w_off = lay.ab_off + lay.ab_rows * AP;
-  lay.total = lay.w_off + ((m.n_params + 3) & ~3);
+  // batches of k-steps read up to 31 rows past zbar: when theta is shorter than that, a zeroed tail keeps them finite
+  const int np4 = (m.n_params + 3) & ~3;
+  lay.tail_off = lay.w_off + np4;
+  lay.total = lay.tail_off + (np4 < 32 * AP ? 32 * AP - np4 : 0);
   return lay;
 }
 
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
   // (scratch-memory) copy and a ~700-cycle round trip per access; a copy in LDS costs an LDS read.
   __shared__ int s_dims[CVF_MAX_LAYERS + 1], s_woff[CVF_MAX_LAYERS], s_boff[CVF_MAX_LAYERS], s_act[CVF_MAX_LAYERS];
   __shared__ int s_img[CVF_MAX_LAYERS + 1];
-  const AeMLayout lay = ae_mlayout(mlp);
+  const AeMLayout lay = ae_mlayout(mlp, with_grad != 0);
   if (tid == 0) {
 #pragma unroll
     for (int i = 0; i <= CVF_MAX_LAYERS; ++i) {
@@ -163,6 +169,7 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
     float4* l4 = reinterpret_cast<float4*>(lds);
     const float4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = tid; i < lay.w_off / 4; i += 256) l4[i] = z4;   // (every region is a multiple of AP = 68 dwords)
+    for (int i = lay.tail_off / 4 + tid; i < lay.total / 4; i += 256) l4[i] = z4;
 #pragma unroll 4
     for (int i = tid; i < mlp.n_params; i += 256) WL[i] = theta[i];
   }
@@ -510,7 +517,7 @@ extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const fl
               mlp->dims[mlp->n_layers], mlp->dims[0]);
   CVF_REQUIRE(adam == nullptr || (grad && adam->theta && adam->m && adam->v && adam->step_count),
               "cvf_ae_step: incomplete adam arguments");
-  const AeMLayout lay = ae_mlayout(*mlp);
+  const AeMLayout lay = ae_mlayout(*mlp, grad != nullptr);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CVF_REQUIRE(lds <= 160 * 1024, "cvf_ae_step: the chain needs %zu B of LDS per workgroup (> 160 KiB)", lds);
   const int G = ae_grid(B);
@@ -556,7 +563,7 @@ static int regae_launch(const cvf_mlp_desc* mlp, const float* theta, const float
               reg.K, mlp->dims[mlp->n_layers]);
   CVF_REQUIRE(reg.lag_t >= 0 && reg.lag_in >= 0 && (reg.coef == nullptr || reg.lag_in > 0),
               "cvf_regae: the regulariser needs lag_input > 0 (transfer-operator loss; the generator loss is not built for this task)");
-  const AeMLayout lay = ae_mlayout(*mlp);
+  const AeMLayout lay = ae_mlayout(*mlp, with_grad);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CVF_REQUIRE(lds <= 160 * 1024, "cvf_regae: the chain needs %zu B of LDS per workgroup (> 160 KiB)", lds);
   reg.T = cvf_ntiles(B);
