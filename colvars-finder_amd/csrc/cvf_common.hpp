@@ -97,7 +97,10 @@ static __device__ unsigned long long g_stamps[64 * 4096];
 // conflict-free.  Global reads are coalesced (the tile is one contiguous 64*nc*4 B run).
 // Frames past B replicate frame B-1 (their weight is forced to 0 by the callers).
 // ------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ int x_tile_stride(int nc) { return nc | 1; }
+// nc = 2 (mod 4): stride nc itself - lane l's row starts at bank 2 l (mod 64), distinct over each 32-lane half (the unit
+// in which ds_read_b32 / ds_read_b64 are serviced), and the tile is then a plain copy of memory (16-byte LDS writes, no
+// index arithmetic); otherwise the next odd number.
+__host__ __device__ __forceinline__ int x_tile_stride(int nc) { return (nc & 3) == 2 ? nc : (nc | 1); }
 
 // `tid` of `nthreads` (a multiple of 64) threads share the work; callers follow with a barrier.
 // `frames` (a multiple of 4) frames per tile: 64, or 16 for the four-lanes-per-frame kernels.
@@ -120,6 +123,23 @@ __device__ __forceinline__ void load_x_tile(const float* __restrict__ x, int64_t
     // alone on its SIMD, and a load -> wait -> write loop paid one full memory round trip per 1 KiB of the tile
     // (17 of them for 22 atoms).  Indices are clamped instead of
     // predicated so the loads stay unconditional (counted waits).
+    if (stride == nc) {   // the tile as it lies in memory
+      float4* dst = reinterpret_cast<float4*>(lds);
+      for (int v0 = tid; v0 < nvec; v0 += nthreads * kBatch) {
+        float4 val[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+          const int v = v0 + nthreads * i;
+          val[i] = src[v < nvec ? v : nvec - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+          const int v = v0 + nthreads * i;
+          if (v < nvec) dst[v] = val[i];
+        }
+      }
+      return;
+    }
     for (int v0 = tid; v0 < nvec; v0 += nthreads * kBatch) {
       float4 val[kBatch];
 #pragma unroll

@@ -103,7 +103,7 @@ template <bool FAST, bool TILED, bool ROWS>
 __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
                                                        float* __restrict__ feat_tiled, float* __restrict__ feat_rows,
                                                        float* __restrict__ aux_tiled) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   const int64_t tile = blockIdx.x;
   const int nc = pp.n_coord;
@@ -190,7 +190,7 @@ template <int NV, bool TILED, bool ROWS>
 __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t n_tiles,
                                                         float* __restrict__ feat_tiled, float* __restrict__ feat_rows,
                                                         float* __restrict__ aux_tiled) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   const int nc = pp.n_coord;
   const int nvec = 16 * nc;   // 16-byte vectors per tile
@@ -276,12 +276,7 @@ __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const flo
     }
     if (it == 2) CVF_STAMP(3);
     KabschOut ko;
-#if defined(CVF_K1_EXP) && CVF_K1_EXP == 2
-    for (int i = 0; i < 9; ++i) ko.R[i] = (i % 4 == 0) ? 1.0f : 0.0f;
-    for (int i = 0; i < 6; ++i) ko.Kinv[i] = (float)H[i % 3][i / 3];
-#else
     kabsch_from_H(H, ko);
-#endif
     if (it == 2) CVF_STAMP(4);
     if (aux_tiled) {
       float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;
@@ -306,11 +301,7 @@ __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const flo
       const f2 d0 = (my2[3 * m] - P0) - C0, d1 = (my2[3 * m + 1] - P1) - C1, d2 = (my2[3 * m + 2] - P2) - C2;
       const f2 axy = rot_xy(d0.x, d0.y, d1.x), bxy = rot_xy(d1.y, d2.x, d2.y);
       const float az = rot_z(d0.x, d0.y, d1.x), bz = rot_z(d1.y, d2.x, d2.y);
-#if defined(CVF_K1_EXP) && CVF_K1_EXP == 1
-      if (TILED && az == 1.2345e30f) {
-#else
       if (TILED) {
-#endif
         float* f = ft + 6 * m * CVF_TILE;
         f[0] = axy.x; f[CVF_TILE] = axy.y; f[2 * CVF_TILE] = az;
         f[3 * CVF_TILE] = bxy.x; f[4 * CVF_TILE] = bxy.y; f[5 * CVF_TILE] = bz;
@@ -370,7 +361,7 @@ template <bool TILED, bool ROWS>
 __global__ __launch_bounds__(64) void k1_align_quad_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
                                                             float* __restrict__ feat_tiled, float* __restrict__ feat_rows,
                                                             float* __restrict__ aux_tiled) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x, f = lane >> 2, p = lane & 3;
   const int nc = pp.n_coord, nal = pp.n_align;
   const int stride = x_tile_stride(nc);
@@ -471,7 +462,7 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
                                                            const float* __restrict__ a, int k,
                                                            const float* __restrict__ g_tiled,
                                                            float* __restrict__ q_tiled, float* __restrict__ e_tiled) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   const int64_t tile = blockIdx.x;
   const int net = blockIdx.y;
@@ -646,7 +637,7 @@ __global__ __launch_bounds__(512) void metric_pure_kernel(cvf_pp_desc pp, const 
                                                            const float* __restrict__ g_tiled,
                                                            float* __restrict__ q_tiled, float* __restrict__ e_tiled,
                                                            MetricFuse fuse) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int64_t tile = blockIdx.x;
   const int net = blockIdx.y * (nthreads >> 6) + wave;   // the host launches wpb | k, so net < k

@@ -110,6 +110,50 @@ def test_mlp_layout_offsets_follow_parameters_order():
         nn.mlp_layout(nn.EigenFunctions([6, 4, 1], 1, activation=torch.nn.ReLU()))
 
 
+def test_regautoencoder_side_by_side_chain_layout():
+    """RegAutoEncoderTask's flat buffer (core._RegFlatParams): encoder, then decoder and regulariser nets side by side.
+    Evaluating the dense chain it describes must reproduce forward_ae | forward_reg; the mask marks exactly the module's
+    parameters; the module's tensors alias their blocks."""
+    from colvarsfinder import core, nn
+    torch.manual_seed(4)
+    model = nn.RegAutoEncoder([7, 5, 3], [3, 4, 6, 7], [3, 2, 5, 1], 2)
+    want_in = torch.randn(9, 7)
+    want = torch.cat([model.forward_ae(want_in), model.forward_reg(want_in)], dim=1).detach()
+    n_real = sum(p.numel() for p in model.parameters())
+    flat = core._RegFlatParams(model, torch.device("cpu"))
+    d = flat.desc
+    assert (d.n_nets, d.n_layers) == (1, 2 + 3)
+    assert [d.dims[i] for i in range(6)] == [7, 5, 3, 4 + 2 * 2, 6 + 2 * 5, 7 + 2]
+    assert [d.act[i] for i in range(5)] == [1, 0, 1, 1, 0]
+    h = want_in
+    for l in range(d.n_layers):
+        fi, fo = d.dims[l], d.dims[l + 1]
+        W = flat.theta[d.w_off[0][l]:d.w_off[0][l] + fo * fi].view(fo, fi)
+        b = flat.theta[d.b_off[0][l]:d.b_off[0][l] + fo]
+        h = h @ W.T + b
+        if d.act[l]:
+            h = torch.tanh(h)
+    torch.testing.assert_close(h, want, rtol=1e-6, atol=1e-6)
+    assert int(flat.mask.sum()) == n_real and set(flat.mask.unique().tolist()) <= {0.0, 1.0}
+    assert float(flat.theta[flat.mask == 0].abs().max()) == 0.0          # structural zeros of the block-diagonal layers
+    assert flat.n == d.n_params > n_real
+    # aliasing: writing through the module changes the flat buffer (and the other way round)
+    with torch.no_grad():
+        model.reg[1][2].weight.add_(1.0)
+    p = model.reg[1][2].weight
+    l, r0, c0 = 2 + 1, 6 + 5, 4 + 2          # merged layer 1 (second of decoder/regularisers), block of regulariser 1
+    W = flat.theta[d.w_off[0][l]:d.w_off[0][l] + d.dims[l + 1] * d.dims[l]].view(d.dims[l + 1], d.dims[l])
+    assert torch.equal(W[r0:r0 + 5, c0:c0 + 2], p.data)
+    # frozen encoder: its entries leave the mask
+    model2 = nn.RegAutoEncoder([7, 5, 3], [3, 4, 7], [3, 4, 1], 1)
+    flat2 = core._RegFlatParams(model2, torch.device("cpu"), freeze_encoder=True)
+    n_enc = sum(p.numel() for p in model2.encoder.parameters())
+    assert int(flat2.mask.sum()) == sum(p.numel() for p in model2.parameters()) - n_enc
+    assert float(flat2.mask[:n_enc].sum()) == 0.0
+    with pytest.raises(NotImplementedError):   # decoder and regularisers of different depth cannot run side by side
+        core._RegFlatParams(nn.RegAutoEncoder([7, 5, 3], [3, 4, 7], [3, 4, 4, 1], 1), torch.device("cpu"))
+
+
 def test_split_consumes_numpy_rng_like_sklearn():
     from sklearn.model_selection import train_test_split
     from colvarsfinder.core import _split
