@@ -92,11 +92,14 @@ _SIGNATURES = {
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p]),
     "cvf_regae_scratch_floats": (C.c_int64, [C.POINTER(MLPDesc), C.c_int64]),
     "cvf_regae_forward": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
-                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_regae_backward": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p]),
-    "cvf_regae_loss_row": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamArgs),
+                                     C.c_void_p]),
+    "cvf_regae_enc_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_regae_loss_row": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_double,
+                                     C.c_double, C.c_void_p, C.c_void_p]),
     "cvf_mlp_eval_rows": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "cvf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_void_p, C.POINTER(MLPDesc), C.c_void_p, C.c_void_p]),

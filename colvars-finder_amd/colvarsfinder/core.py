@@ -872,9 +872,10 @@ class RegAutoEncoderTask(TrainingTask):
 
     Built on the MI355X path: the time-lagged reconstruction loss (``alpha``, ``lag_tau_ae``, core.py:883-885) and the
     transfer-operator eigenfunction regulariser (``gamma``, ``lag_tau_reg > 0``, core.py:973-1036) - the configurations
-    of the reference's notebooks (2d.ipynb:743-760, main.ipynb:452-458) - with ``freeze_encoder``.  Not built (the
-    constructor raises ``NotImplementedError``): the generator-mode regulariser (``lag_tau_reg = 0`` with ``gamma``) and
-    the encoder regularisers ``eta`` (core.py:887-971).
+    of the reference's notebooks (2d.ipynb:743-760, main.ipynb:452-458) - with ``freeze_encoder`` and the variance /
+    covariance penalties on the latent vector (``eta[1]``, ``eta[2]``, core.py:912-971).  Not built (the constructor raises
+    ``NotImplementedError``): the generator-mode regulariser (``lag_tau_reg = 0`` with ``gamma``) and the gradient-norm
+    penalty ``eta[0]`` (core.py:887-910).
 
     A step is three launches + the reduction: ``cvf_regae_forward`` (one chain: encoder, then decoder and regulariser
     nets side by side; y on the batch's frames and on their lagged partners, reconstruction error), ``cvf_ef_stats``
@@ -911,8 +912,10 @@ class RegAutoEncoderTask(TrainingTask):
             if self.gamma[0] <= self._eps:
                 raise NotImplementedError("RegAutoEncoderTask on MI355X: gamma[0] must be positive when gamma[1] is")
             self._beta = beta
-        if max(self.eta) > self._eps:
-            raise NotImplementedError("RegAutoEncoderTask on MI355X: the encoder regularisers eta (core.py:887-971) are not built")
+        if self.eta[0] > self._eps:
+            raise NotImplementedError("RegAutoEncoderTask on MI355X: the encoder gradient-norm regulariser eta[0] (core.py:887-910) "
+                                      "is not built (eta[1], eta[2] are)")
+        self._use_enc = max(self.eta[1], self.eta[2]) > self._eps
         assert _dist.world() == 1, "RegAutoEncoderTask runs in one process per model in this round"
         self.init_model_and_optimizer()
         # --- data: the feature trajectory r(x) of every frame, once (the layer has no parameters), resident in HBM
@@ -934,6 +937,10 @@ class RegAutoEncoderTask(TrainingTask):
         for i in range(self.num_reg):
             cfg.eig_w[i] = float(eig_weights[i])
         self._cfg = cfg
+        ecfg = _hip.EFCfg()                      # batch sums of the latent vector (the generator-mode layout, E unused)
+        ecfg.k, ecfg.lag_idx, ecfg.sort_eigvals, ecfg.alpha, ecfg.beta, ecfg.dt = self.k, 0, 0, 0.0, 1.0, 1.0
+        self._ecfg = ecfg
+        self._n_enc_layers = len([m for m in self.model.encoder if isinstance(m, torch.nn.Linear)])
         self._ws = {}
 
     # -- the base class builds the flat buffer from mlp_layout(); this model needs the side-by-side chain
@@ -980,6 +987,14 @@ class RegAutoEncoderTask(TrainingTask):
                 sscratch=torch.zeros(lib.cvf_ef_stats_scratch_doubles(K, 1), device=dev, dtype=torch.float64),
                 loss_vec=torch.zeros(3 + 2 * K, device=dev, dtype=torch.float64),
                 coef=torch.zeros(4 * K + K * K, device=dev, dtype=torch.float64), T=T)
+            if True:   # (small) latent-vector buffers: the public reg_enc_* functions need them whatever eta is
+                k = self.k
+                ws.update(enc=torch.zeros(T * k * 64, device=dev, dtype=torch.float32),
+                          ezero=torch.zeros(T * k * 64, device=dev, dtype=torch.float32),
+                          estats=torch.zeros(lib.cvf_ef_nstats(k, 0), device=dev, dtype=torch.float64),
+                          esscratch=torch.zeros(lib.cvf_ef_stats_scratch_doubles(k, 0), device=dev, dtype=torch.float64),
+                          eterms=torch.zeros(2, device=dev, dtype=torch.float64),
+                          ecoef=torch.zeros(k + k * k, device=dev, dtype=torch.float64))
             self._ws[B] = ws
         return ws
 
@@ -987,23 +1002,33 @@ class RegAutoEncoderTask(TrainingTask):
         """Loss terms (and, with ``with_grad``, gradient + optimizer step) of one batch: rows ``idx`` of ``feat``
         (``None``: rows 0..B-1), targets at ``+lag_ae``, lagged partners at ``+lag_reg``.  ``wsum``: the batch's weight
         sum when the caller knows it (static batches), else one host read.  Returns (or fills ``out`` with) the device
-        vector [loss, ae, npl, pen, eig_1..K] (fp64)."""
+        vector [loss, ae, npl, pen, eig_1..K, 0, enc_norm, enc_orth] (fp64)."""
         lib, fl, P = _hip.lib(), self._flat, _hip.ptr
         B, K = int(w.shape[0]), self.num_reg
         ws = self._workspace(B)
         use_reg = self._use_reg and K > 0
         alpha = float(self.alpha) if self.alpha > self._eps else 0.0
+        use_enc = self._use_enc
+        eta1 = float(self.eta[1]) if self.eta[1] > self._eps else 0.0
+        eta2 = float(self.eta[2]) if self.eta[2] > self._eps else 0.0
         self._call("cvf_regae_forward", lib.cvf_regae_forward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
-                   lag_reg if use_reg else 0, K, P(w), P(ws["scratch"]), P(ws["y"]), P(ws["out2"]), _hip.stream())
+                   lag_reg if use_reg else 0, K, P(w), P(ws["scratch"]), P(ws["y"]), self._n_enc_layers,
+                   P(ws["enc"]) if use_enc else None, P(ws["out2"]), _hip.stream())
+        if use_enc:   # core.py:912-971: weighted means / variances / covariances of the latent vector, then the two penalties
+            self._call("cvf_ef_stats", lib.cvf_ef_stats, self._ecfg, B, P(w), P(ws["enc"]), P(ws["ezero"]), None, None,
+                       P(ws["esscratch"]), P(ws["estats"]), None, None, _hip.stream())
+            self._call("cvf_regae_enc_loss", lib.cvf_regae_enc_loss, P(ws["estats"]), self.k, eta1, eta2, P(ws["eterms"]),
+                       P(ws["ecoef"]), _hip.stream())
         if use_reg:
             y_lag = ws["y"][ws["T"] * K * 64:]
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws["y"]), None, P(w_lag), P(y_lag),
                        P(ws["sscratch"]), P(ws["stats"]), P(ws["loss_vec"]), P(ws["coef"]), _hip.stream())
             self._cvec_dev = ws["loss_vec"][3 + K:3 + 2 * K]
         if out is None:
-            out = torch.zeros(4 + K, device=self.device, dtype=torch.float64)
+            out = torch.zeros(7 + K, device=self.device, dtype=torch.float64)
         self._call("cvf_regae_loss_row", lib.cvf_regae_loss_row, P(ws["out2"]), P(ws["loss_vec"]) if use_reg else None, alpha,
-                   float(self.gamma[0]) if use_reg else 0.0, float(self.gamma[1]) if use_reg else 0.0, K, P(out), _hip.stream())
+                   float(self.gamma[0]) if use_reg else 0.0, float(self.gamma[1]) if use_reg else 0.0, K,
+                   P(ws["eterms"]) if use_enc else None, eta1, eta2, P(out), _hip.stream())
         if with_grad:
             if wsum is None:
                 wsum = float(w.sum(dtype=torch.float64))
@@ -1011,7 +1036,8 @@ class RegAutoEncoderTask(TrainingTask):
             self._call("cvf_regae_backward", lib.cvf_regae_backward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
                        lag_reg if use_reg else 0, K, P(w), P(w_lag) if use_reg else None, alpha / wsum,
                        float(self.gamma[0]) if use_reg else 0.0, P(ws["y"]) if use_reg else None,
-                       P(ws["coef"]) if use_reg else None, P(ws["scratch"]), P(fl.grad), P(fl.mask),
+                       P(ws["coef"]) if use_reg else None, self._n_enc_layers, P(ws["ecoef"]) if use_enc else None,
+                       P(ws["scratch"]), P(fl.grad), P(fl.mask),
                        P(self.optimizer.step_count) if advance else None, adam, _hip.stream())
             if advance and adam is None:
                 self.optimizer.step(advance=False)
@@ -1022,28 +1048,34 @@ class RegAutoEncoderTask(TrainingTask):
     def _dev(self, t):
         return torch.as_tensor(t).detach().to(device=self.device, dtype=torch.float32).contiguous()
 
+    def _terms(self, feat, w, w_lag, lag_ae, lag_reg, alpha, use_reg, use_enc):
+        """Forward values with only the named parts of the loss switched on."""
+        keep = (self.alpha, self._use_reg, self._use_enc, self.eta)
+        self.alpha, self._use_reg, self._use_enc, self.eta = alpha, use_reg, use_enc, [0.0, 1.0, 1.0] if use_enc else [0.0, 0.0, 0.0]
+        try:
+            return self._step(feat, None, w, w_lag, lag_ae, lag_reg, with_grad=False)
+        finally:
+            self.alpha, self._use_reg, self._use_enc, self.eta = keep
+
     def weighted_MSE_loss(self, X, X_lagged, weight):
         """core.py:879-885."""
         B = int(torch.as_tensor(X).shape[0])
         feat = torch.cat([self._features(X), self._features(X_lagged)])
-        w = self._dev(weight)
-        keep = (self.alpha, self._use_reg)
-        self.alpha, self._use_reg = 1.0, False
-        try:
-            out = self._step(feat, None, w, None, B, 0, with_grad=False)
-        finally:
-            self.alpha, self._use_reg = keep
-        return out[1].to(torch.get_default_dtype())
+        return self._terms(feat, self._dev(weight), None, B, 0, 1.0, False, False)[1].to(torch.get_default_dtype())
 
     def reg_eigen_loss(self, X, weight, X_lagged, weight_lagged):
         """core.py:973-1036 (transfer operator): ``(eig_vals, non_penalty_loss, penalty, cvec)``."""
-        assert self._use_reg, 'the regulariser is switched off (gamma = [0, 0])'
+        assert self.num_reg > 0 and self.lag_idx > 0, 'needs regularisers and lag_tau_reg > 0'
         B = int(torch.as_tensor(X).shape[0])
         feat = torch.cat([self._features(X), self._features(X_lagged)])
-        out = self._step(feat, None, self._dev(weight), self._dev(weight_lagged), 0, B, with_grad=False)
+        gam, self.gamma = self.gamma, (self.gamma if self._use_reg else [1.0, 1.0])
+        try:
+            out = self._terms(feat, self._dev(weight), self._dev(weight_lagged), 0, B, 0.0, True, False)
+        finally:
+            self.gamma = gam
         dt = torch.get_default_dtype()
         cvec = self._cvec_dev.cpu().to(torch.long).numpy()
-        return out[4:].to(dt).cpu(), out[2].to(dt), out[3].to(dt), cvec
+        return out[4:4 + self.num_reg].to(dt).cpu(), out[2].to(dt), out[3].to(dt), cvec
 
     def backward(self):
         """Fill ``p.grad`` of the module's parameters from the flat gradient of the last ``_step(..., with_grad=True)``."""
@@ -1051,9 +1083,19 @@ class RegAutoEncoderTask(TrainingTask):
             p.grad = gv.clone()
 
     def reg_enc_grad_loss(self, X, weight):
-        raise NotImplementedError("encoder regularisers (eta) are not built on the MI355X path")
+        raise NotImplementedError("the encoder gradient-norm regulariser (core.py:887-910) is not built on the MI355X path")
 
-    reg_enc_norm_loss = reg_enc_orthognal_loss = reg_enc_grad_loss
+    def _enc_terms(self, X, weight):
+        out = self._terms(self._features(X), self._dev(weight), None, 0, 0, 0.0, False, True)
+        return out[5 + self.num_reg:].to(torch.get_default_dtype())
+
+    def reg_enc_norm_loss(self, X, weight):
+        """core.py:912-934."""
+        return self._enc_terms(X, weight)[0]
+
+    def reg_enc_orthognal_loss(self, X, weight):
+        """core.py:936-971."""
+        return self._enc_terms(X, weight)[1]
 
     def train(self):
         """core.py:1038-1217."""

@@ -128,6 +128,11 @@ struct AeReg {
   const double* coef;    // [gS1(K), gS2(K*K), gT(K), gS1'(K), gS2'_ii(K)]  (CVF_COEF_LEN)
   const float* w_lag;    // [B] weights of the lagged frames
   float* y_tiled;        // [n_tiles][K][64]
+  // encoder regularisers (core.py:912-971: variance and covariance penalties on the latent vector, rows idx only)
+  int enc_layer;         // image index of the latent vector = number of encoder layers
+  int k_enc;             // its width
+  float* enc_tiled;      // forward pass: [T][k_enc][64] latent values (NULL: not wanted)
+  const double* enc_coef;   // backward pass: [gS1(k), gS2(k*k)] of eta_1 norm + eta_2 orth penalties (NULL: off)
 };
 
 __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
@@ -261,6 +266,10 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
       CVF_STAMP(41 + l);
     }
     CVF_STAMP(21);
+    if (reg.enc_tiled != nullptr && reg.write_y && !lagged) {   // the latent vector of this wave's frames
+      const float* ei = lds + s_img[reg.enc_layer];
+      for (int j = kq; j < reg.k_enc; j += 4) reg.enc_tiled[(t0 * reg.k_enc + j) * CVF_TILE + fcol] = ei[j * AP + fcol];
+    }
     // ---- weighted squared error and zbar_L = 2 w (out - f) / sum(w)     (core.py:666); rows o = 16 rt + 4 kq + r
     {
       const float scale = (float)(2.0 * (double)wb * inv_wsum);
@@ -385,6 +394,7 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
         const float* Wl = WL + wo;
         const float* al = lds + s_img[l];
         const bool act = s_act[l - 1] != 0;
+        const bool add_enc = reg.enc_coef != nullptr && l == reg.enc_layer && !lagged;
         constexpr int kBT = 4, kBC = 8;   // row tiles per pass, k-steps per batch (as in the forward layers)
         for (int rt0 = 0; 16 * rt0 < din; rt0 += kBT) {
           f32x4 acc[kBT];
@@ -423,6 +433,11 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
                 const int i = 16 * rt + 4 * kq + r;
                 if (i < din) {
                   float v = acc[t][r];
+                  if (add_enc) {   // d (eta_1 norm + eta_2 orth) / d latent_i of this frame: w (gS1_i + sum_j c_ij gS2_ij e_j)
+                    double a = reg.enc_coef[i];
+                    for (int j = 0; j < din; ++j) a += (j == i ? 2.0 : 1.0) * reg.enc_coef[din + i * din + j] * (double)al[j * AP + fcol];
+                    v += (float)((double)wraw * a);
+                  }
                   if (act) {
                     const float a = al[i * AP + fcol];
                     v *= 1.0f - a * a;
@@ -563,6 +578,11 @@ static int regae_launch(const cvf_mlp_desc* mlp, const float* theta, const float
               reg.K, mlp->dims[mlp->n_layers]);
   CVF_REQUIRE(reg.lag_t >= 0 && reg.lag_in >= 0 && (reg.coef == nullptr || reg.lag_in > 0),
               "cvf_regae: the regulariser needs lag_input > 0 (transfer-operator loss; the generator loss is not built for this task)");
+  if (reg.enc_tiled != nullptr || reg.enc_coef != nullptr) {
+    CVF_REQUIRE(reg.enc_layer >= 1 && reg.enc_layer < mlp->n_layers, "cvf_regae: n_enc_layers=%d out of range", reg.enc_layer);
+    reg.k_enc = mlp->dims[reg.enc_layer];
+    CVF_REQUIRE(reg.k_enc <= CVF_MAX_NETS, "cvf_regae: latent width %d > %d", reg.k_enc, CVF_MAX_NETS);
+  }
   const AeMLayout lay = ae_mlayout(*mlp, with_grad);
   const size_t lds = (size_t)lay.total * sizeof(float);
   CVF_REQUIRE(lds <= 160 * 1024, "cvf_regae: the chain needs %zu B of LDS per workgroup (> 160 KiB)", lds);
@@ -580,14 +600,16 @@ static int regae_launch(const cvf_mlp_desc* mlp, const float* theta, const float
 
 extern "C" int cvf_regae_forward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
                                  int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, float* scratch,
-                                 float* y_tiled, double* out2, void* stream) {
+                                 float* y_tiled, int n_enc_layers, float* enc_tiled, double* out2, void* stream) {
   CVF_REQUIRE(mlp && theta && feat_rows && w && scratch && out2 && B > 0 && (K == 0 || y_tiled), "cvf_regae_forward: bad argument");
   AeReg reg = {};
   reg.K = K;
-  reg.write_y = K > 0;
+  reg.write_y = K > 0 || enc_tiled != nullptr;
   reg.lag_t = lag_target;
   reg.lag_in = lag_input;
   reg.y_tiled = y_tiled;
+  reg.enc_layer = n_enc_layers;
+  reg.enc_tiled = enc_tiled;
   int G = 0;
   hipStream_t s = (hipStream_t)stream;
   int rc = regae_launch(mlp, theta, feat_rows, idx, B, w, 0.0, false, scratch, nullptr, reg, &G, s);
@@ -602,8 +624,9 @@ int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, fl
 
 extern "C" int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
                                   int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, const float* w_lag,
-                                  double mse_scale, double head_scale, const float* y_tiled, const double* coef, float* scratch,
-                                  float* grad, const float* mask, int32_t* step_count, const cvf_adam_args* adam, void* stream) {
+                                  double mse_scale, double head_scale, const float* y_tiled, const double* coef,
+                                  int n_enc_layers, const double* enc_coef, float* scratch, float* grad, const float* mask,
+                                  int32_t* step_count, const cvf_adam_args* adam, void* stream) {
   CVF_REQUIRE(mlp && theta && feat_rows && w && scratch && grad && B > 0, "cvf_regae_backward: bad argument");
   CVF_REQUIRE(coef == nullptr || (K > 0 && w_lag && y_tiled), "cvf_regae_backward: the regulariser needs heads, w_lag and y_tiled");
   CVF_REQUIRE(adam == nullptr || (adam->theta && adam->m && adam->v && adam->step_count), "cvf_regae_backward: incomplete adam arguments");
@@ -615,6 +638,8 @@ extern "C" int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, c
   reg.coef = coef;
   reg.w_lag = w_lag;
   reg.y_tiled = const_cast<float*>(y_tiled);
+  reg.enc_layer = n_enc_layers;
+  reg.enc_coef = enc_coef;
   int G = 0;
   int rc = regae_launch(mlp, theta, feat_rows, idx, B, w, mse_scale, true, scratch, step_count, reg, &G, (hipStream_t)stream);
   if (rc) return rc;
@@ -627,24 +652,71 @@ extern "C" int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, c
   return cvf_slab_reduce_impl(scratch, G, mlp->n_params, grad, mask, adam != nullptr ? &ad : nullptr, stream);
 }
 
-// row of RegAutoEncoderTask's loss list (core.py:1112-1124): [loss, ae, npl, pen, eig_1..K]
+// row of RegAutoEncoderTask's loss list (core.py:1112-1124): [loss, ae, npl, pen, eig_1..K, enc_grad (0), enc_norm, enc_orth]
 __global__ void regae_loss_row_kernel(const double* __restrict__ out2, const double* __restrict__ loss_vec, double alpha, double g0,
-                                      double g1, int K, double* __restrict__ row) {
+                                      double g1, int K, const double* __restrict__ enc_terms, double eta1, double eta2,
+                                      double* __restrict__ row) {
   if (threadIdx.x != 0) return;
   const double ae = alpha != 0.0 ? out2[0] / out2[1] : 0.0;
   const double npl = loss_vec ? loss_vec[1] : 0.0, pen = loss_vec ? loss_vec[2] : 0.0;
-  row[0] = alpha * ae + g0 * npl + g1 * pen;
+  const double en = (enc_terms && eta1 != 0.0) ? enc_terms[0] : 0.0, eo = (enc_terms && eta2 != 0.0) ? enc_terms[1] : 0.0;
+  row[0] = alpha * ae + g0 * npl + g1 * pen + eta1 * en + eta2 * eo;
   row[1] = ae;
   row[2] = npl;
   row[3] = pen;
   for (int i = 0; i < K; ++i) row[4 + i] = loss_vec ? loss_vec[3 + i] : 0.0;
+  row[4 + K] = 0.0;
+  row[5 + K] = en;
+  row[6 + K] = eo;
 }
 
 extern "C" int cvf_regae_loss_row(const double* out2, const double* loss_vec, double alpha, double gamma0, double gamma1, int K,
-                                  double* row, void* stream) {
+                                  const double* enc_terms, double eta1, double eta2, double* row, void* stream) {
   CVF_REQUIRE(out2 && row && K >= 0 && K <= CVF_MAX_NETS, "cvf_regae_loss_row: bad argument");
-  hipLaunchKernelGGL(regae_loss_row_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out2, loss_vec, alpha, gamma0, gamma1, K, row);
+  hipLaunchKernelGGL(regae_loss_row_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out2, loss_vec, alpha, gamma0, gamma1, K,
+                     enc_terms, eta1, eta2, row);
   return cvf_check_launch("regae_loss_row_kernel");
+}
+
+// Encoder regularisers (core.py:912-971) from the latent vector's batch sums [W, S1(k), S2(i<=j), ...] (cvf_ef_stats layout):
+// terms = {sum_j (var_j - 1)^2, sum_{i<j} cov_ij^2}; coef = d(eta1 terms[0] + eta2 terms[1]) / d{S1_j, S2_ij} in the layout the
+// backward pass reads ([gS1(k), gS2(k*k) symmetric]; a frame's latent gradient is w (gS1_i + sum_j c_ij gS2_ij e_j), c_ii = 2)
+__global__ void regae_enc_loss_kernel(const double* __restrict__ stats, int k, double eta1, double eta2, double* __restrict__ terms,
+                                      double* __restrict__ coef) {
+  if (threadIdx.x != 0) return;
+  const double W = stats[0];
+  const double* S1 = stats + 1;
+  const double* S2 = stats + 1 + k;
+  auto s2 = [&](int i, int j) { return S2[i * k - (i * (i - 1)) / 2 + (j - i)]; };   // i <= j
+  double mean[CVF_MAX_NETS], var[CVF_MAX_NETS];
+  for (int j = 0; j < k; ++j) {
+    mean[j] = S1[j] / W;
+    var[j] = s2(j, j) / W - mean[j] * mean[j];
+  }
+  double tn = 0.0, to = 0.0;
+  for (int j = 0; j < k; ++j) {
+    tn += (var[j] - 1.0) * (var[j] - 1.0);
+    coef[j] = eta1 * 2.0 * (var[j] - 1.0) * (-2.0 * mean[j] / W);
+    for (int i = 0; i < k; ++i) coef[k + j * k + i] = 0.0;
+  }
+  for (int j = 0; j < k; ++j) coef[k + j * k + j] = eta1 * 2.0 * (var[j] - 1.0) / W;
+  for (int i = 0; i < k; ++i)
+    for (int j = i + 1; j < k; ++j) {
+      const double cov = s2(i, j) / W - mean[i] * mean[j];
+      to += cov * cov;
+      const double g = eta2 * 2.0 * cov;
+      coef[k + i * k + j] = coef[k + j * k + i] = g / W;
+      coef[i] += g * (-mean[j] / W);
+      coef[j] += g * (-mean[i] / W);
+    }
+  terms[0] = tn;
+  terms[1] = to;
+}
+
+extern "C" int cvf_regae_enc_loss(const double* stats, int k, double eta1, double eta2, double* terms, double* coef, void* stream) {
+  CVF_REQUIRE(stats && terms && coef && k >= 1 && k <= CVF_MAX_NETS, "cvf_regae_enc_loss: bad argument (k=%d)", k);
+  hipLaunchKernelGGL(regae_enc_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, k, eta1, eta2, terms, coef);
+  return cvf_check_launch("regae_enc_loss_kernel");
 }
 
 extern "C" int cvf_mlp_eval_rows(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, int64_t B,

@@ -233,32 +233,40 @@ int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const float* feat_r
 
 /* --- RegAutoEncoderTask (core.py:746-1217): time-lagged reconstruction loss
  * (weighted_MSE_loss, core.py:883-885) + transfer-operator eigenfunction regulariser (reg_eigen_loss with
- * lag_tau_reg > 0, core.py:973-1036) + backward + optimizer step (core.py:1117,1128).  `mlp` is ONE chain: the
- * encoder's layers, then the decoder and the K regulariser nets side by side as block-structured layers (built by the
- * host, colvarsfinder/core.py:_RegFlatParams), so that its last layer is [reconstruction (d_0 rows) | y_1..y_K].
+ * lag_tau_reg > 0, core.py:973-1036) + the variance / covariance penalties on the latent vector (reg_enc_norm_loss,
+ * reg_enc_orthognal_loss, core.py:912-971) + backward + optimizer step (core.py:1117,1128).  `mlp` is ONE chain: the
+ * encoder's n_enc_layers layers, then the decoder and the K regulariser nets side by side as block-structured layers (built
+ * by the host, colvarsfinder/core.py:_RegFlatParams), so that its last layer is [reconstruction (d_0 rows) | y_1..y_K].
  * feat_rows [n][d_0]: the feature trajectory; idx [B] (or NULL: 0..B-1): the batch's rows; rows idx + lag_target are
- * the reconstruction targets, rows idx + lag_input the lagged arguments of the regularisers (K > 0 needs lag_input > 0:
- * the generator-mode regulariser of the reference is not built).
- *  cvf_regae_forward : y_tiled [2 T][K][64] (tiles 0..T-1: y on the rows idx, T..2T-1: on the lagged rows) and
- *                      out2 = {sum w |dec(enc(f)) - f_target|^2, sum w}; then cvf_ef_stats (lag_idx > 0, k = K) on
- *                      y_tiled gives the loss terms and `coef`.
- *  cvf_regae_backward: flat gradient of  mse_scale * sum w |..|^2 + head_scale * (npl + cfg.alpha * pen)  in the
- *                      chain's own parameter order (mse_scale = alpha / sum w, head_scale = gamma_0, cfg.alpha =
- *                      gamma_1 / gamma_0), times `mask` (may be NULL; zeros at the structural zeros of the block layers
- *                      and at frozen parameters), + the Adam update when adam != NULL; step_count as cvf_ae_step. */
+ * the reconstruction targets, rows idx + lag_input the lagged arguments of the regularisers (the generator-mode
+ * regulariser and the gradient-norm penalty eta_0 of the reference are not built).
+ *  cvf_regae_forward : y_tiled [2 T][K][64] (tiles 0..T-1: y on the rows idx, T..2T-1: on the lagged rows), enc_tiled
+ *                      [T][k][64] (latent vector on the rows idx; NULL: not wanted) and out2 = {sum w |dec(enc(f)) -
+ *                      f_target|^2, sum w}.  Then cvf_ef_stats (lag_idx > 0, k = K) on y_tiled gives the eigenfunction
+ *                      terms and `coef`; cvf_ef_stats (lag_idx = 0, zero e_tiled) on enc_tiled + cvf_regae_enc_loss the
+ *                      latent penalties and `enc_coef`.
+ *  cvf_regae_backward: flat gradient of  mse_scale * sum w |..|^2 + head_scale * (npl + cfg.alpha * pen) + eta_1 norm +
+ *                      eta_2 orth  in the chain's own parameter order (mse_scale = alpha / sum w, head_scale = gamma_0,
+ *                      cfg.alpha = gamma_1 / gamma_0; coef / enc_coef NULL: that part is off), times `mask` (may be NULL;
+ *                      zeros at the structural zeros of the block layers and at frozen parameters), + the Adam update
+ *                      when adam != NULL; step_count as cvf_ae_step. */
 int64_t cvf_regae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B);
 int cvf_regae_forward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx, int64_t B,
                       int64_t lag_target, int64_t lag_input, int K, const float* w, float* scratch, float* y_tiled,
-                      double* out2, void* stream);
+                      int n_enc_layers, float* enc_tiled, double* out2, void* stream);
 int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx, int64_t B,
                        int64_t lag_target, int64_t lag_input, int K, const float* w, const float* w_lag, double mse_scale,
-                       double head_scale, const float* y_tiled, const double* coef, float* scratch, float* grad,
-                       const float* mask, int32_t* step_count, const cvf_adam_args* adam, void* stream);
-
-/* row [4 + K] of the task's loss list (core.py:1112-1124): [alpha ae + gamma_0 npl + gamma_1 pen, ae, npl, pen, eig_1..K]
- * from out2 (cvf_regae_forward) and loss_vec (cvf_ef_stats; NULL: regulariser off); alpha = 0 leaves ae = 0 (core.py:1090). */
+                       double head_scale, const float* y_tiled, const double* coef, int n_enc_layers, const double* enc_coef,
+                       float* scratch, float* grad, const float* mask, int32_t* step_count, const cvf_adam_args* adam,
+                       void* stream);
+/* latent penalties from the latent vector's batch sums (cvf_ef_stats layout [W, S1(k), S2(i<=j), ..]):
+ * terms = {sum_j (var_j - 1)^2, sum_{i<j} cov_ij^2} (core.py:934, 966); enc_coef [k + k*k] for cvf_regae_backward */
+int cvf_regae_enc_loss(const double* stats, int k, double eta1, double eta2, double* terms, double* enc_coef, void* stream);
+/* row [7 + K] of the task's loss list (core.py:1112-1124): [loss, ae, npl, pen, eig_1..K, 0 (gradient-norm term), norm, orth]
+ * with loss = alpha ae + gamma_0 npl + gamma_1 pen + eta_1 norm + eta_2 orth; from out2 (cvf_regae_forward), loss_vec
+ * (cvf_ef_stats; NULL: regulariser off), enc_terms (cvf_regae_enc_loss; NULL: off); alpha = 0 leaves ae = 0 (core.py:1090). */
 int cvf_regae_loss_row(const double* out2, const double* loss_vec, double alpha, double gamma0, double gamma1, int K,
-                       double* row, void* stream);
+                       const double* enc_terms, double eta1, double eta2, double* row, void* stream);
 
 /* --- nets forward on row-major features (inference: colvar_model(), core.py:372-382,
  * 640-647).  out [B][n_out] where n_out = n_nets * d_L; upto_layer < n_layers stops a

@@ -327,13 +327,14 @@ def test_regae_train_trace(dev, name, tag, rtol):
     e_dims, d_dims, r_dims = ([int(d) for d in g[k_]] for k_ in ("e_dims", "d_dims", "r_dims"))
     K, lag_ae, lag_reg, dt = int(g["K"]), int(g["lag_ae"]), int(g["lag_reg"]), float(g["dt"])
     frozen = bool(g["freeze"])
+    eta = [float(v) for v in g["eta"]] if "eta" in g.files else [0.0, 0.0, 0.0]
     model = nn.RegAutoEncoder(e_dims, d_dims, r_dims, K)
     model.load_state_dict(goldens.state_dict(g, dtype=torch.float32))
     traj = np.array(g["traj"])
     layer = make_layer(goldens.pp_spec(g), traj.shape[1] if traj.ndim == 3 else 0, dev)
     task = core.RegAutoEncoderTask(Traj(traj, np.array(g["w"]), dt), layer, model, "/tmp/cvf_test", eig_weights=[float(v) for v in g["eig_w"]],
                                    learning_rate=float(g["lr"]), batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]),
-                                   alpha=float(g["alpha"]), gamma=[float(v) for v in g["gamma"]], lag_tau_ae=lag_ae * dt,
+                                   alpha=float(g["alpha"]), gamma=[float(v) for v in g["gamma"]], eta=eta, lag_tau_ae=lag_ae * dt,
                                    lag_tau_reg=lag_reg * dt, freeze_encoder=frozen, device=dev, verbose=False, save_model_every_step=0)
     # the module's parameters alias the flat chain buffer (strided blocks for the side-by-side layers): values unchanged
     for n, p in model.state_dict().items():
@@ -346,7 +347,10 @@ def test_regae_train_trace(dev, name, tag, rtol):
     task.backward()
     # (the fp32 fixtures carry the reference's own cancellation noise in sum w (y' - y)^2: 1e-3 against its fp64 run here)
     rtol_kat = rtol if tag == "f64" else 10 * rtol
-    np.testing.assert_allclose(out, g["kat"], rtol=rtol_kat)
+    np.testing.assert_allclose(out[:4 + K], g["kat"], rtol=rtol_kat)
+    if "kat_enc" in g.files:     # variance / covariance penalties on the latent vector (core.py:912-971)
+        np.testing.assert_allclose(out[5 + K:], g["kat_enc"], rtol=rtol_kat, atol=1e-9)
+        assert out[4 + K] == 0.0
     np.testing.assert_array_equal(task._cvec_dev.cpu().numpy().astype(np.int64), g["kat_cvec"])
     # absolute tolerance on the scale of the whole gradient (as for the loss_func fixtures above)
     gmax = max(float(np.abs(g["grad/" + n]).max()) for n, _ in model.named_parameters())
@@ -368,6 +372,9 @@ def test_regae_train_trace(dev, name, tag, rtol):
     eig, npl, pen, cvec = task.reg_eigen_loss(X[:nb], task._weights[:nb], X[lag_reg:lag_reg + nb], task._weights[lag_reg:lag_reg + nb])
     np.testing.assert_allclose([float(ae), float(npl), float(pen)] + [float(e) for e in eig], g["kat"][1:], rtol=rtol_kat)
     np.testing.assert_array_equal(np.asarray(cvec), g["kat_cvec"])
+    if "kat_enc" in g.files:
+        np.testing.assert_allclose([float(task.reg_enc_norm_loss(X[:nb], task._weights[:nb])),
+                                    float(task.reg_enc_orthognal_loss(X[:nb], task._weights[:nb]))], g["kat_enc"], rtol=rtol_kat, atol=1e-9)
     np.random.seed(int(g["seed"]))
     task.train()
     tr, te = np.stack([e[0].numpy() for e in task.loss_list]), np.stack([e[1].numpy() for e in task.loss_list])
@@ -400,7 +407,7 @@ def test_regae_unbuilt_options_fail_loudly(dev):
     kw = dict(eig_weights=[1.0], device=dev, verbose=False)
     with pytest.raises(NotImplementedError):   # generator-mode regulariser
         core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), model, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0, **kw)
-    with pytest.raises(NotImplementedError):   # encoder regularisers
+    with pytest.raises(NotImplementedError):   # gradient-norm penalty on the encoder
         core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), model, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0.5,
                                 eta=[1.0, 0.0, 0.0], **kw)
 

@@ -246,7 +246,7 @@ def run_ae_train(core, rnn, name, case, e_dims, d_dims, dtype, lr, bs, epochs, s
 
 
 def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alpha, gamma, eig_w, lag_ae, lag_reg, dt, lr, bs,
-                    epochs, seed, freeze=False):
+                    epochs, seed, freeze=False, eta=(0.0, 0.0, 0.0)):
     torch.set_default_dtype(dtype)
     g = torch.Generator().manual_seed(seed)
     sd0 = nnref.init_regautoencoder(e_dims, d_dims, r_dims, K, g, dtype)
@@ -256,7 +256,7 @@ def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alp
     traj, w = case["traj"], case["w"]
     with tempfile.TemporaryDirectory() as tmp:
         task = core.RegAutoEncoderTask(Traj(traj, w, dt), pp, model, tmp, eig_weights=eig_w, learning_rate=lr, batch_size=bs,
-                                       num_epochs=epochs, test_ratio=0.2, alpha=alpha, gamma=gamma, eta=[0.0, 0.0, 0.0],
+                                       num_epochs=epochs, test_ratio=0.2, alpha=alpha, gamma=gamma, eta=list(eta),
                                        lag_tau_ae=lag_ae * dt, lag_tau_reg=lag_reg * dt, freeze_encoder=freeze, verbose=False,
                                        save_model_every_step=0)
         # known answer at the initial weights: the loss terms of the first 200 frames + all parameter gradients
@@ -264,7 +264,9 @@ def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alp
         X, wb = task._traj[:nb], task._weights[:nb]
         ae0 = task.weighted_MSE_loss(X, task._traj[lag_ae:lag_ae + nb], wb)
         eig0, npl0, pen0, cvec0 = task.reg_eigen_loss(X, wb, task._traj[lag_reg:lag_reg + nb], task._weights[lag_reg:lag_reg + nb])
-        l0 = alpha * ae0 + gamma[0] * npl0 + gamma[1] * pen0
+        en0 = task.reg_enc_norm_loss(X, wb) if eta[1] > 0 else torch.zeros(())
+        eo0 = task.reg_enc_orthognal_loss(X, wb) if eta[2] > 0 else torch.zeros(())
+        l0 = alpha * ae0 + gamma[0] * npl0 + gamma[1] * pen0 + eta[1] * en0 + eta[2] * eo0
         l0.backward()
         grads0 = {f"grad/{n}": p.grad.detach().numpy().copy() for n, p in model.named_parameters()}
         model.zero_grad(set_to_none=True)
@@ -278,6 +280,7 @@ def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alp
     out = dict(kind="regae_train", e_dims=np.asarray(e_dims), d_dims=np.asarray(d_dims), r_dims=np.asarray(r_dims), K=K, lr=lr,
                batch_size=bs, num_epochs=epochs, seed=seed, alpha=alpha, gamma=np.asarray(gamma, dtype=np.float64),
                eig_w=np.asarray(eig_w, dtype=np.float64), lag_ae=lag_ae, lag_reg=lag_reg, dt=dt, freeze=freeze, traj=traj, w=w,
+               eta=np.asarray(eta, dtype=np.float64), kat_enc=np.asarray([float(en0), float(eo0)]),
                train_idx=perm[n_test:], test_idx=perm[:n_test], kat_n=nb,
                kat=np.asarray([float(l0), float(ae0), float(npl0), float(pen0)] + [float(e) for e in eig0]),
                kat_cvec=np.asarray(cvec0),
@@ -293,6 +296,17 @@ def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alp
     tag = "f32" if dtype == torch.float32 else "f64"
     np.savez_compressed(os.path.join(OUT, f"{name}_{tag}.npz"), **out)
     print(f"  {name}_{tag}: kat={out['kat'][:4]} last train {out['train_loss'][-1, -1, :4]}")
+
+
+def run_regae_eta_cases(core, rnn, id2, mol10):
+    for dtype in (torch.float32, torch.float64):
+        # variance / covariance penalties on the latent vector (eta_1, eta_2) on top of the main.ipynb shape
+        run_regae_train(core, rnn, "train_regae_mol10_k2_eta", mol10, [30, 20, 20, 20, 2], [2, 10, 10, 30], [2, 10, 10, 1], 2, dtype, 1.0,
+                        [1.0, 10.0], [1.0, 0.5], 0, 1, 0.5, 2e-3, 64, 3, 704, eta=(0.0, 0.5, 2.0))
+        # ... and alone (no eigenfunction regulariser), three latent components, identity preprocessing
+        run_regae_train(core, rnn, "train_regae_id2_k1_eta", id2, [2, 16, 3], [3, 16, 2], [3, 8, 1], 1, dtype, 1.0,
+                        [1.0, 5.0], [1.0], 1, 2, 0.5, 5e-3, 100, 2, 705, eta=(0.0, 1.5, 0.7))
+    torch.set_default_dtype(torch.float32)
 
 
 def run_regae_cases(core, rnn, id2, mol10):
@@ -373,6 +387,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     core, rnn = import_reference()
     print("reference imported from", core.__file__)
+    if "--regae-eta-only" in sys.argv:
+        t2, w2 = make_2d_traj(600, seed=11)
+        run_regae_eta_cases(core, rnn, dict(pp="identity", traj=t2, w=w2), molecule_case(10, 300, seed=21))
+        return
     if "--regae-only" in sys.argv:   # add the G7 cases without rewriting the other fixtures
         t2, w2 = make_2d_traj(600, seed=11)
         run_regae_cases(core, rnn, dict(pp="identity", traj=t2, w=w2), molecule_case(10, 300, seed=21))
@@ -407,6 +425,7 @@ def main():
         run_ae_train(core, rnn, "train_ae_mol22", mol22, [66, 20, 20, 20, 2], [2, 10, 10, 66], dtype, 1e-3, 64, 3, 302)
     torch.set_default_dtype(torch.float32)
     run_regae_cases(core, rnn, id2, mol10)
+    run_regae_eta_cases(core, rnn, id2, mol10)
 
 
 if __name__ == "__main__":
