@@ -165,3 +165,46 @@ def require_gpu(device):
         raise RuntimeError("colvarsfinder: no HIP device visible")
     lib()
     return device
+
+
+def upload_f32(a, device, chunk_bytes=64 << 20):
+    """Host array -> contiguous fp32 device tensor (trajectory ingestion into the HBM-resident shard).
+
+    A pageable ``tensor.to(device)`` stages through the driver's own bounce buffer.  Here an fp32 C-contiguous source is
+    page-locked in place (``hipHostRegister``) and copied by one DMA; anything else (fp64 text trajectories, strided
+    arrays) is converted chunk by chunk into two pinned staging buffers whose copies run on a side stream while the
+    next chunk is converted.  Small arrays take the plain path."""
+    t = torch.as_tensor(a)
+    if t.is_cuda:
+        return t.to(device=device, dtype=torch.float32).contiguous()
+    n = t.numel()
+    if n * 4 <= (8 << 20) or not torch.cuda.is_available():
+        return t.to(dtype=torch.float32).contiguous().to(device)
+    out = torch.empty(tuple(t.shape), device=device, dtype=torch.float32)
+    if t.dtype == torch.float32 and t.is_contiguous():
+        rt = torch.cuda.cudart()
+        if int(rt.cudaHostRegister(t.data_ptr(), n * 4, 0)) == 0:
+            try:
+                out.copy_(t, non_blocking=True)
+                torch.cuda.current_stream(device).synchronize()
+            finally:
+                rt.cudaHostUnregister(t.data_ptr())
+            return out
+    src, dst = t.reshape(-1), out.reshape(-1)
+    ce = max(1, chunk_bytes // 4)
+    bufs = [torch.empty(ce, dtype=torch.float32).pin_memory() for _ in range(2)]
+    done = [None, None]
+    side = torch.cuda.Stream(device)
+    for i, s0 in enumerate(range(0, n, ce)):
+        e0, b = min(s0 + ce, n), bufs[i % 2]
+        if done[i % 2] is not None:
+            done[i % 2].synchronize()            # the copy that last used this staging buffer has finished
+        b[:e0 - s0].copy_(src[s0:e0])            # host side: gather / convert into page-locked memory
+        with torch.cuda.stream(side):
+            dst[s0:e0].copy_(b[:e0 - s0], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            done[i % 2] = ev
+    torch.cuda.current_stream(device).wait_stream(side)
+    side.synchronize()
+    return out

@@ -336,7 +336,7 @@ class EigenFunctionTask(TrainingTask):
 
         # the trajectory shard and its weights stay resident in HBM (core.py:343-344 keeps CPU copies)
         traj = np.asarray(traj_obj.trajectory)
-        self._traj = torch.as_tensor(traj).to(device=self.device, dtype=torch.float32).contiguous()
+        self._traj = _hip.upload_f32(traj, self.device)
         self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
         self.tot_dim = int(traj[0, ...].size)
         self._beta = beta
@@ -656,7 +656,7 @@ class AutoEncoderTask(TrainingTask):
         self.init_model_and_optimizer()
         traj = np.asarray(traj_obj.trajectory)
         self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
-        X = torch.as_tensor(traj).to(device=self.device, dtype=torch.float32).contiguous()
+        X = _hip.upload_f32(traj, self.device)
         pp = self._pp_desc(int(traj[0, ...].size))
         n = X.shape[0]
         self._feature_traj = torch.empty(n, pp.d_r, device=self.device, dtype=torch.float32)       # core.py:635
@@ -956,7 +956,7 @@ class RegAutoEncoderTask(TrainingTask):
         self.optimizer = _FusedOptimizer(self._flat, self.optimizer_name, self.learning_rate)
 
     def _features(self, X):
-        X = torch.as_tensor(X).detach().to(device=self.device, dtype=torch.float32).contiguous()
+        X = _hip.upload_f32(torch.as_tensor(X).detach(), self.device)
         n = X.shape[0]
         out = torch.empty(n, self._pp.d_r, device=self.device, dtype=torch.float32)
         _hip.check(_hip.lib().cvf_align_feature_fwd(self._pp, _hip.ptr(X), n, None, _hip.ptr(out), None,
