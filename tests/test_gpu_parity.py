@@ -9,6 +9,8 @@ differs from its fp64 run by 6.6e-6..6.4e-5 relative, so
   * against the fp32 fixtures the bar is RTOL32 = 2e-4 (the reference's own fp32 noise on top).
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -589,3 +591,22 @@ def test_generator_step_ragged_batches_vs_oracle(dev, B, k):
     want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
     got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(dev):
+    """SURVEY 8e on the real kernels: the same training as one process and as two ranks (gloo group, both on cuda:0) - sharded
+    batches, all-reduce of the sums before the backward pass, all-reduce of the gradient, identical Adam.  tools/check_dp2.py
+    runs generator mode, transfer mode and the autoencoder and compares every step's loss and the final parameters."""
+    import json
+    import subprocess
+    import sys
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_gloo_available():
+        pytest.skip("gloo not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "check_dp2.py")], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    rep = json.loads(res.stdout.strip().splitlines()[-1])
+    assert rep["ok"], rep
+    for kind in ("gen", "tr", "ae"):
+        assert rep[kind]["max_rel_loss_diff"] < 2e-4, rep
