@@ -24,6 +24,49 @@ __device__ __forceinline__ V3 centred(const float* my, int a, const Centre& c) {
 }
 
 
+// 3x3 products in packed fp32 (v_pk_fma_f32: two results per instruction; a third of the passes' vector instructions)
+struct MatCols {   // y = M v:  (y0, y1) accumulate column pairs of rows 0 and 1, y2 the third row
+  f2 c0, c1, c2;
+  float r0, r1, r2;
+};
+__device__ __forceinline__ MatCols mat_cols(const float* M) {
+  return MatCols{f2{M[0], M[3]}, f2{M[1], M[4]}, f2{M[2], M[5]}, M[6], M[7], M[8]};
+}
+__device__ __forceinline__ void mat_times_acc(const MatCols& m, V3 v, f2& yxy, float& yz) {
+  yxy = fma2(splat2(v.x), m.c0, fma2(splat2(v.y), m.c1, fma2(splat2(v.z), m.c2, yxy)));
+  yz = fmaf(v.x, m.r0, fmaf(v.y, m.r1, fmaf(v.z, m.r2, yz)));
+}
+struct MatRows {   // y = v^T M (row vector times matrix): (y0, y1) accumulate the row pairs (M[3i], M[3i+1]), y2 column 2
+  f2 r0, r1, r2;
+  float c0, c1, c2;
+};
+__device__ __forceinline__ MatRows mat_rows(const float* M) {
+  return MatRows{f2{M[0], M[1]}, f2{M[3], M[4]}, f2{M[6], M[7]}, M[2], M[5], M[8]};
+}
+__device__ __forceinline__ void row_times_acc(const MatRows& m, V3 v, f2& yxy, float& yz) {
+  yxy = fma2(splat2(v.x), m.r0, fma2(splat2(v.y), m.r1, fma2(splat2(v.z), m.r2, yxy)));
+  yz = fmaf(v.x, m.c0, fmaf(v.y, m.c1, fmaf(v.z, m.c2, yz)));
+}
+// outer-product accumulation  A[i][0..1] += a_i (b0, b1),  A[i][2] += a_i b2
+struct Outer3 {
+  f2 xy[3];
+  float z[3];
+};
+__device__ __forceinline__ void outer_acc(Outer3& A, V3 a, V3 b) {
+  const f2 b01 = f2{b.x, b.y};
+  A.xy[0] = fma2(splat2(a.x), b01, A.xy[0]); A.z[0] = fmaf(a.x, b.z, A.z[0]);
+  A.xy[1] = fma2(splat2(a.y), b01, A.xy[1]); A.z[1] = fmaf(a.y, b.z, A.z[1]);
+  A.xy[2] = fma2(splat2(a.z), b01, A.xy[2]); A.z[2] = fmaf(a.z, b.z, A.z[2]);
+}
+__device__ __forceinline__ void outer_to_array(const Outer3& A, float (&M)[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    M[3 * i] = A.xy[i].x;
+    M[3 * i + 1] = A.xy[i].y;
+    M[3 * i + 2] = A.z[i];
+  }
+}
+
 constexpr int kGChunk = 8;   // atoms per prefetch chunk of pass 1
 
 // Fused first stage of K5: every block also reduces its tile's contribution to the batch sums of
@@ -59,18 +102,17 @@ __device__ __forceinline__ void metric_pure_passes(const cvf_pp_desc& pp, int la
   for (int i = 0; i < 6; ++i) Kinv[i] = auxv[12 + i];
   CVF_STAMP(10);
   // pass 1
-  V3 sump = v3(0, 0, 0);
-  float M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const MatCols Rc = mat_cols(R);
+  f2 sump_xy = {0.0f, 0.0f};
+  float sump_z = 0.0f;
+  Outer3 Mo = {{{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}}, {0.0f, 0.0f, 0.0f}};
   if (G_IN_LDS) {
     // g was left in the image by the forward part of the same wave: plain LDS reads, nothing to prefetch or store
 #pragma unroll 4
     for (int at = 0; at < N; ++at) {
       const V3 g = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
-      sump = sump + mat_times(R, g);
-      const V3 xc = centred(my, at, c);
-      M[0] += xc.x * g.x; M[1] += xc.x * g.y; M[2] += xc.x * g.z;
-      M[3] += xc.y * g.x; M[4] += xc.y * g.y; M[5] += xc.y * g.z;
-      M[6] += xc.z * g.x; M[7] += xc.z * g.y; M[8] += xc.z * g.z;
+      mat_times_acc(Rc, g, sump_xy, sump_z);
+      outer_acc(Mo, centred(my, at, c), g);
     }
   } else {
     float nxt[3 * kGChunk];
@@ -93,17 +135,17 @@ __device__ __forceinline__ void metric_pure_passes(const cvf_pp_desc& pp, int la
         Ul[(3 * at + 1) * CVF_TILE] = g.y;
         Ul[(3 * at + 2) * CVF_TILE] = g.z;
         const V3 gm = m * g;
-        sump = sump + mat_times(R, gm);
-        const V3 xc = centred(my, at, c);
-        M[0] += xc.x * gm.x; M[1] += xc.x * gm.y; M[2] += xc.x * gm.z;
-        M[3] += xc.y * gm.x; M[4] += xc.y * gm.y; M[5] += xc.y * gm.z;
-        M[6] += xc.z * gm.x; M[7] += xc.z * gm.y; M[8] += xc.z * gm.z;
+        mat_times_acc(Rc, gm, sump_xy, sump_z);
+        outer_acc(Mo, centred(my, at, c), gm);
       }
   #pragma unroll
       for (int i = 0; i < 3 * kGChunk; ++i) cur[i] = nxt[i];
     }
   }
   CVF_STAMP(11);
+  const V3 sump = v3(sump_xy.x, sump_xy.y, sump_z);
+  float M[9];
+  outer_to_array(Mo, M);
   float T[9], Z[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -120,35 +162,50 @@ __device__ __forceinline__ void metric_pure_passes(const cvf_pp_desc& pp, int la
   const V3 shift = inv_nal * sump;
   CVF_STAMP(12);
   // pass 2: align atoms first (they carry the rotation's and the centroid's derivative), then the rest
-  float E = 0.0f;
-  V3 usum = v3(0, 0, 0), rsum = v3(0, 0, 0);
-  float dH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const MatCols Zc = mat_cols(Z);
+  f2 E2 = {0.0f, 0.0f};
+  float Ez = 0.0f;
+  f2 usum_xy = {0.0f, 0.0f}, rsum_xy = {0.0f, 0.0f};
+  float usum_z = 0.0f, rsum_z = 0.0f;
+  Outer3 dHo = {{{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}}, {0.0f, 0.0f, 0.0f}};
+  const f2 nshift_xy = f2{-shift.x, -shift.y};
 #pragma unroll 4
   for (int at = 0; at < nal; ++at) {
     const V3 g = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
     const V3 rf = v3(refL[3 * at], refL[3 * at + 1], refL[3 * at + 2]);
-    const V3 G = mat_times(R, g) + (mat_times(Z, rf) - shift);
-    const V3 u = v3(aL[3 * at] * G.x, aL[3 * at + 1] * G.y, aL[3 * at + 2] * G.z);
-    E += u.x * G.x + u.y * G.y + u.z * G.z;
-    Ul[(3 * at) * CVF_TILE] = u.x;
-    Ul[(3 * at + 1) * CVF_TILE] = u.y;
-    Ul[(3 * at + 2) * CVF_TILE] = u.z;
-    usum = usum + u;
-    rsum = rsum + rf;
-    dH[0] += u.x * rf.x; dH[1] += u.x * rf.y; dH[2] += u.x * rf.z;
-    dH[3] += u.y * rf.x; dH[4] += u.y * rf.y; dH[5] += u.y * rf.z;
-    dH[6] += u.z * rf.x; dH[7] += u.z * rf.y; dH[8] += u.z * rf.z;
+    f2 Gxy = nshift_xy;            // G = R g + (Z rf - shift)
+    float Gz = -shift.z;
+    mat_times_acc(Rc, g, Gxy, Gz);
+    mat_times_acc(Zc, rf, Gxy, Gz);
+    const f2 uxy = f2{aL[3 * at], aL[3 * at + 1]} * Gxy;
+    const float uz = aL[3 * at + 2] * Gz;
+    E2 = fma2(uxy, Gxy, E2);
+    Ez = fmaf(uz, Gz, Ez);
+    Ul[(3 * at) * CVF_TILE] = uxy.x;
+    Ul[(3 * at + 1) * CVF_TILE] = uxy.y;
+    Ul[(3 * at + 2) * CVF_TILE] = uz;
+    usum_xy += uxy; usum_z += uz;
+    rsum_xy += f2{rf.x, rf.y}; rsum_z += rf.z;
+    outer_acc(dHo, v3(uxy.x, uxy.y, uz), rf);
   }
 #pragma unroll 4
   for (int at = nal; at < N; ++at) {
     const V3 g = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
-    const V3 G = mat_times(R, g);
-    const V3 u = v3(aL[3 * at] * G.x, aL[3 * at + 1] * G.y, aL[3 * at + 2] * G.z);
-    E += u.x * G.x + u.y * G.y + u.z * G.z;
-    Ul[(3 * at) * CVF_TILE] = u.x;
-    Ul[(3 * at + 1) * CVF_TILE] = u.y;
-    Ul[(3 * at + 2) * CVF_TILE] = u.z;
+    f2 Gxy = {0.0f, 0.0f};
+    float Gz = 0.0f;
+    mat_times_acc(Rc, g, Gxy, Gz);
+    const f2 uxy = f2{aL[3 * at], aL[3 * at + 1]} * Gxy;
+    const float uz = aL[3 * at + 2] * Gz;
+    E2 = fma2(uxy, Gxy, E2);
+    Ez = fmaf(uz, Gz, Ez);
+    Ul[(3 * at) * CVF_TILE] = uxy.x;
+    Ul[(3 * at + 1) * CVF_TILE] = uxy.y;
+    Ul[(3 * at + 2) * CVF_TILE] = uz;
   }
+  const float E = (E2.x + E2.y) + Ez;
+  const V3 usum = v3(usum_xy.x, usum_xy.y, usum_z), rsum = v3(rsum_xy.x, rsum_xy.y, rsum_z);
+  float dH[9];
+  outer_to_array(dHo, dH);
   CVF_STAMP(13);
   e_tiled[(tile * k + net) * CVF_TILE + lane] = E;
   if (fuse.on) {
@@ -186,13 +243,17 @@ __device__ __forceinline__ void metric_pure_passes(const cvf_pp_desc& pp, int la
   }
   CVF_STAMP(14);
   // pass 3
+  const MatRows Rr = mat_rows(R), dRr = mat_rows(dR);
 #pragma unroll 4
   for (int at = 0; at < N; ++at) {
     const V3 u = v3(Ul[(3 * at) * CVF_TILE], Ul[(3 * at + 1) * CVF_TILE], Ul[(3 * at + 2) * CVF_TILE]);
-    const V3 qa = row_times(u - ubar, R) + row_times(centred(my, at, c), dR);
-    qt[(3 * at) * CVF_TILE] = qa.x;
-    qt[(3 * at + 1) * CVF_TILE] = qa.y;
-    qt[(3 * at + 2) * CVF_TILE] = qa.z;
+    f2 qxy = {0.0f, 0.0f};
+    float qz = 0.0f;
+    row_times_acc(Rr, u - ubar, qxy, qz);
+    row_times_acc(dRr, centred(my, at, c), qxy, qz);
+    qt[(3 * at) * CVF_TILE] = qxy.x;
+    qt[(3 * at + 1) * CVF_TILE] = qxy.y;
+    qt[(3 * at + 2) * CVF_TILE] = qz;
   }
   CVF_STAMP(15);
 }
