@@ -673,6 +673,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
 #pragma unroll
       for (int i = 0; i < CVF_AUX_ROWS; ++i) ax[i * CVF_TILE] = auxv[i];
     }
+    CVF_STAMP(60);
     float* ft = feat + tile * (int64_t)D * CVF_TILE + lane;
 #pragma unroll 2
     for (int at = wave; at < pp.n_rec; at += nw) {
@@ -684,6 +685,7 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
       ft[(3 * at + 1) * CVF_TILE] = al.y;
       ft[(3 * at + 2) * CVF_TILE] = al.z;
     }
+    CVF_STAMP(61);
     lds_barrier();   // the feature image is complete
     CVF_STAMP(54);
     in_lane = Ub + fo;

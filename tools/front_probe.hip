@@ -57,8 +57,8 @@ int main(int argc, char** argv) {
   printf("front launch B=%lld: %.1f us (back-to-back)\n", (long long)B, 1e3 * ms / 20);
   std::vector<unsigned long long> st(64 * 4096);
   (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
-  const int ids[] = {50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 10, 11, 12, 13, 14, 15};
-  const char* nm[] = {"", "stage tile + tables", "covariance (split) + exchange", "solve", "features + barrier", "forward operand loads issued", "layer 0", "hidden layers, y, hand-off", "d chain", "barrier + g -> LDS", "barrier, y exchange", "pass 1", "Z", "pass 2", "sums + dR", "pass 3"};
+  const int ids[] = {50, 51, 52, 53, 60, 61, 54, 55, 56, 57, 58, 59, 10, 11, 12, 13, 14, 15};
+  const char* nm[] = {"", "stage tile + tables", "covariance (split) + exchange", "solve", "aux rows stored", "features", "barrier", "forward operand loads issued", "layer 0", "hidden layers, y, hand-off", "d chain", "barrier + g -> LDS", "barrier, y exchange", "pass 1", "Z", "pass 2", "sums + dR", "pass 3"};
   const int NS = sizeof(ids) / sizeof(ids[0]);
   std::vector<double> acc(NS, 0.0); int cnt = 0;
   for (int b = 0; b < T && b < 2000; ++b) {
