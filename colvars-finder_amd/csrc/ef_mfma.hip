@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
         }
       }
       init_bias<H, FT>(t[0], nullptr, q);
-      layer0_apply<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane);   // (deeper chunks: more spills, no gain)
+      layer0_apply<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane);   // (batches of 4 / 6 / 9 k-steps: 20.1 / 20.6 / 22.0 k cycles for this phase against 18.3 k - spills)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
