@@ -135,7 +135,7 @@ struct AeReg {
   const double* enc_coef;   // backward pass: [gS1(k), gS2(k*k)] of eta_1 norm + eta_2 orth penalties (NULL: off)
 };
 
-__global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
+__global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                        const float* __restrict__ feat_rows, const int64_t* __restrict__ idx,
                                                        int64_t B, const float* __restrict__ w, double inv_wsum, int with_grad,
                                                        float* __restrict__ slab, double* __restrict__ partial,
@@ -433,11 +433,6 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
                 const int i = 16 * rt + 4 * kq + r;
                 if (i < din) {
                   float v = acc[t][r];
-                  if (add_enc) {   // d (eta_1 norm + eta_2 orth) / d latent_i of this frame: w (gS1_i + sum_j c_ij gS2_ij e_j)
-                    double a = reg.enc_coef[i];
-                    for (int j = 0; j < din; ++j) a += (j == i ? 2.0 : 1.0) * reg.enc_coef[din + i * din + j] * (double)al[j * AP + fcol];
-                    v += (float)((double)wraw * a);
-                  }
                   if (act) {
                     const float a = al[i * AP + fcol];
                     v *= 1.0f - a * a;
@@ -446,6 +441,16 @@ __global__ __launch_bounds__(256) void ae_mfma_kernel(cvf_mlp_desc mlp, const fl
                 }
               }
             }
+          }
+        }
+        if (add_enc) {
+          // + d (eta_1 norm + eta_2 orth) / d latent_i of this frame: w (gS1_i + sum_j c_ij gS2_ij e_j); the latent layer has
+          // no activation (host check), so the term adds to zbar as it stands.  Kept out of the loops above: inside them it
+          // cost the plain autoencoder 28 registers and its second workgroup per CU.
+          for (int i = kq; i < din; i += 4) {
+            double a = reg.enc_coef[i];
+            for (int j = 0; j < din; ++j) a += (j == i ? 2.0 : 1.0) * reg.enc_coef[din + i * din + j] * (double)al[j * AP + fcol];
+            Zn[i * AP + fcol] += (float)((double)wraw * a);
           }
         }
         float* t = Zc;
@@ -581,6 +586,7 @@ static int regae_launch(const cvf_mlp_desc* mlp, const float* theta, const float
   if (reg.enc_tiled != nullptr || reg.enc_coef != nullptr) {
     CVF_REQUIRE(reg.enc_layer >= 1 && reg.enc_layer < mlp->n_layers, "cvf_regae: n_enc_layers=%d out of range", reg.enc_layer);
     reg.k_enc = mlp->dims[reg.enc_layer];
+    CVF_REQUIRE(mlp->act[reg.enc_layer - 1] == 0, "cvf_regae: the encoder's last layer must have no activation");
     CVF_REQUIRE(reg.k_enc <= CVF_MAX_NETS, "cvf_regae: latent width %d > %d", reg.k_enc, CVF_MAX_NETS);
   }
   const AeMLayout lay = ae_mlayout(*mlp, with_grad);
