@@ -22,13 +22,21 @@ __device__ __forceinline__ AdamScalars adam_scalars(const AdamDev& a) {
 }
 // torch.optim.Adam (single-tensor path): m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
 // theta -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-__device__ __forceinline__ void adam_apply(const AdamDev& a, const AdamScalars& sc, const cvf_mlp_desc& mlp, int64_t i, float g) {
-  const float mi = a.m[i] + (g - a.m[i]) * (1.0f - a.b1);
-  const float vi = a.b2 * a.v[i] + (1.0f - a.b2) * g * g;
+// (m0, v0, th0: the parameter's state, which a caller may have requested long before the gradient is known)
+__device__ __forceinline__ void adam_apply(const AdamDev& a, const AdamScalars& sc, const PackTab& tab, int64_t i, float g,
+                                           float m0, float v0, float th0) {
+  // (explicit fused multiply-adds: left to the compiler, the contraction of these expressions depends on the surrounding
+  //  kernel, and the stand-alone and the fused update must agree bit for bit)
+  const float mi = fmaf(g - m0, 1.0f - a.b1, m0);
+  const float g2 = ((1.0f - a.b2) * g) * g;
+  const float vi = fmaf(a.b2, v0, g2);
   a.m[i] = mi;
   a.v[i] = vi;
   const float denom = sqrtf(vi) / sc.bc2_sqrt + a.eps;
-  const float th = a.theta[i] - sc.step_size * (mi / denom);
+  const float th = fmaf(-sc.step_size, mi / denom, th0);
   a.theta[i] = th;
-  if (a.packed != nullptr) pack_scatter(mlp, (int)i, th, a.packed);
+  if (a.packed != nullptr) pack_scatter(tab, (int)i, th, a.packed);
+}
+__device__ __forceinline__ void adam_apply(const AdamDev& a, const AdamScalars& sc, const PackTab& tab, int64_t i, float g) {
+  adam_apply(a, sc, tab, i, g, a.m[i], a.v[i], a.theta[i]);
 }

@@ -33,15 +33,38 @@ __host__ __device__ inline void hid_row_slot(int o, int& rt, int& rho) {
   rt = g >> 2;
   rho = 4 * qq + (g & 3);
 }
+// The nets' offset table for pack_scatter, kept in LDS: indexed with a run-time (net, layer), the by-value kernel argument
+// turns into a private (scratch-memory) copy and ~700 cycles per access - the serial part of the reduce + Adam kernel.
+struct PackTab {
+  int n_nets, NH, H, D;
+  int w[CVF_MAX_NETS][CVF_MAX_LAYERS];
+  int bend[CVF_MAX_NETS];   // last parameter of net n
+};
+// one thread, constant indices only (scalar loads from the kernel arguments); callers follow with a barrier
+__device__ __forceinline__ void pack_tab_fill(PackTab& t, const cvf_mlp_desc& mlp) {
+  t.n_nets = mlp.n_nets;
+  t.NH = mlp.n_layers - 1;
+  t.H = mlp.dims[1];
+  t.D = mlp.dims[0];
+#pragma unroll
+  for (int n = 0; n < CVF_MAX_NETS; ++n) {
+#pragma unroll
+    for (int l = 0; l < CVF_MAX_LAYERS; ++l) t.w[n][l] = mlp.w_off[n][l];
+    int be = 0;
+#pragma unroll
+    for (int l = 0; l < CVF_MAX_LAYERS; ++l) be = (l == mlp.n_layers - 1) ? mlp.b_off[n][l] : be;
+    t.bend[n] = be;
+  }
+}
 // scatter parameter p (new value v) of the flat buffer into its fragment slots
-__device__ __forceinline__ void pack_scatter(const cvf_mlp_desc& mlp, int p, float v, float* __restrict__ packed) {
-  const int NH = mlp.n_layers - 1, H = mlp.dims[1], D = mlp.dims[0];
+__device__ __forceinline__ void pack_scatter(const PackTab& t, int p, float v, float* __restrict__ packed) {
+  const int NH = t.NH, H = t.H, D = t.D;
   const PackLayout L = pack_layout(H, NH, D);
-  for (int n = 0; n < mlp.n_nets; ++n) {
-    if (p < mlp.w_off[n][0] || p > mlp.b_off[n][NH]) continue;
+  for (int n = 0; n < t.n_nets; ++n) {
+    if (p < t.w[n][0] || p > t.bend[n]) continue;
     float* base = packed + (int64_t)n * L.per_net;
     {
-      const int rel = p - mlp.w_off[n][0];
+      const int rel = p - t.w[n][0];
       if (rel >= 0 && rel < H * D) {
         const int o = rel / D, i = rel - o * D;
         int rt, rho;
@@ -52,7 +75,7 @@ __device__ __forceinline__ void pack_scatter(const cvf_mlp_desc& mlp, int p, flo
       }
     }
     for (int l = 1; l < NH; ++l) {
-      const int rel = p - mlp.w_off[n][l];
+      const int rel = p - t.w[n][l];
       if (rel >= 0 && rel < H * H) {
         const int o = rel / H, i = rel - o * H;
         int rt, rho;

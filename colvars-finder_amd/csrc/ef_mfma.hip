@@ -1393,40 +1393,57 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
   CVF_STAMP(18);
 }
 
-// grad[p] = sum over slab rows, fixed order: 16 row groups (strided) per parameter, then the 16
+// grad[p] = sum over slab rows, fixed order: 32 row groups (strided) per parameter, then the 32
 // sub-sums in sequence -> bitwise reproducible without atomics.  With `adam` set (single-process runs:
 // no cross-rank reduction of the gradient in between) the same thread applies the Adam update.
-__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nrows, int P,
-                                                            float* __restrict__ grad, const float* __restrict__ mask,
-                                                            int use_adam, AdamDev adam, cvf_mlp_desc mlp) {
-  __shared__ float sub[16][64];
+constexpr int kSlabPX = 32, kSlabGY = 32, kSlabU = 10;   // parameters per block, row groups, loads in flight per thread
+__global__ __launch_bounds__(kSlabPX * kSlabGY) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nrows, int P,
+                                                                        float* __restrict__ grad, const float* __restrict__ mask,
+                                                                        int use_adam, AdamDev adam, cvf_mlp_desc mlp) {
+  __shared__ float sub[kSlabGY][kSlabPX];
+  __shared__ PackTab tab;
   const int px = threadIdx.x, gy = threadIdx.y;
-  const int p = blockIdx.x * 64 + px;
-  // eight independent loads in flight per thread (two left every thread with ~10 dependent round trips at 313 rows);
-  // rows past the end re-read the last row of the group with weight 0: no branch around the loads
-  float a8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  if (p < P) {
-    for (int64_t g0 = gy; g0 < nrows; g0 += 16 * 8) {
-      float v[8];
+  __shared__ AdamScalars scal;
+  // the offset table and the step's bias corrections (two fp64 pow calls) are prepared by idle lanes while the rows load
+  if (use_adam && adam.packed != nullptr && px == 0 && gy == 1) pack_tab_fill(tab, mlp);
+  if (use_adam && px == 0 && gy == 2) scal = adam_scalars(adam);
+  const int p = blockIdx.x * kSlabPX + px;
+  // kSlabU independent loads in flight per thread (two left every thread with ~10 dependent round trips at 313 rows; with
+  // 32 row groups a 20 000-frame batch is one round); rows past the end re-read the group's first row with weight 0: no
+  // branch around the loads
+  float m0 = 0.0f, v0 = 0.0f, th0 = 0.0f;   // the optimiser state of this thread's parameter, requested with the rows
+  if (use_adam && gy == 0 && p < P) {
+    m0 = adam.m[p];
+    v0 = adam.v[p];
+    th0 = adam.theta[p];
+  }
+  float au[kSlabU];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t g = g0 + 16 * u;
+  for (int u = 0; u < kSlabU; ++u) au[u] = 0.0f;
+  if (p < P) {
+    for (int64_t g0 = gy; g0 < nrows; g0 += kSlabGY * kSlabU) {
+      float v[kSlabU];
+#pragma unroll
+      for (int u = 0; u < kSlabU; ++u) {
+        const int64_t g = g0 + kSlabGY * u;
         v[u] = slab[(g < nrows ? g : g0) * P + p];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a8[u] += (g0 + 16 * u < nrows) ? v[u] : 0.0f;
+      for (int u = 0; u < kSlabU; ++u) au[u] += (g0 + kSlabGY * u < nrows) ? v[u] : 0.0f;
     }
   }
-  const float acc0 = (a8[0] + a8[1]) + (a8[2] + a8[3]), acc1 = (a8[4] + a8[5]) + (a8[6] + a8[7]);
-  sub[gy][px] = acc0 + acc1;
+  float acc = 0.0f;
+#pragma unroll
+  for (int u = 0; u < kSlabU; ++u) acc += au[u];
+  sub[gy][px] = acc;
   __syncthreads();
   if (gy == 0 && p < P) {
     float s = 0.0f;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) s += sub[t][px];
+    for (int t = 0; t < kSlabGY; ++t) s += sub[t][px];
     if (mask != nullptr) s *= mask[p];   // structural zeros of block-structured layers / frozen parameters
     grad[p] = s;
-    if (use_adam) adam_apply(adam, adam_scalars(adam), mlp, p, s);
+    if (use_adam) adam_apply(adam, scal, tab, p, s, m0, v0, th0);
   }
 }
 
@@ -1463,8 +1480,11 @@ bool ef_dispatch(int H, int NH, F&& f) {
 }  // namespace
 
 __global__ void ef_pack_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta, float* __restrict__ packed) {
+  __shared__ PackTab tab;
+  if (threadIdx.x == 0) pack_tab_fill(tab, mlp);
+  __syncthreads();
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < mlp.n_params) pack_scatter(mlp, p, theta[p], packed);
+  if (p < mlp.n_params) pack_scatter(tab, p, theta[p], packed);
 }
 
 extern "C" int64_t cvf_ef_pack_floats(const cvf_mlp_desc* mlp) {
@@ -1698,7 +1718,7 @@ int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, fl
                  adam->step_count, adam->packed};
     if (adam->packed) md = *adam->mlp;
   }
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n_params + 63) / 64)), dim3(64, 16), 0, (hipStream_t)stream, slab,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n_params + kSlabPX - 1) / kSlabPX)), dim3(kSlabPX, kSlabGY), 0, (hipStream_t)stream, slab,
                      n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md);
   return cvf_check_launch("slab_reduce_kernel");
 }

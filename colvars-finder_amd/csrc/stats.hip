@@ -134,17 +134,24 @@ __global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, i
 }
 
 __global__ void adam_kernel(AdamDev a, const float* __restrict__ grad, int64_t n, cvf_mlp_desc mlp) {
-  const AdamScalars sc = adam_scalars(a);
+  __shared__ PackTab tab;
+  __shared__ AdamScalars sc;
+  if (threadIdx.x == 0 && a.packed != nullptr) pack_tab_fill(tab, mlp);
+  if (threadIdx.x == 64 % blockDim.x) sc = adam_scalars(a);
+  __syncthreads();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    adam_apply(a, sc, mlp, i, grad[i]);
+    adam_apply(a, sc, tab, i, grad[i]);
 }
 
 __global__ void sgd_kernel(float* __restrict__ theta, const float* __restrict__ grad, int64_t n, float lr, cvf_mlp_desc mlp,
                            float* __restrict__ packed) {
+  __shared__ PackTab tab;
+  if (threadIdx.x == 0 && packed != nullptr) pack_tab_fill(tab, mlp);
+  __syncthreads();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float th = theta[i] - lr * grad[i];
     theta[i] = th;
-    if (packed != nullptr) pack_scatter(mlp, (int)i, th, packed);
+    if (packed != nullptr) pack_scatter(tab, (int)i, th, packed);
   }
 }
 
