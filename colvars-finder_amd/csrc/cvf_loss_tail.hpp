@@ -25,32 +25,38 @@ __device__ void ef_loss_tail(const cvf_ef_cfg& cfg, const double* __restrict__ s
         s2[i][j] = s2[j][i] = S2[p++];
       }
   }
+  // (one reciprocal of W, one of each denominator: the dozen fp64 divisions this replaces were a dependent chain of
+  //  ~200 cycles each in a single thread that the whole step waits for)
+  const double iW = 1.0 / W;
   for (int i = 0; i < k; ++i) {
-    m[i] = S1[i] / W;                       // core.py:409
-    v[i] = s2[i][i] / W - m[i] * m[i];      // core.py:410
+    m[i] = S1[i] * iW;                      // core.py:409
+    v[i] = s2[i][i] * iW - m[i] * m[i];     // core.py:410
   }
-  __shared__ double eig[KT], num[KT], den[KT];
+  __shared__ double eig[KT], num[KT], den[KT], iden[KT];
   double pref;
   __shared__ double vl[KT], ml[KT];
   double Wl = 1.0;
   const int o = 1 + k + npair;
   if (cfg.lag_idx == 0) {
-    pref = 1.0 / (W * cfg.beta);            // core.py:426,438
+    pref = iW / cfg.beta;                   // core.py:426,438
     for (int i = 0; i < k; ++i) {
       num[i] = stats[o + i];
       den[i] = v[i];
-      eig[i] = pref * num[i] / den[i];
+      iden[i] = 1.0 / den[i];
+      eig[i] = pref * num[i] * iden[i];
     }
   } else {
     Wl = stats[o];
+    const double iWl0 = 1.0 / Wl;
     for (int i = 0; i < k; ++i) {
-      ml[i] = stats[o + 1 + i] / Wl;                          // core.py:415
-      vl[i] = stats[o + 1 + k + i] / Wl - ml[i] * ml[i];      // core.py:416
+      ml[i] = stats[o + 1 + i] * iWl0;                          // core.py:415
+      vl[i] = stats[o + 1 + k + i] * iWl0 - ml[i] * ml[i];      // core.py:416
       num[i] = stats[o + 1 + 2 * k + i];
       den[i] = v[i] + vl[i];
+      iden[i] = 1.0 / den[i];
     }
-    pref = 1.0 / (cfg.dt * cfg.lag_idx) / W;                  // core.py:428,440
-    for (int i = 0; i < k; ++i) eig[i] = pref * num[i] / den[i];
+    pref = iW / (cfg.dt * cfg.lag_idx);                       // core.py:428,440
+    for (int i = 0; i < k; ++i) eig[i] = pref * num[i] * iden[i];
   }
   // cvec = argsort(eig) (core.py:432), stable insertion sort
   __shared__ int cvec[KT];
@@ -75,9 +81,9 @@ __device__ void ef_loss_tail(const cvf_ef_cfg& cfg, const double* __restrict__ s
   for (int idx = 0; idx < k; ++idx) {
     const int c = cvec[idx];
     const int nsrc = cfg.lag_idx == 0 ? c : idx;
-    npl += cfg.eig_w[idx] * num[nsrc] / den[c];
-    gnum[nsrc] += pref * cfg.eig_w[idx] / den[c];
-    gden[c] += -pref * cfg.eig_w[idx] * num[nsrc] / (den[c] * den[c]);
+    npl += cfg.eig_w[idx] * num[nsrc] * iden[c];
+    gnum[nsrc] += pref * cfg.eig_w[idx] * iden[c];
+    gden[c] += -pref * cfg.eig_w[idx] * num[nsrc] * (iden[c] * iden[c]);
   }
   npl *= pref;
   double pen = 0.0;
@@ -85,7 +91,7 @@ __device__ void ef_loss_tail(const cvf_ef_cfg& cfg, const double* __restrict__ s
   for (int i = 0; i < k; ++i) pen += (v[i] - 1.0) * (v[i] - 1.0);           // core.py:446
   for (int i = 0; i < k; ++i)
     for (int j = i + 1; j < k; ++j) {
-      cov[i][j] = cov[j][i] = s2[i][j] / W - m[i] * m[j];                   // core.py:452
+      cov[i][j] = cov[j][i] = s2[i][j] * iW - m[i] * m[j];                  // core.py:452
       pen += cov[i][j] * cov[i][j];
     }
   const double loss = npl + cfg.alpha * pen;                                // core.py:455
@@ -104,16 +110,17 @@ __device__ void ef_loss_tail(const cvf_ef_cfg& cfg, const double* __restrict__ s
   double* gS2l = coef + 3 * k + k * k;
   for (int i = 0; i < k; ++i) {
     const double Lv = gden[i] + 2.0 * cfg.alpha * (v[i] - 1.0);   // d loss / d var_i
-    double g1 = Lv * (-2.0 * m[i] / W);
+    double g1 = Lv * (-2.0 * m[i] * iW);
     for (int j = 0; j < k; ++j)
-      if (j != i) g1 += 2.0 * cfg.alpha * cov[i][j] * (-m[j] / W);
+      if (j != i) g1 += 2.0 * cfg.alpha * cov[i][j] * (-m[j] * iW);
     gS1[i] = g1;
-    for (int j = 0; j < k; ++j) gS2[i * k + j] = (i == j) ? Lv / W : 2.0 * cfg.alpha * cov[i][j] / W;
+    for (int j = 0; j < k; ++j) gS2[i * k + j] = (i == j) ? Lv * iW : 2.0 * cfg.alpha * cov[i][j] * iW;
     gEt[i] = gnum[i];
     if (cfg.lag_idx > 0) {
       const double Lvl = gden[i];                                 // d loss / d var'_i
-      gS1l[i] = Lvl * (-2.0 * ml[i] / Wl);
-      gS2l[i] = Lvl / Wl;
+      const double iWl = 1.0 / Wl;
+      gS1l[i] = Lvl * (-2.0 * ml[i] * iWl);
+      gS2l[i] = Lvl * iWl;
     } else {
       gS1l[i] = 0.0;
       gS2l[i] = 0.0;
