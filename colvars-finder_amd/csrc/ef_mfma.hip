@@ -209,6 +209,20 @@ __device__ __forceinline__ void layer0_apply(Vec<H, FT>& X, const float* __restr
   }
 }
 
+// the same with the first chunk's operands already requested by the caller (ahead of other work)
+template <int H, int FT, int CH>
+__device__ __forceinline__ void layer0_apply_from(Vec<H, FT>& X, const float* __restrict__ pk0, int D,
+                                                  const float* __restrict__ in_lane, int lane, L0Chunk<H, FT, CH>& c0) {
+  const int S = (D + 3) >> 2;
+  L0Chunk<H, FT, CH> c1;
+  for (int s0 = 0; s0 < S; s0 += 2 * CH) {
+    load_l0chunk<H, FT, CH>(c1, pk0, D, S, in_lane, s0 + CH, lane);
+    mul_l0chunk<H, FT, CH>(X, c0);
+    load_l0chunk<H, FT, CH>(c0, pk0, D, S, in_lane, s0 + 2 * CH, lane);
+    mul_l0chunk<H, FT, CH>(X, c1);
+  }
+}
+
 // per-lane bias / last-layer weights in hidden order
 template <int H>
 struct HConst {
@@ -1181,6 +1195,10 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
           load_hfrag<H>(ffr[l - 1], pk + L.fh(l), lane);
         }
       }
+      // the tangent chain's first operands (weights, q rows) are requested before the d chain runs: one memory round trip
+      // of this wave's dependent chain overlaps that chain's matrix instructions (18.3 k -> 17.0 k cycles for this phase)
+      L0Chunk<H, FT, 3> tc0;
+      if (SAVED) load_l0chunk<H, FT, 3>(tc0, pk + L.f0(), D, (D + 3) >> 2, q_tile + fo, 0, lane);
       {
         Vec<H, FT> d;
 #pragma unroll
@@ -1201,7 +1219,10 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
         }
       }
       init_bias<H, FT>(t[0], nullptr, q);
-      layer0_apply<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane);   // (batches of 4 / 6 / 9 k-steps: 20.1 / 20.6 / 22.0 k cycles for this phase against 18.3 k - spills)
+      // (batches of 4 / 6 / 9 k-steps: 20.1 / 20.6 / 22.0 k cycles for this phase against 18.3 k - spills; requesting the
+      //  first layer's first column tile of B operands at the end of the layer-1 step: 73.7 k vs 69.0 k cycles in all - spills)
+      if (SAVED) layer0_apply_from<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane, tc0);
+      else layer0_apply<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
