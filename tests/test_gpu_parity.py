@@ -610,3 +610,32 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(dev):
     assert rep["ok"], rep
     for kind in ("gen", "tr", "ae"):
         assert rep[kind]["max_rel_loss_diff"] < 2e-4, rep
+
+
+def test_large_batch_paths_by_duplication(dev):
+    """Size-independent check of the large-launch paths (more than 1024 tiles: streaming alignment kernel, the batch sums'
+    two-stage reduction, backward workgroups walking several tiles): a batch made of two copies of a 35 200-frame batch has
+    the same loss, eigenvalues and parameter gradient as that batch (every batch sum doubles, the loss is a ratio of sums)."""
+    from colvarsfinder import core, nn
+    n_atoms, B, k = 22, 35_200, 3
+    traj, w, ref = make_molecule_traj(n_atoms, B, seed=4242)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_atoms)))], use_angle_value=False)
+    a = torch.tensor(diag_coeff_for(n_atoms, 3), dtype=torch.float32)
+    torch.manual_seed(11)
+    model = nn.EigenFunctions([66, 20, 20, 20, 1], k)
+    task = core.EigenFunctionTask(Traj(traj[:64], w[:64], 0.5), make_layer(spec, n_atoms, dev), model, "/tmp/cvf_test", 20.0,
+                                  [1.0, 0.7, 0.4], diag_coeff=a, beta=1.0, lag_tau=0, learning_rate=1e-3, k=k, device=dev,
+                                  verbose=False, save_model_every_step=0)
+    X, W = torch.tensor(traj), torch.tensor(w, dtype=torch.float32)
+
+    def run(Xb, Wb):
+        loss, eig, npl, pen, cvec = task.loss_func(Xb, Wb, None, None)
+        task.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+        return np.asarray([float(loss), float(npl), float(pen)] + [float(e) for e in eig]), g, list(cvec)
+
+    v1, g1, c1 = run(X, W)
+    v2, g2, c2 = run(torch.cat([X, X]), torch.cat([W, W]))
+    assert c1 == c2
+    np.testing.assert_allclose(v2, v1, rtol=2e-6)
+    np.testing.assert_allclose(g2, g1, rtol=1e-4, atol=2e-6 * np.abs(g1).max())
