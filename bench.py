@@ -176,7 +176,7 @@ def main():
     if graphs:
         # graph replay hides the individual launches: time them with HIP events around every C-ABI call over
         # a second, eager pass of the same K steps (not part of `value`)
-        task._use_graphs, task._events = False, {}
+        task._use_graphs, task._events, task._last_call = False, {}, {}
         for i in range(args.steps):
             # park the GPU while the host queues this step's launches, so that the events bracket back-to-back
             # kernel executions rather than the host's launch latency
@@ -185,6 +185,7 @@ def main():
         barrier()
         task._use_graphs = True
     events, task._events = task._events, None
+    last_calls, task._last_call = (task._last_call or {}), None
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -197,6 +198,22 @@ def main():
     if rank != 0:
         return
     dom = max(kern_ms, key=kern_ms.get)
+    # The dominant call once more, 40 launches back to back inside ONE event pair (the GPU parked while they are queued):
+    # an event pair around a single launch also times the bracket itself (~3 us here), which is why the per-call averages
+    # above sit that much over rocprofv3's kernel durations; this figure is the one `roofline` uses.
+    dom_b2b_ms = None
+    if dom in last_calls and dom != "cvf_ef_backward":      # (the backward call advances the optimiser's step counter)
+        fn_, args_ = last_calls[dom]
+        reps_ = 40
+        torch.cuda.synchronize()
+        torch.cuda._sleep(4_000_000)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps_):
+            fn_(*args_)
+        e1.record()
+        torch.cuda.synchronize()
+        dom_b2b_ms = e0.elapsed_time(e1) / reps_
 
     def pmc_traffic(call):
         """HBM bytes per launch of the kernel behind a C-ABI call, from the committed rocprofv3 PMC passes."""
@@ -213,9 +230,12 @@ def main():
     if dom in ("cvf_ef_backward", "cvf_ef_mlp_fwd", "cvf_ef_fwd_metric_stats", "cvf_ef_align_fwd_metric_stats"):
         flop = {"cvf_ef_backward": FLOP_BWD, "cvf_ef_mlp_fwd": FLOP_FWD, "cvf_ef_fwd_metric_stats": FLOP_FWD + FLOP_METRIC,
                 "cvf_ef_align_fwd_metric_stats": FLOP_FWD + FLOP_METRIC + FLOP_K1}[dom] * B
-        ach = flop / (kern_ms[dom] * 1e-3) / 1e12
+        dom_ms = dom_b2b_ms if dom_b2b_ms is not None else kern_ms[dom]
+        ach = flop / (dom_ms * 1e-3) / 1e12
         roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS,
-                    traffic=pmc_traffic(dom), avg_launch_us=kern_ms[dom] * 1e3,
+                    traffic=pmc_traffic(dom), avg_launch_us=dom_ms * 1e3,
+                    timing=("40 back-to-back launches in one HIP-event pair" if dom_b2b_ms is not None else
+                            "HIP-event pair per launch (includes the bracket)"),
                     note="fp32 work (VALU chains + f32-input MFMA weight gradients); peak = fp32 vector = fp32 MFMA rate")
     else:
         ach = K1_BYTES * B / (kern_ms[dom] * 1e-3) / 1e9

@@ -187,6 +187,7 @@ class TrainingTask(ABC):
 
     # -- every kernel launch goes through here; bench.py sets ``_events`` to time launches with HIP events
     _events = None
+    _last_call = None      # with ``_events``: name -> (fn, args) of the most recent launch (bench.py re-times the dominant one)
 
     def _call(self, name, fn, *args):
         ev = self._events
@@ -196,6 +197,8 @@ class TrainingTask(ABC):
             rc = fn(*args)
             b.record()
             ev.setdefault(name, []).append((a, b))
+            if self._last_call is not None:
+                self._last_call[name] = (fn, args)
         else:
             rc = fn(*args)
         _hip.check(rc, name)
