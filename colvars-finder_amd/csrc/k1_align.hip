@@ -184,9 +184,10 @@ __global__ __launch_bounds__(64) void k1_align_kernel(cvf_pp_desc pp, const floa
 //    its own loads: 16 k of 32 k cycles at one million frames);
 //  * the reference is converted to fp64 once per wave and kept in LDS;
 //  * the row-major output (ROWS) is written over the tile in LDS and leaves as it came, in 16-byte stores.
+// Odd 3 N: the same with 4-byte reads (an odd stride is conflict-free as it is); 3 N = 0 (mod 4) keeps the one-tile kernel.
 // Frames past the last whole tile are left to k1_align_kernel.
 // ------------------------------------------------------------------------------------
-template <int NV, bool TILED, bool ROWS>
+template <int NV, bool TILED, bool ROWS, bool PAIR>
 __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t n_tiles,
                                                         float* __restrict__ feat_tiled, float* __restrict__ feat_rows,
                                                         float* __restrict__ aux_tiled) {
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const flo
     // whatever the frame's distance from the origin, so fp32 products and sums (packed, two per instruction) carry
     // the reference's own fp32 accuracy without the 3 N quarter-rate fp32 -> fp64 conversions of the fp64 pass.
     // Register pairs follow the tile: [x y] [z x'] [y' z'] per atom pair.
-    const f2 P0 = my2[0];
+    const f2 P0 = PAIR ? my2[0] : f2{my[0], my[1]};   // (an odd stride leaves odd lanes' rows 4-byte aligned only)
     const float pz = my[2];
     const f2 P1 = f2{pz, P0.x}, P2 = f2{P0.y, pz};
     f2 sA = {0, 0}, sB = {0, 0}, sC = {0, 0};
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const flo
       H01[1] = fma2(splat2(d1), r01, H01[1]); H2[1] = fmaf(d1, r.z, H2[1]);
       H01[2] = fma2(splat2(d2), r01, H01[2]); H2[2] = fmaf(d2, r.z, H2[2]);
     };
-    const int npa = pp.n_align >> 1;
+    const int npa = PAIR ? pp.n_align >> 1 : 0;   // PAIR: 3N = 2 (mod 4), 8-byte reads of atom pairs; else 3N odd, 4-byte reads
 #pragma unroll 2
     for (int m = 0; m < npa; ++m) {
       const f2 d0 = my2[3 * m] - P0, d1 = my2[3 * m + 1] - P1, d2 = my2[3 * m + 2] - P2;
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const flo
       acc(d1.y, d2.x, d2.y, ref4[2 * m + 1]);
     }
     float sx = sA.x + sB.y, sy = sA.y + sC.x, sz = sB.x + sC.y;
-    if (pp.n_align & 1) {
-      const int a = pp.n_align - 1;
+#pragma unroll 2
+    for (int a = 2 * npa; a < pp.n_align; ++a) {   // the odd last atom, or every atom when the stride is odd
       const float d0 = my[3 * a] - P0.x, d1 = my[3 * a + 1] - P0.y, d2 = my[3 * a + 2] - pz;
       sx += d0; sy += d1; sz += d2;
       acc(d0, d1, d2, ref4[a]);
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const flo
     const f2 R01 = f2{ko.R[0], ko.R[1]}, R34 = f2{ko.R[3], ko.R[4]}, R67 = f2{ko.R[6], ko.R[7]};
     auto rot_xy = [&](float a0, float a1, float a2) { return fma2(splat2(a0), R01, fma2(splat2(a1), R34, splat2(a2) * R67)); };
     auto rot_z = [&](float a0, float a1, float a2) { return fmaf(a0, ko.R[2], fmaf(a1, ko.R[5], a2 * ko.R[8])); };
-    const int npr = pp.n_rec >> 1;
+    const int npr = PAIR ? pp.n_rec >> 1 : 0;
 #pragma unroll 2
     for (int m = 0; m < npr; ++m) {
       const f2 d0 = (my2[3 * m] - P0) - C0, d1 = (my2[3 * m + 1] - P1) - C1, d2 = (my2[3 * m + 2] - P2) - C2;
@@ -312,8 +313,8 @@ __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const flo
         my2[3 * m + 2] = f2{bxy.y, bz};
       }
     }
-    if (pp.n_rec & 1) {
-      const int a = pp.n_rec - 1;
+#pragma unroll 2
+    for (int a = 2 * npr; a < pp.n_rec; ++a) {
       const float d0 = (my[3 * a] - P0.x) - cf[0], d1 = (my[3 * a + 1] - P0.y) - cf[1], d2 = (my[3 * a + 2] - pz) - cf[2];
       const f2 axy = rot_xy(d0, d1, d2);
       const float az = rot_z(d0, d1, d2);
@@ -776,7 +777,7 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
   static const bool no_stream = getenv("CVF_K1_NOSTREAM") != nullptr;
   const int nc = pp->n_coord;
   const int64_t T_full = B / CVF_TILE;
-  if (fast && !no_stream && nc % 4 == 2 && nc <= 4 * 26 && T_full > kSplitMaxTiles && (!feat_rows || pp->d_r == nc)) {
+  if (fast && !no_stream && (nc % 4 == 2 || nc % 2 == 1) && nc <= 4 * 26 && T_full > kSplitMaxTiles && (!feat_rows || pp->d_r == nc)) {
     const size_t ldss = (size_t)CVF_TILE * nc * sizeof(float) + (size_t)pp->n_align * sizeof(float4);
     auto launchs = [&](auto kernel) {
       if (ldss > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss);
@@ -787,16 +788,22 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
                          feat_tiled, feat_rows, aux_tiled);
     };
     const int nv = (nc + 3) / 4;
+#define CVF_K1_STREAM2(NV, PAIR)                                                         \
+    do {                                                                                 \
+      if (feat_tiled && feat_rows) launchs(k1_stream_kernel<NV, true, true, PAIR>);      \
+      else if (feat_tiled) launchs(k1_stream_kernel<NV, true, false, PAIR>);             \
+      else launchs(k1_stream_kernel<NV, false, true, PAIR>);                             \
+    } while (0)
 #define CVF_K1_STREAM(NV)                                                                \
     do {                                                                                 \
-      if (feat_tiled && feat_rows) launchs(k1_stream_kernel<NV, true, true>);            \
-      else if (feat_tiled) launchs(k1_stream_kernel<NV, true, false>);                   \
-      else launchs(k1_stream_kernel<NV, false, true>);                                   \
+      if (nc % 2 == 0) CVF_K1_STREAM2(NV, true);                                         \
+      else CVF_K1_STREAM2(NV, false);                                                    \
     } while (0)
     if (nv <= 8) CVF_K1_STREAM(8);
     else if (nv <= 17) CVF_K1_STREAM(17);
     else CVF_K1_STREAM(26);
 #undef CVF_K1_STREAM
+#undef CVF_K1_STREAM2
     const int rc = cvf_check_launch("k1_stream_kernel");
     const int64_t done = T_full * CVF_TILE;
     if (rc || done == B) return rc;

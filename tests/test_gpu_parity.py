@@ -86,7 +86,8 @@ def test_k1_rigid_motion_invariance_full_size(dev):
     assert float(f0.reshape(B, n_atoms, 3).sum(1).abs().max()) < 1e-4 * float(f0.abs().max()) * n_atoms
 
 
-@pytest.mark.parametrize("n_atoms,n_align,B", [(22, 22, 64 * 1100 + 37), (10, 7, 64 * 1030 + 5), (22, 22, 64 * 1025)])
+@pytest.mark.parametrize("n_atoms,n_align,B", [(22, 22, 64 * 1100 + 37), (10, 7, 64 * 1030 + 5), (22, 22, 64 * 1025), (21, 21, 64 * 1030 + 9),
+                                               (9, 6, 64 * 1026 + 1)])
 def test_k1_streaming_tiles_large_launch(dev, n_atoms, n_align, B):
     """Launches of more than 1024 tiles take the persistent streaming kernel (whole tiles) + the remainder launch:
     rows vs the oracle, tiled == rows bit for bit, rotation / centroid / K^-1 rows vs the small-launch kernel."""
