@@ -600,6 +600,28 @@ class EigenFunctionTask(TrainingTask):
         def sl(data, a, b):
             return tuple(None if t is None else t[a:b] for t in data)
 
+        ring = [dict(tr=torch.zeros(log_tr.shape, dtype=log_tr.dtype).pin_memory(), te=torch.zeros(log_te.shape, dtype=log_te.dtype).pin_memory(),
+                     ev=torch.cuda.Event(), pending=None) for _ in range(4)]
+
+        def flush(slot):
+            """Host side of one finished epoch, in order: loss_list (core.py:553), _cvec (core.py:515), the writer (core.py:559-561)."""
+            slot["ev"].synchronize()
+            ep, slot["pending"] = slot["pending"], None
+            tr, te = slot["tr"][:len(tr_batches)].clone(), slot["te"][:len(te_batches)].clone()
+            dt = torch.get_default_dtype()
+            if len(tr_batches) > 0:
+                self._cvec = tr[-1, 3 + k:].round().to(torch.long).numpy()
+            self.loss_list.append([tr[:, :3 + k].to(dt), te[:, :3 + k].to(dt)])
+            mean_tr = self.loss_list[-1][0].mean(0) if len(tr_batches) else torch.full((3 + k,), float("nan"))
+            mean_te = self.loss_list[-1][1].mean(0) if len(te_batches) else torch.full((3 + k,), float("nan"))
+            for i, name in enumerate(loss_names):
+                self.writer.add_scalar('%s/train' % name, mean_tr[i], ep)
+                self.writer.add_scalar('%s/test' % name, mean_te[i], ep)
+
+        def flush_all():
+            for slot in sorted((s_ for s_ in ring if s_["pending"] is not None), key=lambda s_: s_["pending"]):
+                flush(slot)
+
         for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
             self.model.train()
             for it, (a, b) in enumerate(tr_batches):
@@ -614,27 +636,31 @@ class EigenFunctionTask(TrainingTask):
             for it, (a, b) in enumerate(te_batches):              # core.py:535-551 (same loss, no update)
                 X, w, Xl, wl = sl(Xte, a, b)
                 self._graph_step(("test", it), lambda: self._forward(X, w, Xl, wl).loss_vec, log_te[it])
-            tr = log_tr[:len(tr_batches)].cpu()                    # the only host synchronisation of the epoch
-            te = log_te[:len(te_batches)].cpu()
-            dt = torch.get_default_dtype()
-            if len(tr_batches) > 0:
-                self._cvec = tr[-1, 3 + k:].round().to(torch.long).numpy()      # core.py:515
-            self.loss_list.append([tr[:, :3 + k].to(dt), te[:, :3 + k].to(dt)])   # core.py:553
-
-            if self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1:
+            # The epoch's losses leave the device through a small ring of pinned buffers, asynchronously: the host reads an
+            # epoch's numbers (loss_list, _cvec, the writer's scalars) up to three epochs later instead of draining the
+            # stream after every epoch - with a few steps per epoch that drain was most of the epoch.  Epochs that save or
+            # plot need the current numbers and flush first.
+            slot = ring[epoch % len(ring)]
+            if slot["pending"] is not None:
+                flush(slot)
+            slot["tr"][:len(tr_batches)].copy_(log_tr[:len(tr_batches)], non_blocking=True)
+            slot["te"][:len(te_batches)].copy_(log_te[:len(te_batches)], non_blocking=True)
+            slot["ev"].record()
+            slot["pending"] = epoch
+            saving = self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1
+            plotting = self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1
+            if saving or plotting:
+                flush_all()
+            if saving:
                 self.save_model(epoch)
-                last = float(tr[-1, 0]) if len(tr_batches) > 0 else float("inf")
+                last = float(self.loss_list[-1][0][-1, 0]) if len(tr_batches) > 0 else float("inf")
                 if last < min_loss:                                             # core.py:526-528
                     min_loss = last
                     self.save_model(epoch, 'best')
-            if self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1:
+            if plotting:
                 if self.plot_class is not None and rank == 0:
                     self.plot_class.plot(self.colvar_model(), epoch=epoch)
-            mean_tr = self.loss_list[-1][0].mean(0) if len(tr_batches) else torch.full((3 + k,), float("nan"))
-            mean_te = self.loss_list[-1][1].mean(0) if len(te_batches) else torch.full((3 + k,), float("nan"))
-            for i, name in enumerate(loss_names):                               # core.py:559-561
-                self.writer.add_scalar('%s/train' % name, mean_tr[i], epoch)
-                self.writer.add_scalar('%s/test' % name, mean_te[i], epoch)
+        flush_all()
 
         self.train_loss_df = pd.DataFrame(torch.cat([e[0].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
                                           columns=loss_names)
