@@ -73,6 +73,42 @@ def _split(n, test_ratio):
     return perm[n_test:], perm[:n_test]
 
 
+class _AsyncEpochLog:
+    """The per-epoch loss rows leave the device through a small ring of pinned buffers, asynchronously: the host side of an
+    epoch (``loss_list``, ``_cvec``, the writer's scalars - ``on_epoch(epoch, train_rows, test_rows)``) runs up to
+    ``depth - 1`` epochs later, in order, instead of draining the stream after every epoch (with a few steps per epoch that
+    drain was most of the epoch: 1.38 -> 0.54 ms per epoch at config 3).  Epochs that save or plot ``flush_all()`` first."""
+
+    def __init__(self, log_tr, log_te, n_tr, n_te, on_epoch, depth=4):
+        self.log_tr, self.log_te, self.n_tr, self.n_te, self.on_epoch = log_tr, log_te, n_tr, n_te, on_epoch
+        self.ring = [dict(tr=torch.zeros(log_tr.shape, dtype=log_tr.dtype).pin_memory(),
+                          te=torch.zeros(log_te.shape, dtype=log_te.dtype).pin_memory(), ev=torch.cuda.Event(), pending=None)
+                     for _ in range(depth)]
+
+    def _flush(self, slot):
+        slot["ev"].synchronize()
+        ep, slot["pending"] = slot["pending"], None
+        self.on_epoch(ep, slot["tr"][:self.n_tr].clone(), slot["te"][:self.n_te].clone())
+
+    def reserve(self, epoch):
+        """Finish the epoch that still occupies this epoch's ring slot (callers with side buffers of their own do this first)."""
+        slot = self.ring[epoch % len(self.ring)]
+        if slot["pending"] is not None:
+            self._flush(slot)
+        return slot
+
+    def push(self, epoch):
+        slot = self.reserve(epoch)
+        slot["tr"][:self.n_tr].copy_(self.log_tr[:self.n_tr], non_blocking=True)
+        slot["te"][:self.n_te].copy_(self.log_te[:self.n_te], non_blocking=True)
+        slot["ev"].record()
+        slot["pending"] = epoch
+
+    def flush_all(self):
+        for slot in sorted((s_ for s_ in self.ring if s_["pending"] is not None), key=lambda s_: s_["pending"]):
+            self._flush(slot)
+
+
 class _FlatParams:
     """The model's parameters as views of one fp32 device buffer (+ gradient and Adam moments)."""
 
@@ -600,14 +636,8 @@ class EigenFunctionTask(TrainingTask):
         def sl(data, a, b):
             return tuple(None if t is None else t[a:b] for t in data)
 
-        ring = [dict(tr=torch.zeros(log_tr.shape, dtype=log_tr.dtype).pin_memory(), te=torch.zeros(log_te.shape, dtype=log_te.dtype).pin_memory(),
-                     ev=torch.cuda.Event(), pending=None) for _ in range(4)]
-
-        def flush(slot):
-            """Host side of one finished epoch, in order: loss_list (core.py:553), _cvec (core.py:515), the writer (core.py:559-561)."""
-            slot["ev"].synchronize()
-            ep, slot["pending"] = slot["pending"], None
-            tr, te = slot["tr"][:len(tr_batches)].clone(), slot["te"][:len(te_batches)].clone()
+        def on_epoch(ep, tr, te):
+            """Host side of one finished epoch: loss_list (core.py:553), _cvec (core.py:515), the writer (core.py:559-561)."""
             dt = torch.get_default_dtype()
             if len(tr_batches) > 0:
                 self._cvec = tr[-1, 3 + k:].round().to(torch.long).numpy()
@@ -618,9 +648,7 @@ class EigenFunctionTask(TrainingTask):
                 self.writer.add_scalar('%s/train' % name, mean_tr[i], ep)
                 self.writer.add_scalar('%s/test' % name, mean_te[i], ep)
 
-        def flush_all():
-            for slot in sorted((s_ for s_ in ring if s_["pending"] is not None), key=lambda s_: s_["pending"]):
-                flush(slot)
+        elog = _AsyncEpochLog(log_tr, log_te, len(tr_batches), len(te_batches), on_epoch)
 
         for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
             self.model.train()
@@ -636,21 +664,11 @@ class EigenFunctionTask(TrainingTask):
             for it, (a, b) in enumerate(te_batches):              # core.py:535-551 (same loss, no update)
                 X, w, Xl, wl = sl(Xte, a, b)
                 self._graph_step(("test", it), lambda: self._forward(X, w, Xl, wl).loss_vec, log_te[it])
-            # The epoch's losses leave the device through a small ring of pinned buffers, asynchronously: the host reads an
-            # epoch's numbers (loss_list, _cvec, the writer's scalars) up to three epochs later instead of draining the
-            # stream after every epoch - with a few steps per epoch that drain was most of the epoch.  Epochs that save or
-            # plot need the current numbers and flush first.
-            slot = ring[epoch % len(ring)]
-            if slot["pending"] is not None:
-                flush(slot)
-            slot["tr"][:len(tr_batches)].copy_(log_tr[:len(tr_batches)], non_blocking=True)
-            slot["te"][:len(te_batches)].copy_(log_te[:len(te_batches)], non_blocking=True)
-            slot["ev"].record()
-            slot["pending"] = epoch
+            elog.push(epoch)        # (the host reads the epoch's numbers later; epochs that save or plot flush first)
             saving = self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1
             plotting = self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1
             if saving or plotting:
-                flush_all()
+                elog.flush_all()
             if saving:
                 self.save_model(epoch)
                 last = float(self.loss_list[-1][0][-1, 0]) if len(tr_batches) > 0 else float("inf")
@@ -660,7 +678,7 @@ class EigenFunctionTask(TrainingTask):
             if plotting:
                 if self.plot_class is not None and rank == 0:
                     self.plot_class.plot(self.colvar_model(), epoch=epoch)
-        flush_all()
+        elog.flush_all()
 
         self.train_loss_df = pd.DataFrame(torch.cat([e[0].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
                                           columns=loss_names)
@@ -788,6 +806,15 @@ class AutoEncoderTask(TrainingTask):
                   (len(idx_test), len(te_batches), len(te_batches) * self.num_epochs), flush=True)
         log_tr = torch.zeros(max(len(tr_batches), 1), device=self.device, dtype=torch.float64)
         log_te = torch.zeros(max(len(te_batches), 1), device=self.device, dtype=torch.float64)
+
+        def on_epoch(ep, tr, te):
+            dt = torch.get_default_dtype()
+            tr, te = tr.to(dt), te.to(dt)
+            self.loss_list.append([tr, te])                                        # core.py:736
+            self.writer.add_scalar('Loss/train', tr.mean() if len(tr) else float("nan"), ep)   # core.py:738-739
+            self.writer.add_scalar('Loss/test', te.mean() if len(te) else float("nan"), ep)
+
+        elog = _AsyncEpochLog(log_tr, log_te, len(tr_batches), len(te_batches), on_epoch)
         for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
             self.model.train()
             for it, (a, b) in enumerate(tr_batches):
@@ -796,20 +823,21 @@ class AutoEncoderTask(TrainingTask):
             self.model.eval()
             for it, (a, b) in enumerate(te_batches):
                 log_te[it] = self._step(self._feature_traj, ite[a:b], wte[a:b], False, iw_te[it])
-            dt = torch.get_default_dtype()
-            tr, te = log_tr[:len(tr_batches)].cpu().to(dt), log_te[:len(te_batches)].cpu().to(dt)
-            self.loss_list.append([tr, te])                                        # core.py:736
-            if self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1:
+            elog.push(epoch)
+            saving = self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1
+            plotting = self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1
+            if saving or plotting:
+                elog.flush_all()
+            if saving:
                 self.save_model(epoch)
-                last = float(tr[-1]) if len(tr) else float("inf")
+                last = float(self.loss_list[-1][0][-1]) if len(tr_batches) else float("inf")
                 if last < min_loss:
                     min_loss = last
                     self.save_model(epoch, 'best')
-            if self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1:
+            if plotting:
                 if self.plot_class is not None and rank == 0:
                     self.plot_class.plot(self.colvar_model(), epoch=epoch)
-            self.writer.add_scalar('Loss/train', tr.mean() if len(tr) else float("nan"), epoch)   # core.py:738-739
-            self.writer.add_scalar('Loss/test', te.mean() if len(te) else float("nan"), epoch)
+        elog.flush_all()
         self.train_loss_df = pd.DataFrame(torch.cat([e[0].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
                                           columns=['loss'])
         self.test_loss_df = pd.DataFrame(torch.cat([e[1].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
@@ -1153,35 +1181,48 @@ class RegAutoEncoderTask(TrainingTask):
         ncol = len(loss_names)
         log_tr = torch.zeros(max(len(tr_batches), 1), ncol, device=self.device, dtype=torch.float64)
         log_te = torch.zeros(max(len(te_batches), 1), ncol, device=self.device, dtype=torch.float64)
+        cvec_log = [torch.zeros(max(K, 1), dtype=torch.float64).pin_memory() for _ in range(4)]   # the ordering, with the ring below
+
+        def on_epoch(ep, tr, te):
+            dt = torch.get_default_dtype()
+            tr, te = tr.to(dt), te.to(dt)
+            if self._use_reg and (tr_batches or te_batches):
+                self._cvec = cvec_log[ep % len(cvec_log)][:K].clone().to(torch.long)          # core.py:1110 (last evaluation)
+            self.loss_list.append([tr, te])                                                       # core.py:1202
+            mean_tr = tr.mean(0) if len(tr) else torch.full((ncol,), float("nan"))
+            mean_te = te.mean(0) if len(te) else torch.full((ncol,), float("nan"))
+            for i, name in enumerate(loss_names):                                                 # core.py:1208-1212
+                self.writer.add_scalar('%s/train' % name, mean_tr[i], ep)
+                self.writer.add_scalar('%s/test' % name, mean_te[i], ep)
+
+        elog = _AsyncEpochLog(log_tr, log_te, len(tr_batches), len(te_batches), on_epoch)
         for epoch in _tqdm(range(self.num_epochs)):
             self.model.train()
             for it, (a, b) in enumerate(tr_batches):
                 self._step(self._feature_traj, itr[a:b], wtr[a:b], wtr_lag[a:b], self.lag_ae_idx, self.lag_idx, with_grad=True,
                            advance=True, wsum=wsum_tr[it], out=log_tr[it])
-            if self._use_reg and tr_batches:
-                self._cvec = self._cvec_dev.cpu().to(torch.long)
-            if self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1:
+            saving = self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1
+            plotting = self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1
+            if saving or plotting:                       # (order of the reference: save / plot before the test pass, core.py:1130-1140)
+                if self._use_reg and tr_batches:
+                    self._cvec = self._cvec_dev.cpu().to(torch.long)
+            if saving:
                 self.save_model(epoch)
                 last = float(log_tr[len(tr_batches) - 1, 0]) if tr_batches else float("inf")
                 if last < min_loss:
                     min_loss = last
                     self.save_model(epoch, 'best')
-            if self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1:
+            if plotting:
                 if self.plot_class is not None:
                     self.plot_class.plot(self.colvar_model(), self.reg_model(), epoch=epoch)
             for it, (a, b) in enumerate(te_batches):
                 self._step(self._feature_traj, ite[a:b], wte[a:b], wte_lag[a:b], self.lag_ae_idx, self.lag_idx, with_grad=False,
                            out=log_te[it])
-            if self._use_reg and te_batches:
-                self._cvec = self._cvec_dev.cpu().to(torch.long)
-            dt = torch.get_default_dtype()
-            tr, te = log_tr[:len(tr_batches)].cpu().to(dt), log_te[:len(te_batches)].cpu().to(dt)
-            self.loss_list.append([tr, te])                                                       # core.py:1202
-            mean_tr = tr.mean(0) if len(tr) else torch.full((ncol,), float("nan"))
-            mean_te = te.mean(0) if len(te) else torch.full((ncol,), float("nan"))
-            for i, name in enumerate(loss_names):                                                 # core.py:1208-1212
-                self.writer.add_scalar('%s/train' % name, mean_tr[i], epoch)
-                self.writer.add_scalar('%s/test' % name, mean_te[i], epoch)
+            elog.reserve(epoch)
+            if self._use_reg and (tr_batches or te_batches):
+                cvec_log[epoch % len(cvec_log)].copy_(self._cvec_dev, non_blocking=True)
+            elog.push(epoch)
+        elog.flush_all()
         self.train_loss_df = pd.DataFrame(torch.cat([e[0].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
                                           columns=loss_names)
         self.test_loss_df = pd.DataFrame(torch.cat([e[1].mean(dim=0, keepdim=True) for e in self.loss_list]).numpy(),
