@@ -714,7 +714,7 @@ class AutoEncoderTask(TrainingTask):
             'autoencoder input/output width must equal the feature dimension'
         if self.verbose:
             print('\nShape of trajectory data array:\n {}'.format(self._feature_traj.shape), flush=True)
-        self._out2 = torch.zeros(2, device=self.device, dtype=torch.float64)
+        self._out2 = torch.zeros(3, device=self.device, dtype=torch.float64)
         self._scratch = {}
 
     def colvar_model(self):
@@ -742,7 +742,13 @@ class AutoEncoderTask(TrainingTask):
                                    inv_wsum, _hip.ptr(sc), _hip.ptr(self._out2),
                                    _hip.ptr(fl.grad) if with_grad else None,
                                    _hip.ptr(self.optimizer.step_count) if advance else None, adam, _hip.stream()), "cvf_ae_step")
-        out = self._out2.clone()
+        if _dist.world() == 1:
+            # (the kernel left the ratio beside the two sums: no arithmetic launches on the host side of a step; the caller
+            #  copies the value out before the next step overwrites it)
+            if with_grad and adam is None and advance:
+                self.optimizer.step(advance=False)
+            return self._out2[2]
+        out = self._out2[:2].clone()
         _dist.allreduce_sum_(out)
         if with_grad and adam is None:
             _dist.allreduce_sum_(fl.grad)
@@ -755,7 +761,7 @@ class AutoEncoderTask(TrainingTask):
         X = torch.as_tensor(X).detach().to(device=self.device, dtype=torch.float32).contiguous()
         weight = torch.as_tensor(weight).detach().to(device=self.device, dtype=torch.float32).contiguous()
         loss = self._step(X, None, weight, with_grad=True)
-        return loss.to(torch.get_default_dtype())
+        return loss.to(torch.get_default_dtype(), copy=True)
 
     def backward(self):
         pos = 0
@@ -1039,7 +1045,7 @@ class RegAutoEncoderTask(TrainingTask):
             ws = dict(
                 scratch=torch.empty(lib.cvf_regae_scratch_floats(self._flat.desc, B), device=dev, dtype=torch.float32),
                 y=torch.zeros(2 * T * K * 64, device=dev, dtype=torch.float32),
-                out2=torch.zeros(2, device=dev, dtype=torch.float64),
+                out2=torch.zeros(3, device=dev, dtype=torch.float64),
                 stats=torch.zeros(lib.cvf_ef_nstats(K, 1), device=dev, dtype=torch.float64),
                 sscratch=torch.zeros(lib.cvf_ef_stats_scratch_doubles(K, 1), device=dev, dtype=torch.float64),
                 loss_vec=torch.zeros(3 + 2 * K, device=dev, dtype=torch.float64),

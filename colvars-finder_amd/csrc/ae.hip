@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
   }
 }
 
-// out2 = fixed-order sums of the per-block {sum w*err, sum w}: lane l adds rows l, l+64, ..., then the DPP reduction
+// out2 = fixed-order sums of the per-block {sum w*err, sum w} (+ their ratio): lane l adds rows l, l+64, ..., then the DPP reduction
 __global__ __launch_bounds__(64) void ae_loss_sum_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out2) {
   const int lane = threadIdx.x;
   double a0 = 0.0, a1 = 0.0;
@@ -489,6 +489,7 @@ __global__ __launch_bounds__(64) void ae_loss_sum_kernel(const double* __restric
   if (lane == 0) {
     out2[0] = a0;
     out2[1] = a1;
+    out2[2] = a0 / a1;   // the loss of a single-process run (core.py:666)
   }
 }
 

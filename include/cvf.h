@@ -223,7 +223,7 @@ int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* 
 /* --- AutoEncoder: weighted reconstruction loss and its parameter gradient in one pass
  * (core.py:664-666,708).  feat_rows [n][d0] row-major (the precomputed feature
  * trajectory of core.py:635); idx NULL or [B] frame indices into it; w [B]; inv_wsum =
- * 1/sum(w) (host-known: batches are static).  out2 [2] doubles: {sum w*err, sum w}.
+ * 1/sum(w) (host-known: batches are static).  out2 [3] doubles: {sum w*err, sum w, their ratio = the loss}.
  * grad may be NULL (test pass, core.py:725-735). */
 int64_t cvf_ae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B);
 int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx, int64_t B,
@@ -241,8 +241,8 @@ int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const float* feat_r
  * the reconstruction targets, rows idx + lag_input the lagged arguments of the regularisers (the generator-mode
  * regulariser and the gradient-norm penalty eta_0 of the reference are not built).
  *  cvf_regae_forward : y_tiled [2 T][K][64] (tiles 0..T-1: y on the rows idx, T..2T-1: on the lagged rows), enc_tiled
- *                      [T][k][64] (latent vector on the rows idx; NULL: not wanted) and out2 = {sum w |dec(enc(f)) -
- *                      f_target|^2, sum w}.  Then cvf_ef_stats (lag_idx > 0, k = K) on y_tiled gives the eigenfunction
+ *                      [T][k][64] (latent vector on the rows idx; NULL: not wanted) and out2 [3] = {sum w |dec(enc(f)) -
+ *                      f_target|^2, sum w, their ratio}.  Then cvf_ef_stats (lag_idx > 0, k = K) on y_tiled gives the eigenfunction
  *                      terms and `coef`; cvf_ef_stats (lag_idx = 0, zero e_tiled) on enc_tiled + cvf_regae_enc_loss the
  *                      latent penalties and `enc_coef`.
  *  cvf_regae_backward: flat gradient of  mse_scale * sum w |..|^2 + head_scale * (npl + cfg.alpha * pen) + eta_1 norm +
