@@ -640,3 +640,38 @@ def test_large_batch_paths_by_duplication(dev):
     assert c1 == c2
     np.testing.assert_allclose(v2, v1, rtol=2e-6)
     np.testing.assert_allclose(g2, g1, rtol=1e-4, atol=2e-6 * np.abs(g1).max())
+
+
+def test_regae_three_regularisers_three_latents_vs_oracle(dev):
+    """RegAutoEncoderTask beyond the fixtures' shapes: K = 3 regularisers, 3 latent components, latent penalties on, unequal
+    lags, a batch that is not a multiple of 64 - first-step loss terms and a short training trace against the fp64 oracle."""
+    from colvarsfinder import core, nn
+    from oracle import nnref, train as otrain
+    rs = np.random.RandomState(12)
+    n, d = 700, 6
+    traj = np.cumsum(rs.normal(scale=0.15, size=(n, d)), axis=0).astype(np.float32)     # a slowly moving 6-d signal
+    traj -= traj.mean(0)
+    w = rs.uniform(0.5, 1.5, size=n)
+    w /= w.mean()
+    e_dims, d_dims, r_dims, K = [d, 8, 3], [3, 8, d], [3, 6, 1], 3
+    kw = dict(eig_w=[1.0, 0.6, 0.3], alpha=0.7, gamma=[1.0, 5.0], eta=[0.0, 0.3, 0.4], dt=0.5)
+    g = torch.Generator().manual_seed(5)
+    sd0 = nnref.init_regautoencoder(e_dims, d_dims, r_dims, K, g, torch.float32)
+    model = nn.RegAutoEncoder(e_dims, d_dims, r_dims, K)
+    model.load_state_dict(sd0)
+    np.random.seed(3)
+    task = core.RegAutoEncoderTask(Traj(traj, w, kw["dt"]), torch.nn.Identity(), model, "/tmp/cvf_test", eig_weights=kw["eig_w"],
+                                   learning_rate=3e-3, batch_size=150, num_epochs=2, alpha=kw["alpha"], gamma=kw["gamma"],
+                                   eta=kw["eta"], lag_tau_ae=1 * kw["dt"], lag_tau_reg=2 * kw["dt"], device=dev, verbose=False,
+                                   save_model_every_step=0)
+    task.train()
+    got = np.stack([e[0].numpy() for e in task.loss_list])
+    torch.set_default_dtype(torch.float64)
+    np.random.seed(3)
+    res = otrain.train_regae({n_: p.double() for n_, p in sd0.items()}, K, torch.nn.Identity(), traj.astype(np.float64), w,
+                             eig_w=kw["eig_w"], alpha=kw["alpha"], gamma=kw["gamma"], eta=kw["eta"], lag_ae_idx=1, lag_idx=2,
+                             dt=kw["dt"], learning_rate=3e-3, batch_size=150, num_epochs=2)
+    want = np.stack([e[0].numpy() for e in res["loss_list"]])
+    assert got.shape == want.shape == (2, 3, 4 + K + 3)
+    np.testing.assert_allclose(got[0, 0], want[0, 0], rtol=1e-4, atol=1e-6)          # first step: same weights on both sides
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=1e-5)                      # six Adam steps on, fp32 vs fp64
