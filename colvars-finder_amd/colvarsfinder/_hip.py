@@ -86,6 +86,8 @@ _SIGNATURES = {
     "cvf_ef_backward": (C.c_int, [C.POINTER(EFCfg), C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    "cvf_ef_align_fwd": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PPDesc), C.c_void_p, C.c_void_p,
+                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_slab_reduce": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p]),
     "cvf_ae_scratch_floats": (C.c_int64, [C.POINTER(MLPDesc), C.c_int64]),
     "cvf_ae_step": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double,

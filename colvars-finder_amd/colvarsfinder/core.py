@@ -410,7 +410,7 @@ class EigenFunctionTask(TrainingTask):
         # CVF_PIPELINE=1: the next batch's alignment (independent of the parameters) runs on this stream beside the
         # current step's backward kernel.  Off by default: at 20 000 frames per step it measured 133 us/step against
         # 126 serial - the two-branch graph costs more at the fork/join than the 14 us kernel it hides.
-        self._fused_fm = self._fused_k1 = None   # decided on first use: cvf_ef_[align_]fwd_metric_supported(nets, layer)
+        self._fused_fm = self._fused_k1 = self._fused_tr = None   # decided on first use: cvf_ef_[align_]fwd_metric_supported(nets, layer)
         self._side = torch.cuda.Stream(device=self.device)
         self._pipeline = os.environ.get("CVF_PIPELINE", "0") == "1"
 
@@ -464,7 +464,11 @@ class EigenFunctionTask(TrainingTask):
             self._fused_fm = lag == 0 and bool(lib.cvf_ef_fwd_metric_supported(fl.desc, self._pp))
             self._fused_k1 = self._fused_fm and bool(lib.cvf_ef_align_fwd_metric_supported(fl.desc, self._pp))
         with_k1 = self._fused_k1 and not aligned   # the alignment runs inside the fused launch
-        if not aligned and not with_k1:
+        if self._fused_tr is None:                 # transfer mode: alignment + forward of both frame sets in one launch
+            self._fused_tr = (lag > 0 and os.environ.get("CVF_NO_ALIGN_FWD") is None and
+                              bool(lib.cvf_ef_align_fwd_metric_supported(fl.desc, self._pp)))
+        with_tr = self._fused_tr and not aligned
+        if not aligned and not with_k1 and not with_tr:
             self._align(ws, slot, X, X_lag)
         single = not _dist.collectives()   # no cross-rank reduction: the loss tail runs inside the stats launch
         lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
@@ -482,8 +486,12 @@ class EigenFunctionTask(TrainingTask):
                 _dist.allreduce_sum_(ws.stats)                                           # collective #1
                 self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_vec), P(ws.coef), s)
             return ws
-        self._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(ws.y),
-                   P(ws.g) if lag == 0 else None, P(ws.saved), s)
+        if with_tr:
+            self._call("cvf_ef_align_fwd", lib.cvf_ef_align_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), self._pp, P(X),
+                       P(X_lag), B, P(ws.y), P(ws.saved), s)
+        else:
+            self._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(ws.y),
+                       P(ws.g) if lag == 0 else None, P(ws.saved), s)
         if lag == 0:   # q = J A J^T g, E, and the batch sums (K2/K3 + K5) in one launch
             self._call("cvf_metric_apply", lib.cvf_metric_apply_stats, self._pp, P(X), B, P(ws.aux), P(self._diag_coeff), k,
                        P(ws.g), P(ws.q), P(ws.e), P(ws.k1_scratch), P(self._dense), self._cfg, P(w), P(ws.y),

@@ -825,6 +825,124 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
                            yv, cur);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// K1 + K4a in one launch for the transfer-operator mode (core.py:403,414: y = model(pp_layer(X)), y' on the lagged frames):
+// the alignment part and the forward part of ef_fwd_metric_kernel without its derivative part.  Tiles 0..T1-1 take their
+// frames from x, tiles T1.. from x2 (the lagged frames); block = tile, one wave per net; LDS = coordinate tile + the
+// feature image only (34 KB at 22 atoms: four workgroups per CU, 2T tiles in one round).  Replaces two alignment launches
+// and the 2T-tile forward launch (12 + 12 + 22 us at 20 000 frames) and the feature round trip between them.
+// ------------------------------------------------------------------------------------------------------------------
+template <int H, int NH>
+__global__ __launch_bounds__(512) void ef_align_fwd_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
+                                                            const float* __restrict__ packed, float* __restrict__ feat,
+                                                            cvf_pp_desc pp, const float* __restrict__ x,
+                                                            const float* __restrict__ x2, int64_t T1, int64_t B,
+                                                            float* __restrict__ y_tiled, float* __restrict__ saved) {
+  constexpr int RT = Hid<H>::RT, FT = 4, CH = 6;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int col = lane & 15, q = lane >> 4;
+  const int64_t tile = blockIdx.x;
+  const int net = wave;
+  const int k = mlp.n_nets, D = mlp.dims[0];
+  const int S = (D + 3) >> 2;
+  const int nc = pp.n_coord, nal = pp.n_align;
+  const int stride = x_tile_stride(nc);
+  float* refL = lds + CVF_TILE * stride;                              // [3*nal]
+  float* Ub = lds + ((CVF_TILE * stride + 3 * nal + 3) & ~3);         // feature image [D][64], 16-byte aligned
+  const PackLayout L = pack_layout(H, NH, D);
+  const float* pk = packed + (int64_t)net * L.per_net;
+  const int fo = 4 * col;
+  const bool second = tile >= T1;
+  load_x_tile(second ? x2 : x, B, nc, second ? tile - T1 : tile, lds, tid, nthreads);
+  for (int j = tid; j < 3 * nal; j += nthreads) refL[j] = pp.ref_c[j];
+  __syncthreads();
+  const float* my = lds + lane * stride;
+  const int nw = nthreads >> 6;
+  // centroid + covariance over d = x - (atom 0 of the frame), packed fp32 (as ef_fwd_metric_kernel)
+  const float p0 = my[0], p1 = my[1], p2 = my[2];
+  f2 H01[3] = {{0, 0}, {0, 0}, {0, 0}};
+  float H2[3] = {0, 0, 0}, sd[3] = {0, 0, 0};
+#pragma unroll 2
+  for (int b = 0; b < nal; ++b) {
+    const float d0 = my[3 * b] - p0, d1 = my[3 * b + 1] - p1, d2 = my[3 * b + 2] - p2;
+    const f2 r01 = f2{refL[3 * b], refL[3 * b + 1]};
+    const float r2 = refL[3 * b + 2];
+    sd[0] += d0; sd[1] += d1; sd[2] += d2;
+    H01[0] = fma2(splat2(d0), r01, H01[0]); H2[0] = fmaf(d0, r2, H2[0]);
+    H01[1] = fma2(splat2(d1), r01, H01[1]); H2[1] = fmaf(d1, r2, H2[1]);
+    H01[2] = fma2(splat2(d2), r01, H01[2]); H2[2] = fmaf(d2, r2, H2[2]);
+  }
+  const double inv = fast_rcp((double)nal);
+  const double cd[3] = {(double)p0 + (double)sd[0] * inv, (double)p1 + (double)sd[1] * inv, (double)p2 + (double)sd[2] * inv};
+  double Hm[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Hm[i][0] = (double)H01[i].x;
+    Hm[i][1] = (double)H01[i].y;
+    Hm[i][2] = (double)H2[i];
+  }
+  KabschOut ko;
+  kabsch_from_H(Hm, ko);
+  const Centre c = centre_of(cd);
+  float* ft = feat + tile * (int64_t)D * CVF_TILE + lane;
+#pragma unroll 2
+  for (int at = wave; at < pp.n_rec; at += nw) {
+    const V3 al = row_times(centred(my, at, c), ko.R);
+    Ub[(3 * at) * CVF_TILE + lane] = al.x;
+    Ub[(3 * at + 1) * CVF_TILE + lane] = al.y;
+    Ub[(3 * at + 2) * CVF_TILE + lane] = al.z;
+    ft[(3 * at) * CVF_TILE] = al.x;
+    ft[(3 * at + 1) * CVF_TILE] = al.y;
+    ft[(3 * at + 2) * CVF_TILE] = al.z;
+  }
+  lds_barrier();   // the feature image is complete
+  const float* in_lane = Ub + fo;
+  L0Chunk<H, FT, CH> c0, c1, c2;
+  load_l0chunk<H, FT, CH>(c0, pk + L.f0(), D, S, in_lane, 0, lane);
+  load_l0chunk<H, FT, CH>(c1, pk + L.f0(), D, S, in_lane, CH, lane);
+  load_l0chunk<H, FT, CH>(c2, pk + L.f0(), D, S, in_lane, 2 * CH, lane);
+  HConst<H> bias[NH];
+#pragma unroll
+  for (int l = 0; l < NH; ++l) load_hconst<H>(bias[l], theta + mlp.b_off[net][l], q);
+  HFrag<H> hf[NH > 1 ? NH - 1 : 1];
+#pragma unroll
+  for (int l = 1; l < NH; ++l) load_hfrag<H>(hf[l - 1], pk + L.fh(l), lane);
+  float wl[RT][4];
+  load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
+  const float bL = theta[mlp.b_off[net][NH]];
+  Vec<H, FT> h[NH];
+  set_const<H, FT>(h[0], bias[0]);
+  mul_l0chunk<H, FT, CH>(h[0], c0);
+  mul_l0chunk<H, FT, CH>(h[0], c1);
+  mul_l0chunk<H, FT, CH>(h[0], c2);
+  tanh_inplace<H, FT>(h[0]);
+#pragma unroll
+  for (int l = 1; l < NH; ++l) {
+    set_const<H, FT>(h[l], bias[l]);
+    hidden_mul<H, FT>(h[l], hf[l - 1], h[l - 1]);
+    tanh_inplace<H, FT>(h[l]);
+  }
+  {
+    float yv4[FT];
+#pragma unroll
+    for (int ft_ = 0; ft_ < FT; ++ft_) {
+      float part = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(wl[rt][r], h[NH - 1].v[rt][ft_][r], part);
+      yv4[ft_] = sum_over_q(part) + bL;
+    }
+    if (q == 0) store_frames<FT>(y_tiled + (tile * k + net) * CVF_TILE + fo, yv4);
+  }
+  if (saved != nullptr) {
+    float* sv = saved + (tile * k + net) * (int64_t)(NH * saved_per_vec<H>());
+#pragma unroll
+    for (int l = 0; l < NH; ++l) save_vec<H>(sv + l * saved_per_vec<H>(), h[l], lane);
+  }
+}
+
 // K4a, workgroup form: four waves = four consecutive 64-frame tiles of ONE net.  The net's weight fragments
 // (F0, Fh, Th, T0: ~25 KB for 66 -> 20 -> 20 -> 20 -> 1) are fetched ONCE per workgroup with 16-byte loads into
 // LDS and read from there by all four waves; per-wave global traffic is then only its feature tile.  (The per-CU
@@ -1644,6 +1762,28 @@ extern "C" int cvf_ef_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* the
                                        double* loss_vec, double* coef, void* stream) {
   return fwd_metric_launch(false, mlp, theta, packed, const_cast<float*>(feat_tiled), pp, x, B, const_cast<float*>(aux_tiled), a,
                            y_tiled, saved, q_tiled, e_tiled, cfg, w, scratch, stats, loss_vec, coef, stream);
+}
+
+extern "C" int cvf_ef_align_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                                const cvf_pp_desc* pp, const float* x, const float* x_lag, int64_t B, float* y_tiled, float* saved,
+                                void* stream) {
+  CVF_REQUIRE(cvf_ef_align_fwd_metric_supported(mlp, pp), "cvf_ef_align_fwd: shape not covered (cvf_ef_align_fwd_metric_supported() == 0)");
+  CVF_REQUIRE(theta && packed && feat_tiled && x && y_tiled && B > 0, "cvf_ef_align_fwd: bad argument");
+  int H, NH;
+  ef_shape(mlp, &H, &NH);
+  const int k = mlp->n_nets;
+  const int64_t T = cvf_ntiles(B), n_tiles = x_lag ? 2 * T : T;
+  const size_t lds = (((size_t)CVF_TILE * x_tile_stride(pp->n_coord) + 3 * (size_t)pp->n_align + 3) & ~(size_t)3) * sizeof(float) +
+                     (size_t)mlp->dims[0] * CVF_TILE * sizeof(float);
+  CVF_REQUIRE(lds <= 160 * 1024, "cvf_ef_align_fwd: %zu B of LDS per workgroup (> 160 KiB)", lds);
+  ef_dispatch(H, NH, [&](auto h_, auto nh_) {
+    constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
+    auto kernel = ef_align_fwd_kernel<kH, kNH>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)n_tiles), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, feat_tiled, *pp, x,
+                       x_lag, T, B, y_tiled, saved);
+  });
+  return cvf_check_launch("ef_align_fwd_kernel");
 }
 
 // Rows of per-tile partial sums the fused launches leave in `scratch` (0: the batch is too large for the fused sums and

@@ -180,6 +180,13 @@ int cvf_ef_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, const f
 
 /* With stats == NULL the fused launches stop after leaving cvf_ef_fused_stats_rows() (> 0 required) rows of per-tile
  * sums in `scratch`; cvf_ef_stats_finish_rows adds them in a fixed order (and evaluates cvf_ef_loss when loss_vec != NULL). */
+/* Transfer-operator mode (lag_tau > 0; core.py:403,414): alignment + features + nets forward in one launch for the frames x
+ * and their lagged partners x_lag (may be NULL: T tiles only) -> feat_tiled [2T][d_r][64] (tiles T.. = lagged), y_tiled
+ * [2T][k][64], saved (cvf_ef_saved_floats(mlp, 2T); may be NULL).  Same shapes as cvf_ef_align_fwd_metric_supported().
+ * Follow with cvf_ef_stats (lag_idx > 0) and cvf_ef_backward as after cvf_align_feature_fwd x 2 + cvf_ef_mlp_fwd. */
+int cvf_ef_align_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                     const cvf_pp_desc* pp, const float* x, const float* x_lag, int64_t B, float* y_tiled, float* saved,
+                     void* stream);
 int64_t cvf_ef_fused_stats_rows(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp, int64_t B, int with_align);
 int cvf_ef_stats_finish_rows(const cvf_ef_cfg* cfg, int64_t n_rows, const double* partial, double* stats, double* loss_vec,
                              double* coef, void* stream);

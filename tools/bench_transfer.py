@@ -22,3 +22,9 @@ torch.cuda.synchronize(); t0=time.perf_counter()
 for i in range(100): step(10+i)
 torch.cuda.synchronize(); el=time.perf_counter()-t0
 print(json.dumps({"transfer_mode_ms_per_step": el/100*1e3, "frames_per_s": B*100/el, "loss": float(log[0,0])}))
+task._use_graphs, task._events = False, {}
+for i in range(30):
+    torch.cuda._sleep(2_000_000)
+    step(200 + i)
+torch.cuda.synchronize()
+print(json.dumps({"call_avg_us": {n_: float(np.mean([a_.elapsed_time(b_) for a_, b_ in ev[5:]])) * 1e3 for n_, ev in task._events.items()}}))
