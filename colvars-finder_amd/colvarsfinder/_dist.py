@@ -57,6 +57,26 @@ def local_slice(n_global, r=None, w=None):
     return start, start + base + (1 if r < rem else 0)
 
 
+def shard_batches(n, bs, r=None, w=None):
+    """The static batches of a permuted set of ``n`` items - ``DataLoader(batch_size=bs, drop_last=True, shuffle=False)``,
+    core.py:470-481 - split over the ranks: global batch ``j`` is items ``[j bs, (j+1) bs)`` and rank ``r`` owns the
+    contiguous slice ``local_slice(bs, r, w)`` of every batch.
+
+    Returns ``(pos, nb)``: ``pos`` = the positions (into the permuted set) this rank keeps RESIDENT, batch-major, and
+    ``nb`` = frames per local batch, so that local batch ``j`` is resident rows ``[j nb, (j+1) nb)``.  The union over the
+    ranks of batch ``j``'s rows is exactly global batch ``j``; items of the dropped tail are resident nowhere.
+    """
+    import numpy as np
+    r = rank() if r is None else r
+    w = world() if w is None else w
+    n_batches = n // bs if bs > 0 else 0
+    a, b = local_slice(bs, r, w)
+    if n_batches == 0:
+        return np.zeros(0, dtype=np.int64), b - a
+    pos = (np.arange(n_batches, dtype=np.int64)[:, None] * bs + np.arange(a, b, dtype=np.int64)[None, :]).reshape(-1)
+    return pos, b - a
+
+
 def allreduce_sum_(t):
     """In-place sum over ranks; a no-op in a single-process run."""
     if collectives():

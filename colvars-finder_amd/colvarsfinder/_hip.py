@@ -14,6 +14,7 @@ TILE = 64
 MAX_NETS = 8
 MAX_LAYERS = 12
 AUX_ROWS = 18
+EF_HIDDEN_WIDTHS = (8, 12, 16, 20, 24, 32)   # hidden widths the eigenfunction kernels are instantiated for (csrc/ef_mfma.hip)
 
 FEAT_ANGLE, FEAT_BOND, FEAT_DIHEDRAL, FEAT_POSITION = 0, 1, 2, 3
 PP_IDENTITY, PP_ALIGN = 0, 1
@@ -45,7 +46,7 @@ class EFCfg(C.Structure):
 class AdamArgs(C.Structure):
     _fields_ = [("theta", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_double), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("eps", C.c_double), ("step_count", C.c_void_p), ("mlp", C.POINTER(MLPDesc)),
-                ("packed", C.c_void_p)]
+                ("packed", C.c_void_p), ("lr_dev", C.c_void_p)]
 
 
 _SIGNATURES = {
@@ -103,9 +104,10 @@ _SIGNATURES = {
     "cvf_regae_loss_row": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_double,
                                      C.c_double, C.c_void_p, C.c_void_p]),
     "cvf_mlp_eval_rows": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
-    "cvf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+    "cvf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_double,
                                 C.c_double, C.c_double, C.c_void_p, C.POINTER(MLPDesc), C.c_void_p, C.c_void_p]),
-    "cvf_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.POINTER(MLPDesc), C.c_void_p, C.c_void_p]),
+    "cvf_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.POINTER(MLPDesc), C.c_void_p,
+                               C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -197,6 +199,8 @@ def upload_f32(a, device, chunk_bytes=64 << 20):
     bufs = [torch.empty(ce, dtype=torch.float32).pin_memory() for _ in range(2)]
     done = [None, None]
     side = torch.cuda.Stream(device)
+    # `out` came from the caching allocator on the current stream: work queued there may still use the block it recycled
+    side.wait_stream(torch.cuda.current_stream(device))
     for i, s0 in enumerate(range(0, n, ce)):
         e0, b = min(s0 + ce, n), bufs[i % 2]
         if done[i % 2] is not None:

@@ -3,7 +3,9 @@
 API twin (own code) of reference ``colvarsfinder/core.py``: ``TrainingTask`` (core.py:60-249),
 ``EigenFunctionTask`` (core.py:251-566) and ``AutoEncoderTask`` (core.py:569-744) keep their
 constructor arguments, defaults, public methods and attributes, so the reference's example
-scripts run unchanged once ``device=torch.device('cuda')`` is passed.  What differs is *how* a
+scripts run unchanged (``device`` defaults to ``torch.device('cuda')``, PyTorch-ROCm's name for the HIP device; the
+modules returned by ``colvar_model()`` / ``reg_model()`` take CPU tensors and answer on the CPU, as the notebooks'
+evaluation cells expect).  What differs is *how* a
 step is computed: the model's parameters live in one flat HBM buffer, the trajectory shard is
 resident in HBM and pre-permuted once (batches are static: ``shuffle=False``, core.py:472-481),
 and every step is a short sequence of hand-written gfx950 kernels called through the C ABI of
@@ -109,11 +111,39 @@ class _AsyncEpochLog:
             self._flush(slot)
 
 
+class _CVModel(torch.nn.Sequential):
+    """What ``colvar_model()`` / ``reg_model()`` return: ``Sequential(preprocessing_layer, nets)`` as in the reference
+    (core.py:372-382, 640-647, 855-877), evaluated on the task's GPU whatever device the input lives on.  The reference's
+    callers pass CPU tensors made from the trajectory and call ``.detach().numpy()`` on the result (2d.ipynb:437-446,
+    main.ipynb:561-562, and ``plot_class.plot(self.colvar_model(), ...)`` at core.py:530-532): the input is moved to the
+    device, alignment kernel and nets run there, the result comes back on the input's device and floating-point type."""
+
+    def __init__(self, *modules, device=None):
+        super().__init__(*modules)
+        self._cvf_device = None if device is None else torch.device(device)
+
+    def _compute_device(self):
+        if self._cvf_device is not None:
+            return self._cvf_device
+        for t in list(self.parameters()) + list(self.buffers()):   # (a slice of this Sequential: where its tensors live)
+            return t.device
+        return torch.device("cuda")
+
+    def forward(self, x):
+        x = torch.as_tensor(x)
+        dev = _hip.require_gpu(self._compute_device())
+        src_dev, src_dt = x.device, (x.dtype if x.dtype.is_floating_point else torch.float32)
+        with torch.cuda.device(dev):
+            out = super().forward(x.detach().to(device=dev, dtype=torch.float32))
+        return out.to(device=src_dev, dtype=src_dt)
+
+
 class _FlatParams:
     """The model's parameters as views of one fp32 device buffer (+ gradient and Adam moments)."""
 
     def __init__(self, model, device):
         model.to(device=device, dtype=torch.float32)
+        self.model = model
         lay = mlp_layout(model)
         self.n = lay["n_params"]
         self.theta = torch.empty(self.n, device=device, dtype=torch.float32)
@@ -142,6 +172,14 @@ class _FlatParams:
         self.packed = torch.zeros(n_pack, device=device, dtype=torch.float32) if n_pack > 0 else None
         self.repack()
 
+    def grad_views(self):
+        """[(module parameter, its slice of the flat gradient)] in flat order."""
+        out, pos = [], 0
+        for p in self.model.parameters():
+            out.append((p, self.grad[pos:pos + p.numel()].view(p.shape)))
+            pos += p.numel()
+        return out
+
     def repack(self):
         """Rebuild the fragment copy from theta (needed after the parameters were written from outside)."""
         if self.packed is not None:
@@ -150,8 +188,11 @@ class _FlatParams:
 
 
 class _FusedOptimizer:
-    """``optimizer`` attribute of the tasks: Adam / SGD as ONE kernel over the flat buffer
-    (same update rule and defaults as the ``torch.optim`` objects built at core.py:163-166)."""
+    """``optimizer`` attribute of the tasks: Adam / SGD as ONE kernel over the flat buffer (same update rule and
+    defaults as the ``torch.optim`` objects built at core.py:163-166), with the parts of the ``torch.optim.Optimizer``
+    surface user code touches: ``param_groups`` (``lr`` may be changed between steps - a scheduler, a manual decay -
+    and is honoured by captured hipGraphs too: the kernels read it from a device scalar), ``zero_grad``, ``step``,
+    ``state_dict`` / ``load_state_dict`` (the reference never checkpoints the optimizer; SURVEY 8f row 2 asks for it)."""
 
     def __init__(self, flat, name, lr):
         self.flat, self.name, self.lr = flat, name.lower(), float(lr)
@@ -159,10 +200,29 @@ class _FusedOptimizer:
         self.exp_avg = torch.zeros_like(flat.theta)
         self.exp_avg_sq = torch.zeros_like(flat.theta)
         self.step_count = torch.zeros(1, device=flat.theta.device, dtype=torch.int32)
-        self.param_groups = [dict(lr=self.lr, betas=self.betas, eps=self.eps)]
+        self.param_groups = [dict(params=[p for p, _ in flat.grad_views()], lr=self.lr, betas=self.betas, eps=self.eps,
+                                  weight_decay=0, amsgrad=False)]
+        self.lr_dev = torch.full((1,), self.lr, device=flat.theta.device, dtype=torch.float32)
+        self._lr_written = self.lr
+
+    def sync_lr(self):
+        """Write ``param_groups[0]['lr']`` to the device scalar the kernels read, if it changed since the last write
+        (called before every eager step and before every graph replay)."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_written:
+            self.lr_dev.fill_(lr)
+            self._lr_written = lr
+        return lr
 
     def zero_grad(self, set_to_none=True):
-        pass  # the backward kernels overwrite the whole flat gradient
+        # the backward kernels overwrite the whole flat gradient; module-level .grad tensors (copies made by the
+        # tasks' backward()) are dropped or zeroed as torch.optim does
+        for p, _ in self.flat.grad_views():
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
 
     def fused_args(self):
         """``cvf_adam_args`` for the kernels that reduce the gradient and apply Adam in one launch
@@ -171,7 +231,8 @@ class _FusedOptimizer:
             return None
         f, a = self.flat, _hip.AdamArgs()
         a.theta, a.m, a.v = f.theta.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
-        a.lr, a.beta1, a.beta2, a.eps = float(self.param_groups[0]["lr"]), self.betas[0], self.betas[1], self.eps
+        a.lr, a.beta1, a.beta2, a.eps = self.sync_lr(), self.betas[0], self.betas[1], self.eps
+        a.lr_dev = self.lr_dev.data_ptr()
         a.step_count = self.step_count.data_ptr()
         if f.packed is not None:
             a.mlp, a.packed = C_pointer(f.desc), f.packed.data_ptr()
@@ -179,18 +240,39 @@ class _FusedOptimizer:
 
     def step(self, advance=True):
         """``advance=False`` when the gradient kernel of this step has already advanced the step counter
-        (the fused training loops); the public ``loss -> backward() -> optimizer.step()`` path advances here."""
+        (the fused training loops); the public ``loss -> backward() -> optimizer.step()`` path advances here and
+        takes the gradient from the modules' ``.grad`` tensors where they are set (so that edits made after
+        ``backward()`` - clipping, masking - count, as with ``torch.optim``)."""
         f, lib = self.flat, _hip.lib()
-        lr = float(self.param_groups[0]["lr"])
+        lr = self.sync_lr()
         if advance:
             self.step_count += 1
+            for p, gv in f.grad_views():
+                if p.grad is not None:
+                    gv.copy_(p.grad.to(device=gv.device, dtype=gv.dtype))
         if self.name == "adam":
             _hip.check(lib.cvf_adam_step(_hip.ptr(f.theta), _hip.ptr(f.grad), _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq),
-                                         f.n, lr, self.betas[0], self.betas[1], self.eps, _hip.ptr(self.step_count),
-                                         f.desc, _hip.ptr(f.packed), _hip.stream()), "cvf_adam_step")
+                                         f.n, lr, _hip.ptr(self.lr_dev), self.betas[0], self.betas[1], self.eps,
+                                         _hip.ptr(self.step_count), f.desc, _hip.ptr(f.packed), _hip.stream()), "cvf_adam_step")
         else:
-            _hip.check(lib.cvf_sgd_step(_hip.ptr(f.theta), _hip.ptr(f.grad), f.n, lr, f.desc, _hip.ptr(f.packed),
-                                        _hip.stream()), "cvf_sgd_step")
+            _hip.check(lib.cvf_sgd_step(_hip.ptr(f.theta), _hip.ptr(f.grad), f.n, lr, _hip.ptr(self.lr_dev), f.desc,
+                                        _hip.ptr(f.packed), _hip.stream()), "cvf_sgd_step")
+
+    def state_dict(self):
+        """Adam moments, step number and hyper-parameters as CPU tensors / numbers (flat order = ``parameters()`` order for
+        EigenFunctions / AutoEncoder models, the chain order of ``_RegFlatParams`` for RegAutoEncoder)."""
+        return dict(name=self.name, n=int(self.flat.n), step=int(self.step_count.item()),
+                    exp_avg=self.exp_avg.detach().cpu().clone(), exp_avg_sq=self.exp_avg_sq.detach().cpu().clone(),
+                    param_groups=[dict(lr=float(self.param_groups[0]["lr"]), betas=tuple(self.betas), eps=float(self.eps))])
+
+    def load_state_dict(self, sd):
+        assert sd["name"] == self.name and int(sd["n"]) == int(self.flat.n), \
+            f"optimizer state is for {sd['name']} over {sd['n']} parameters, this one is {self.name} over {self.flat.n}"
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count.fill_(int(sd["step"]))
+        self.param_groups[0]["lr"] = float(sd["param_groups"][0]["lr"])
+        self.sync_lr()
 
 
 class TrainingTask(ABC):
@@ -372,11 +454,23 @@ class EigenFunctionTask(TrainingTask):
         if self.verbose:
             print('\nEigenfunctions:\n', self.model, flush=True)
         self.init_model_and_optimizer()
+        if self._flat.packed is None:   # no matrix-core kernel instance for this architecture: say so here, not at the first step
+            d = self._flat.desc
+            raise NotImplementedError(
+                "EigenFunctionTask on MI355X: no kernel instance for nets with layer widths "
+                f"{[d.dims[i] for i in range(d.n_layers + 1)]}. Supported: d0 -> H -> .. -> H -> 1 with ONE hidden width "
+                f"H in {_hip.EF_HIDDEN_WIDTHS}, 1 to 3 hidden layers (H = 24, 32: 2 or 3), Tanh between layers, k <= "
+                f"{_hip.MAX_NETS} (csrc/ef_mfma.hip: ef_shape / ef_dispatch).")
 
-        # the trajectory shard and its weights stay resident in HBM (core.py:343-344 keeps CPU copies)
+        # The frames stay resident in HBM (core.py:343-344 keeps CPU copies and moves every batch, core.py:500).  One process:
+        # the whole trajectory.  Data-parallel job (one process per GPU): NOT here - train() uploads only the rows of this
+        # rank's slices of the static batches, 1/world of the trajectory per GPU.
         traj = np.asarray(traj_obj.trajectory)
-        self._traj = _hip.upload_f32(traj, self.device)
+        self._traj_host, self._n_frames = traj, int(traj.shape[0])
+        self._sharded = _dist.world() > 1
+        self._traj = None if self._sharded else _hip.upload_f32(traj, self.device)
         self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
+        self.resident_bytes = 0 if self._sharded else self._traj.numel() * 4    # frames held in HBM (train() adds its gathers)
         self.tot_dim = int(traj[0, ...].size)
         self._beta = beta
         if self.lag_idx == 0:
@@ -425,7 +519,7 @@ class EigenFunctionTask(TrainingTask):
         """core.py:372-382: ``Sequential(preprocessing_layer, nets re-ordered by the last cvec)``."""
         if self._cvec is None:
             self._cvec = torch.arange(self.k)
-        return torch.nn.Sequential(self.preprocessing_layer, self.get_reordered_eigenfunctions(self.model, self._cvec))
+        return _CVModel(self.preprocessing_layer, self.get_reordered_eigenfunctions(self.model, self._cvec), device=self.device)
 
     def reg_model(self):
         return None
@@ -563,6 +657,7 @@ class EigenFunctionTask(TrainingTask):
                 return
             self._graphs[key] = g
             return                                     # the warm-up call already did this step's work once... see note
+        self.optimizer.sync_lr()                       # the captured kernels read the learning rate from a device scalar
         g.replay()
 
     def _dev(self, t, dtype=torch.float32):
@@ -597,7 +692,7 @@ class EigenFunctionTask(TrainingTask):
         k, lag = self.k, self.lag_idx
         self._flat.repack()
         self._graphs = {}   # captured steps hold pointers into the previous call's batches
-        ll = self._traj.shape[0] - lag
+        ll = self._n_frames - lag
         _split(ll, self.test_ratio)                                  # core.py:465 (drawn, discarded)
         idx_train, idx_test = _split(ll, self.test_ratio)            # core.py:468
         world, rank = _dist.world(), _dist.rank()
@@ -607,26 +702,34 @@ class EigenFunctionTask(TrainingTask):
             both = both.cpu().numpy()
             idx_train, idx_test = both[:len(idx_train)], both[len(idx_train):]
 
-        def resident(idx):
-            it = torch.as_tensor(idx, device=self.device, dtype=torch.long)
-            X, w = self._traj[it].contiguous(), self._weights[it].contiguous()
-            if lag > 0:
-                return X, w, self._traj[it + lag].contiguous(), self._weights[it + lag].contiguous()
-            return X, w, None, None
-
-        def batches(n, bs):
-            # DataLoader(batch_size=bs, drop_last=True, shuffle=False); each rank owns one contiguous slice
-            out = []
-            for s in range(0, n - bs + 1, bs) if bs > 0 else []:
-                a, b = _dist.local_slice(bs, rank, world)
-                out.append((s + a, s + b))
-            return out
+        def resident(idx, bs):
+            """Frames (weights, lagged partners) of the permuted set `idx` that this process works on, gathered once in
+            batch order, and its batches as row ranges of that copy: DataLoader(batch_size=bs, drop_last=True,
+            shuffle=False), core.py:470-481.  One process: the whole set, gathered on the device from the resident
+            trajectory.  Data-parallel: only this rank's slice of every global batch (_dist.shard_batches), gathered on
+            the host and uploaded - the lagged partners are pre-gathered too, so a frame may live on two ranks."""
+            if not self._sharded:
+                it = torch.as_tensor(idx, device=self.device, dtype=torch.long)
+                X, w = self._traj[it].contiguous(), self._weights[it].contiguous()
+                Xl, wl = (self._traj[it + lag].contiguous(), self._weights[it + lag].contiguous()) if lag > 0 else (None, None)
+                bl = [(s, s + bs) for s in range(0, len(idx) - bs + 1, bs)] if bs > 0 else []
+            else:
+                assert bs == 0 or bs >= world, f"batch size {bs} is smaller than the number of ranks {world}"
+                pos, nb = _dist.shard_batches(len(idx), bs, rank, world)
+                rows = np.asarray(idx)[pos]
+                it = torch.as_tensor(rows, device=self.device, dtype=torch.long)
+                X, w = _hip.upload_f32(self._traj_host[rows], self.device), self._weights[it].contiguous()
+                Xl, wl = ((_hip.upload_f32(self._traj_host[rows + lag], self.device), self._weights[it + lag].contiguous())
+                          if lag > 0 else (None, None))
+                bl = [(j * nb, (j + 1) * nb) for j in range(len(pos) // nb)] if nb > 0 else []
+            self.resident_bytes += sum(t.numel() * t.element_size() for t in (X, w, Xl, wl) if t is not None)
+            return (X, w, Xl, wl), bl
 
         bs_train = min(self.batch_size, len(idx_train))
         bs_test = min(self.batch_size, len(idx_test))
-        Xtr = resident(idx_train)
-        Xte = resident(idx_test)
-        tr_batches, te_batches = batches(len(idx_train), bs_train), batches(len(idx_test), bs_test)
+        self.resident_bytes = 0 if self._sharded else self._traj.numel() * 4
+        Xtr, tr_batches = resident(idx_train, bs_train)
+        Xte, te_batches = resident(idx_test, bs_test)
 
         self.loss_list = []
         min_loss = float("inf")
@@ -710,24 +813,35 @@ class AutoEncoderTask(TrainingTask):
         assert isinstance(model, AutoEncoder), 'model must be an object of the class AutoEncoder'
         self.init_model_and_optimizer()
         traj = np.asarray(traj_obj.trajectory)
+        self._traj_host, self._n_frames = traj, int(traj.shape[0])
         self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
-        X = _hip.upload_f32(traj, self.device)
-        pp = self._pp_desc(int(traj[0, ...].size))
-        n = X.shape[0]
-        self._feature_traj = torch.empty(n, pp.d_r, device=self.device, dtype=torch.float32)       # core.py:635
-        _hip.check(_hip.lib().cvf_align_feature_fwd(pp, _hip.ptr(X), n, None, _hip.ptr(self._feature_traj), None,
-                                                    _hip.ptr(_hip.align_scratch(pp, n, self.device)), _hip.stream()),
-                   "cvf_align_feature_fwd")
+        self._pp = pp = self._pp_desc(int(traj[0, ...].size))
+        # core.py:635: the feature trajectory r(x) of ALL frames, once.  In a data-parallel job (one process per GPU) each
+        # rank computes the features of its own rows only, in train(), once the split is known.
+        self._sharded = _dist.world() > 1
+        self._feature_traj = None if self._sharded else self._features(traj)
+        self.resident_bytes = 0 if self._sharded else self._feature_traj.numel() * 4
         assert pp.d_r == self._flat.desc.dims[0] == self._flat.desc.dims[self._flat.desc.n_layers], \
             'autoencoder input/output width must equal the feature dimension'
         if self.verbose:
-            print('\nShape of trajectory data array:\n {}'.format(self._feature_traj.shape), flush=True)
+            print('\nShape of trajectory data array:\n {}'.format((self._n_frames, pp.d_r)), flush=True)
         self._out2 = torch.zeros(3, device=self.device, dtype=torch.float64)
         self._scratch = {}
 
+    def _features(self, rows):
+        """K1 over host frames -> row-major feature rows resident in HBM."""
+        X = _hip.upload_f32(rows, self.device)
+        n = X.shape[0]
+        out = torch.empty(n, self._pp.d_r, device=self.device, dtype=torch.float32)
+        if n > 0:
+            _hip.check(_hip.lib().cvf_align_feature_fwd(self._pp, _hip.ptr(X), n, None, _hip.ptr(out), None,
+                                                        _hip.ptr(_hip.align_scratch(self._pp, n, self.device)), _hip.stream()),
+                       "cvf_align_feature_fwd")
+        return out
+
     def colvar_model(self):
         """core.py:640-647."""
-        return torch.nn.Sequential(self.preprocessing_layer, self.model.encoder)
+        return _CVModel(self.preprocessing_layer, self.model.encoder, device=self.device)
 
     def reg_model(self):
         return None
@@ -779,7 +893,7 @@ class AutoEncoderTask(TrainingTask):
 
     def train(self):
         """core.py:668-744."""
-        n = self._feature_traj.shape[0]
+        n = self._n_frames
         idx_train, idx_test = _split(n, self.test_ratio)             # core.py:672 (one draw)
         world, rank = _dist.world(), _dist.rank()
         if world > 1:
@@ -788,18 +902,32 @@ class AutoEncoderTask(TrainingTask):
             both = both.cpu().numpy()
             idx_train, idx_test = both[:len(idx_train)], both[len(idx_train):]
         bs_train, bs_test = min(self.batch_size, len(idx_train)), min(self.batch_size, len(idx_test))
-        itr = torch.as_tensor(idx_train, device=self.device, dtype=torch.long)
-        ite = torch.as_tensor(idx_test, device=self.device, dtype=torch.long)
-        wtr, wte = self._weights[itr].contiguous(), self._weights[ite].contiguous()
 
-        def batches(n_, bs):
-            out = []
-            for s in range(0, n_ - bs + 1, bs) if bs > 0 else []:
-                a, b = _dist.local_slice(bs, rank, world)
-                out.append((s + a, s + b))
-            return out
+        def resident(idx, bs):
+            """(feature rows, per-batch row indices or None, weights, batches) of the permuted set `idx` for this process.
+            One process: batches index the resident feature trajectory.  Data-parallel: only this rank's slice of every
+            global batch is uploaded and run through K1 (_dist.shard_batches); its batches are contiguous row ranges."""
+            if not self._sharded:
+                it = torch.as_tensor(idx, device=self.device, dtype=torch.long)
+                bl = [(s, s + bs) for s in range(0, len(idx) - bs + 1, bs)] if bs > 0 else []
+                return self._feature_traj, it, self._weights[it].contiguous(), bl
+            assert bs == 0 or bs >= world, f"batch size {bs} is smaller than the number of ranks {world}"
+            pos, nb = _dist.shard_batches(len(idx), bs, rank, world)
+            rows = np.asarray(idx)[pos]
+            feat = self._features(self._traj_host[rows])
+            self.resident_bytes += feat.numel() * 4
+            wv = self._weights[torch.as_tensor(rows, device=self.device, dtype=torch.long)].contiguous()
+            return feat, None, wv, ([(j * nb, (j + 1) * nb) for j in range(len(pos) // nb)] if nb > 0 else [])
 
-        tr_batches, te_batches = batches(len(idx_train), bs_train), batches(len(idx_test), bs_test)
+        if self._sharded:
+            self.resident_bytes = 0
+        ftr, itr, wtr, tr_batches = resident(idx_train, bs_train)
+        fte, ite, wte, te_batches = resident(idx_test, bs_test)
+        if self._sharded:
+            self._feature_traj = ftr      # (this rank's training rows; the reference's attribute holds all frames)
+
+        def rows_of(feat, it, a, b):
+            return (feat, it[a:b]) if it is not None else (feat[a:b], None)
 
         def inv_wsums(wv, bl):
             # batches are static (shuffle=False): their weight sums are known before the first step
@@ -832,11 +960,11 @@ class AutoEncoderTask(TrainingTask):
         for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
             self.model.train()
             for it, (a, b) in enumerate(tr_batches):
-                log_tr[it] = self._step(self._feature_traj, itr[a:b], wtr[a:b], True, iw_tr[it], advance=True,
+                log_tr[it] = self._step(*rows_of(ftr, itr, a, b), wtr[a:b], True, iw_tr[it], advance=True,
                                         fuse_adam=(world == 1))
             self.model.eval()
             for it, (a, b) in enumerate(te_batches):
-                log_te[it] = self._step(self._feature_traj, ite[a:b], wte[a:b], False, iw_te[it])
+                log_te[it] = self._step(*rows_of(fte, ite, a, b), wte[a:b], False, iw_te[it])
             elog.push(epoch)
             saving = self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1
             plotting = self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1
@@ -936,6 +1064,9 @@ class _RegFlatParams:
 
     def repack(self):
         pass
+
+    def grad_views(self):
+        return [(p, gv) for p, _, gv in self.views]
 
 
 class RegAutoEncoderTask(TrainingTask):
@@ -1037,13 +1168,13 @@ class RegAutoEncoderTask(TrainingTask):
 
     def colvar_model(self):
         """core.py:855-863."""
-        return torch.nn.Sequential(self.preprocessing_layer, self.model.encoder)
+        return _CVModel(self.preprocessing_layer, self.model.encoder, device=self.device)
 
     def reg_model(self):
         """core.py:865-877."""
         if self._cvec is None:
             self._cvec = torch.arange(self.model.num_reg)
-        return torch.nn.Sequential(self.preprocessing_layer, RegModel(self.model, self._cvec))
+        return _CVModel(self.preprocessing_layer, RegModel(self.model, self._cvec), device=self.device)
 
     def _workspace(self, B):
         ws = self._ws.get(B)

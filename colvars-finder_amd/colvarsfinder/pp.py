@@ -149,24 +149,28 @@ class AlignFeatureLayer(torch.nn.Module):
         return d
 
     def forward(self, x):
-        """``[B, N, 3]`` fp32 device tensor -> ``[B, d_r]`` (no autograd: the training tasks use the
-        analytic derivative kernels instead of differentiating through this call)."""
-        _hip.require_gpu(x.device)
+        """``[B, N, 3]`` -> ``[B, d_r]``.  The reference calls this layer (through ``colvar_model()``) on CPU tensors
+        made from the trajectory (2d.ipynb:437-446, main.ipynb:561-562): the frames are moved to the layer's GPU, run
+        through kernel K1 and the features come back on the input's device in the input's floating-point type.  No
+        autograd: the training tasks use the analytic derivative kernels instead of differentiating through this call."""
+        x = torch.as_tensor(x)
+        dev = _hip.require_gpu(self.rec.device)   # raises when the layer was never moved to a GPU: there is no CPU path
         assert x.dim() == 3 and x.shape[1] == self.n_atoms and x.shape[2] == 3, \
             f"expected [B,{self.n_atoms},3], got {tuple(x.shape)}"
-        if x.requires_grad:
+        if x.requires_grad and torch.is_grad_enabled():
             raise RuntimeError("AlignFeatureLayer.forward is not differentiable through autograd; "
-                               "EigenFunctionTask applies its analytic Jacobian on the GPU instead")
-        x = x.detach().to(torch.float32).contiguous()
+                               "EigenFunctionTask applies its analytic Jacobian on the GPU instead (detach the input)")
+        src_dev, src_dt = x.device, (x.dtype if x.dtype.is_floating_point else torch.float32)
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
         B = x.shape[0]
-        out = torch.empty(B, self.d_r, device=x.device, dtype=torch.float32)
-        if B == 0:
-            return out
-        desc = self.pp_desc()
-        scratch = _hip.align_scratch(desc, B, x.device)
-        _hip.check(_hip.lib().cvf_align_feature_fwd(desc, _hip.ptr(x), B, None, _hip.ptr(out), None, _hip.ptr(scratch),
-                                                    _hip.stream()), "cvf_align_feature_fwd")
-        return out
+        out = torch.empty(B, self.d_r, device=dev, dtype=torch.float32)
+        if B > 0:
+            with torch.cuda.device(dev):
+                desc = self.pp_desc()
+                scratch = _hip.align_scratch(desc, B, dev)
+                _hip.check(_hip.lib().cvf_align_feature_fwd(desc, _hip.ptr(x), B, None, _hip.ptr(out), None, _hip.ptr(scratch),
+                                                            _hip.stream()), "cvf_align_feature_fwd")
+        return out.to(device=src_dev, dtype=src_dt)
 
 
 class FeatureLayer:

@@ -9,6 +9,7 @@ struct AdamDev {           // device-side view of cvf_adam_args
   float lr, b1, b2, eps;
   const int32_t* step;     // number t >= 1 of the current step (advanced by the gradient kernel)
   float* packed;           // MFMA fragment copy to refresh, or nullptr
+  const float* lr_dev;     // device scalar overriding `lr` (a captured hipGraph then follows the host's learning rate), or nullptr
 };
 
 struct AdamScalars {
@@ -18,7 +19,8 @@ __device__ __forceinline__ AdamScalars adam_scalars(const AdamDev& a) {
   const int t = *a.step;
   const double bc1 = 1.0 - pow((double)a.b1, (double)t);
   const double bc2 = 1.0 - pow((double)a.b2, (double)t);
-  return AdamScalars{(float)((double)a.lr / bc1), (float)sqrt(bc2)};
+  const float lr = a.lr_dev != nullptr ? *a.lr_dev : a.lr;
+  return AdamScalars{(float)((double)lr / bc1), (float)sqrt(bc2)};
 }
 // torch.optim.Adam (single-tensor path): m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
 // theta -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)

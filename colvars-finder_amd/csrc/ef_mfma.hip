@@ -1876,7 +1876,7 @@ int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, fl
     CVF_REQUIRE(adam->packed == nullptr || (adam->mlp != nullptr && adam->mlp->n_params == n_params),
                 "cvf_slab_reduce: packed buffer needs its mlp desc");
     ad = AdamDev{adam->theta, adam->m, adam->v, (float)adam->lr, (float)adam->beta1, (float)adam->beta2, (float)adam->eps,
-                 adam->step_count, adam->packed};
+                 adam->step_count, adam->packed, adam->lr_dev};
     if (adam->packed) md = *adam->mlp;
   }
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n_params + kSlabPX - 1) / kSlabPX)), dim3(kSlabPX, kSlabGY), 0, (hipStream_t)stream, slab,

@@ -143,9 +143,10 @@ __global__ void adam_kernel(AdamDev a, const float* __restrict__ grad, int64_t n
     adam_apply(a, sc, tab, i, grad[i]);
 }
 
-__global__ void sgd_kernel(float* __restrict__ theta, const float* __restrict__ grad, int64_t n, float lr, cvf_mlp_desc mlp,
-                           float* __restrict__ packed) {
+__global__ void sgd_kernel(float* __restrict__ theta, const float* __restrict__ grad, int64_t n, float lr,
+                           const float* __restrict__ lr_dev, cvf_mlp_desc mlp, float* __restrict__ packed) {
   __shared__ PackTab tab;
+  if (lr_dev != nullptr) lr = *lr_dev;
   if (threadIdx.x == 0 && packed != nullptr) pack_tab_fill(tab, mlp);
   __syncthreads();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -219,26 +220,26 @@ extern "C" int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* l
   return cvf_check_launch("ef_loss_kernel");
 }
 
-extern "C" int cvf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
-                             double beta2, double eps, int32_t* step_count, const cvf_mlp_desc* mlp, float* packed,
-                             void* stream) {
+extern "C" int cvf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, double lr, const float* lr_dev,
+                             double beta1, double beta2, double eps, int32_t* step_count, const cvf_mlp_desc* mlp,
+                             float* packed, void* stream) {
   CVF_REQUIRE(theta && grad && m && v && step_count && n > 0, "cvf_adam_step: bad argument");
   CVF_REQUIRE(packed == nullptr || (mlp != nullptr && mlp->n_params == n), "cvf_adam_step: packed buffer needs its mlp desc");
   cvf_mlp_desc none = {};
   const cvf_mlp_desc& md = packed ? *mlp : none;
   const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-  AdamDev ad{theta, m, v, (float)lr, (float)beta1, (float)beta2, (float)eps, step_count, packed};
+  AdamDev ad{theta, m, v, (float)lr, (float)beta1, (float)beta2, (float)eps, step_count, packed, lr_dev};
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ad, grad, n, md);
   return cvf_check_launch("adam_kernel");
 }
 
-extern "C" int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, const cvf_mlp_desc* mlp, float* packed,
-                            void* stream) {
+extern "C" int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, const float* lr_dev,
+                            const cvf_mlp_desc* mlp, float* packed, void* stream) {
   CVF_REQUIRE(theta && grad && n > 0, "cvf_sgd_step: bad argument");
   CVF_REQUIRE(packed == nullptr || (mlp != nullptr && mlp->n_params == n), "cvf_sgd_step: packed buffer needs its mlp desc");
   cvf_mlp_desc none = {};
   const cvf_mlp_desc& md = packed ? *mlp : none;
   const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-  hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, grad, n, (float)lr, md, packed);
+  hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, grad, n, (float)lr, lr_dev, md, packed);
   return cvf_check_launch("sgd_kernel");
 }

@@ -116,6 +116,8 @@ typedef struct cvf_adam_args {
   const int32_t* step_count;   /* device: number t >= 1 of the current step */
   const cvf_mlp_desc* mlp;     /* with `packed`: the nets whose fragment copy is refreshed, else NULL */
   float* packed;
+  const float* lr_dev;         /* device scalar that overrides `lr` when non-NULL: a captured hipGraph of the step then follows
+                                * a learning rate the host changes between replays (scheduler, manual decay) */
 } cvf_adam_args;
 
 int cvf_version(void);
@@ -286,10 +288,11 @@ int cvf_mlp_eval_rows(const cvf_mlp_desc* mlp, const float* theta, const float* 
  * step_count is a device int32 holding the number t of the CURRENT step (>= 1): it is advanced by the
  * gradient-producing call of the step (cvf_slab_reduce / cvf_ae_step), so a captured step replays
  * correctly without host involvement. */
-int cvf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, double lr, double beta1,
-                  double beta2, double eps, int32_t* step_count, const cvf_mlp_desc* mlp, float* packed, void* stream);
-int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, const cvf_mlp_desc* mlp, float* packed,
-                 void* stream); /* mlp/packed: NULL, or the nets' desc + fragment buffer to refresh */
+int cvf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, double lr, const float* lr_dev,
+                  double beta1, double beta2, double eps, int32_t* step_count, const cvf_mlp_desc* mlp, float* packed,
+                  void* stream);   /* lr_dev (may be NULL): device scalar overriding lr, as in cvf_adam_args */
+int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, const float* lr_dev, const cvf_mlp_desc* mlp,
+                 float* packed, void* stream); /* mlp/packed: NULL, or the nets' desc + fragment buffer to refresh */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,282 @@
+"""GPU (-m gpu): the reference's CALL CONTRACT on the MI355X path, and the rows of SURVEY section 8f that surround the step.
+
+The reference's users evaluate the learned collective variables on CPU tensors made from the trajectory and take
+``.detach().numpy()`` of the result (examples/2d/2d.ipynb:437-446, examples/dipeptide/main.ipynb:561-562); its training
+loops hand ``self.colvar_model()`` to a user ``plot_class`` (core.py:530-532, 720-722); its tasks expose a
+``torch.optim`` object as ``task.optimizer`` (core.py:163-166) and restart from ``load_model_filename``
+(core.py:156-161).  These tests make exactly those calls (own code; nothing copied from the notebooks).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.synth import Traj, diag_coeff_for, make_2d_traj, make_molecule_traj
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _restore_dtype():
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+def _position_layer(n_atoms, ref, dev):
+    from colvarsfinder import pp
+    return pp.AlignFeatureLayer(n_atoms, list(range(n_atoms)), ref, [("position", tuple(range(n_atoms)))]).to(dev)
+
+
+class _Recorder:
+    """A user plot class: evaluates the CV model the way the notebooks' plotting cells do - CPU tensor in, numpy out."""
+
+    def __init__(self, traj, with_reg=False):
+        self.X = torch.tensor(traj)            # CPU tensor, default dtype cast as torch.tensor does
+        self.calls = []
+        self.with_reg = with_reg
+
+    def plot(self, cv_model, reg_model=None, epoch=0):
+        out = cv_model(self.X).detach().numpy()
+        assert isinstance(out, np.ndarray) and out.shape[0] == self.X.shape[0]
+        if self.with_reg:
+            assert reg_model is not None
+            r = reg_model(self.X).detach().numpy()
+            assert r.shape[0] == self.X.shape[0]
+        self.calls.append((epoch, out))
+
+
+def _ef_task(dev, tmp_path, n_atoms=10, n_frames=400, k=2, lag_tau=0.0, **kw):
+    from colvarsfinder import core, nn
+    traj, w, ref = make_molecule_traj(n_atoms, n_frames, seed=901)
+    layer = _position_layer(n_atoms, ref, dev)
+    torch.manual_seed(11)
+    model = nn.EigenFunctions([3 * n_atoms, 20, 20, 20, 1], k)
+    a = torch.tensor(diag_coeff_for(n_atoms, 4), dtype=torch.float32)
+    args = dict(diag_coeff=a if lag_tau == 0 else None, beta=1.0, lag_tau=lag_tau, learning_rate=1e-3, k=k, batch_size=100,
+                num_epochs=3, device=dev, verbose=False, save_model_every_step=0)
+    args.update(kw)
+    task = core.EigenFunctionTask(Traj(traj, w, 0.5), layer, model, str(tmp_path), 10.0, [1.0, 0.6][:k], **args)
+    return task, traj, w
+
+
+def test_colvar_model_takes_cpu_tensors_like_the_notebooks(dev, tmp_path):
+    """EigenFunctionTask: ``cv = task.colvar_model(); cv(torch.tensor(traj)).detach().numpy()`` and the plot callback
+    inside train() (core.py:530-532), generator and transfer mode."""
+    for lag_tau in (0.0, 1.0):
+        rec_traj = make_molecule_traj(10, 400, seed=901)[0]
+        plotter = _Recorder(rec_traj)
+        np.random.seed(3)
+        task, traj, w = _ef_task(dev, tmp_path, lag_tau=lag_tau, plot_class=plotter, plot_frequency=1)
+        task.train()
+        assert [e for e, _ in plotter.calls] == [0, 1, 2]
+        cv_model = task.colvar_model()
+        x_cpu = torch.tensor(traj)                       # what the notebooks build from traj_obj.trajectory
+        out = cv_model(x_cpu)
+        assert out.device.type == "cpu" and out.dtype == x_cpu.dtype and tuple(out.shape) == (400, 2)
+        got = out.detach().numpy()
+        on_gpu = cv_model(x_cpu.to(dev))                 # device tensors keep working and stay on the device
+        assert on_gpu.device.type == "cuda"
+        np.testing.assert_allclose(got, on_gpu.cpu().numpy(), rtol=0, atol=0)
+        np.testing.assert_allclose(plotter.calls[-1][1], got, rtol=0, atol=0)   # the last callback saw the final model
+        # float64 input (text trajectories, np.loadtxt): answered in float64
+        assert cv_model(torch.tensor(traj, dtype=torch.float64)).dtype == torch.float64
+        # the layer alone, as a user would call pp_layer(x)
+        feats = task.preprocessing_layer(x_cpu)
+        assert feats.device.type == "cpu" and tuple(feats.shape) == (400, 30)
+
+
+def test_autoencoder_and_identity_layer_cpu_calls(dev, tmp_path):
+    """AutoEncoderTask with the 2-D examples' Identity layer and with the alignment layer: colvar_model() on CPU tensors,
+    plot callback inside train() (core.py:720-722)."""
+    from colvarsfinder import core, nn
+    x2d, w2d = make_2d_traj(600, seed=5, dtype=np.float64)
+    plotter = _Recorder(x2d)
+    torch.manual_seed(2)
+    model = nn.AutoEncoder([2, 20, 20, 1], [1, 20, 20, 2])
+    np.random.seed(8)
+    task = core.AutoEncoderTask(Traj(x2d, w2d, 0.1), torch.nn.Identity(), model, str(tmp_path), learning_rate=5e-3, batch_size=200,
+                                num_epochs=2, device=dev, verbose=False, save_model_every_step=0, plot_class=plotter,
+                                plot_frequency=1)
+    task.train()
+    assert len(plotter.calls) == 2
+    cv = task.colvar_model()(torch.tensor(x2d)).detach().numpy()      # float64 CPU in -> float64 numpy out
+    assert cv.shape == (600, 1) and cv.dtype == np.float64
+    np.testing.assert_allclose(cv, plotter.calls[-1][1], rtol=0, atol=0)
+
+    traj, w, ref = make_molecule_traj(10, 300, seed=77)
+    torch.manual_seed(2)
+    model = nn.AutoEncoder([30, 20, 2], [2, 20, 30])
+    task = core.AutoEncoderTask(Traj(traj, w, 1.0), _position_layer(10, ref, dev), model, str(tmp_path), batch_size=100, num_epochs=1,
+                                device=dev, verbose=False, save_model_every_step=0)
+    task.train()
+    out = task.colvar_model()(torch.tensor(traj)).detach().numpy()
+    assert out.shape == (300, 2) and np.isfinite(out).all()
+
+
+def test_regautoencoder_models_take_cpu_tensors(dev, tmp_path):
+    """RegAutoEncoderTask: plot_class.plot(colvar_model(), reg_model(), epoch=) (core.py:1136-1140) with CPU evaluation."""
+    from colvarsfinder import core, nn
+    traj, w, ref = make_molecule_traj(10, 400, seed=12)
+    plotter = _Recorder(traj, with_reg=True)
+    torch.manual_seed(4)
+    model = nn.RegAutoEncoder([30, 20, 2], [2, 20, 30], [2, 20, 1], 2)
+    np.random.seed(1)
+    task = core.RegAutoEncoderTask(Traj(traj, w, 1.0), _position_layer(10, ref, dev), model, str(tmp_path), eig_weights=[1.0, 0.5],
+                                   batch_size=100, num_epochs=2, alpha=1.0, gamma=[1.0, 5.0], lag_tau_ae=1.0, lag_tau_reg=1.0,
+                                   device=dev, verbose=False, save_model_every_step=0, plot_class=plotter, plot_frequency=1)
+    task.train()
+    assert len(plotter.calls) == 2
+    r = task.reg_model()(torch.tensor(traj)).detach().numpy()
+    assert r.shape == (400, 2) and np.isfinite(r).all()
+
+
+def test_optimizer_surface_lr_change_reaches_captured_graphs(dev, tmp_path):
+    """``task.optimizer.param_groups[0]['lr']`` changed between epochs (a scheduler / manual decay) must take effect although
+    every step after the first epoch is a hipGraph replay: the kernels read the rate from a device scalar."""
+    snaps = {}
+
+    class Decay:
+        def plot(self, cv_model, epoch=0):
+            snaps[epoch] = torch.cat([p.detach().reshape(-1) for p in task.model.parameters()]).cpu().clone()
+            if epoch == 1:
+                task.optimizer.param_groups[0]["lr"] = 0.0     # from here on the parameters must stand still
+
+    np.random.seed(5)
+    task, _, _ = _ef_task(dev, tmp_path, num_epochs=4, plot_class=Decay(), plot_frequency=1)
+    assert task._use_graphs
+    pg = task.optimizer.param_groups[0]
+    assert pg["lr"] == 1e-3 and pg["betas"] == (0.9, 0.999) and pg["eps"] == 1e-8 and len(pg["params"]) == len(list(task.model.parameters()))
+    task.train()
+    assert not torch.equal(snaps[0], snaps[1])              # lr = 1e-3: moving
+    assert torch.equal(snaps[1], snaps[2]) and torch.equal(snaps[2], snaps[3])   # lr = 0 inside replayed graphs
+
+
+def test_optimizer_step_honours_edited_grads(dev, tmp_path):
+    """loss_func -> backward() -> (user edits p.grad, e.g. clipping) -> optimizer.step(): the edit counts, as with torch.optim."""
+    task, traj, w = _ef_task(dev, tmp_path)
+    before = torch.cat([p.detach().reshape(-1) for p in task.model.parameters()]).clone()
+    task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    task.backward()
+    assert all(p.grad is not None and float(p.grad.abs().sum()) >= 0 for p in task.model.parameters())
+    for p in task.model.parameters():
+        p.grad.zero_()
+    task.optimizer.step()
+    after = torch.cat([p.detach().reshape(-1) for p in task.model.parameters()])
+    assert torch.equal(before, after)                       # zero gradient, zero moments: Adam leaves the parameters alone
+    task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    task.backward()
+    task.optimizer.step()
+    assert not torch.equal(before, torch.cat([p.detach().reshape(-1) for p in task.model.parameters()]))
+    task.optimizer.zero_grad()
+    assert all(p.grad is None for p in task.model.parameters())
+
+
+def test_restart_from_model_file_and_optimizer_state(dev, tmp_path):
+    """core.py:156-161 ``load_model_filename`` (+ the optimizer state the reference does not checkpoint):
+    3 epochs, save, new task restarted from the files, 2 more epochs == 5 epochs in one go (same batches)."""
+    import os
+
+    def run(path, epochs, load=None, opt_state=None):
+        np.random.seed(21)                                   # train() draws the split from NumPy's global RNG
+        task, _, _ = _ef_task(dev, path, num_epochs=epochs, load_model_filename=load)
+        if opt_state is not None:
+            task.optimizer.load_state_dict(opt_state)
+        task.train()
+        return task
+
+    full = run(tmp_path / "full", 5)
+    part = run(tmp_path / "part", 3)
+    part.save_model(2)
+    fname = str(tmp_path / "part" / "latest" / "model.pt")
+    assert os.path.isfile(fname)
+    state = part.optimizer.state_dict()
+    assert state["step"] == 3 * 3 and state["exp_avg"].device.type == "cpu"      # 320 train frames / 100 = 3 steps per epoch
+    torch.save(state, str(tmp_path / "opt.pt"))
+    rest = run(tmp_path / "rest", 2, load=fname, opt_state=torch.load(str(tmp_path / "opt.pt")))
+    # the restarted model picks up the saved parameters ...
+    got0 = torch.load(fname)
+    assert set(got0) == set(full.model.state_dict())
+    # ... and, with the moments and the step number restored, continues exactly where the first run stood
+    for (n, a), (_, b) in zip(full.model.state_dict().items(), rest.model.state_dict().items()):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=n)
+    for e in range(2):
+        np.testing.assert_allclose(rest.loss_list[e][0].numpy(), full.loss_list[3 + e][0].numpy(), rtol=1e-6)
+    # without the optimizer state the restart is a different trajectory (Adam's bias correction starts over)
+    cold = run(tmp_path / "cold", 2, load=fname)
+    assert not np.allclose(cold.loss_list[1][0].numpy(), full.loss_list[4][0].numpy(), rtol=1e-6)
+    # a missing file is reported, not fatal (core.py:160-161)
+    run(tmp_path / "none", 1, load=str(tmp_path / "does_not_exist.pt"))
+
+
+def test_unsupported_net_shape_is_rejected_at_construction(dev, tmp_path):
+    from colvarsfinder import core, nn
+    traj, w, ref = make_molecule_traj(10, 100, seed=1)
+    for dims in ([30, 64, 64, 1], [30, 20, 10, 1]):
+        model = nn.EigenFunctions(dims, 2)
+        with pytest.raises(NotImplementedError, match="no kernel instance"):
+            core.EigenFunctionTask(Traj(traj, w, 1.0), _position_layer(10, ref, dev), model, str(tmp_path), 10.0, [1.0, 0.5], k=2,
+                                   device=dev, verbose=False)
+    with pytest.raises(NotImplementedError, match="Tanh"):
+        core.EigenFunctionTask(Traj(traj, w, 1.0), _position_layer(10, ref, dev), nn.EigenFunctions([30, 20, 1], 1, torch.nn.ReLU()),
+                               str(tmp_path), 10.0, [1.0], k=1, device=dev, verbose=False)
+
+
+@pytest.mark.parametrize("kind", ["f32", "f64", "strided", "small"])
+def test_upload_matches_tensor_to(dev, kind):
+    """the trajectory's way into HBM (page-locked single DMA for fp32, chunked convert-and-copy through two
+    pinned staging buffers otherwise) is byte-equal to ``torch.as_tensor(a).to(float32).to(device)``."""
+    from colvarsfinder import _hip
+    rs = np.random.RandomState(0)
+    if kind == "f32":
+        a = rs.standard_normal((150_000, 22, 3)).astype(np.float32)            # 39.6 MB: the hipHostRegister path
+    elif kind == "f64":
+        a = rs.standard_normal((150_000, 22, 3))                                  # fp64 source: chunked conversion
+    elif kind == "strided":
+        a = rs.standard_normal((150_000, 44, 3)).astype(np.float32)[:, ::2, :]  # non-contiguous fp32
+    else:
+        a = rs.standard_normal((100, 22, 3))
+    torch.cuda.synchronize()
+    got = _hip.upload_f32(a, dev, chunk_bytes=8 << 20) if kind != "small" else _hip.upload_f32(a, dev)
+    want = torch.as_tensor(np.ascontiguousarray(a)).to(torch.float32).to(dev)
+    assert got.dtype == torch.float32 and got.is_contiguous() and tuple(got.shape) == tuple(a.shape)
+    assert torch.equal(got, want)
+
+
+class _AtomGroup:
+    """Duck-typed MDAnalysis AtomGroup: the two attributes the constructors read."""
+
+    def __init__(self, ix, positions=None):
+        self.ix = np.asarray(ix)
+        self.positions = positions
+
+    def __len__(self):
+        return len(self.ix)
+
+
+def test_molann_style_layer_runs_on_the_gpu_vs_oracle(dev):
+    """PreprocessingANN(AlignmentLayer(...), FeatureLayer(...)) built the way main.ipynb:333-348 builds it
+    (global atom indices, positions of the align group), run on the GPU, against the CPU oracle on local indices."""
+    from colvarsfinder import pp
+    from oracle.pp import AlignFeature
+    glob = [1, 4, 5, 6, 8, 10, 14, 15, 16, 18]
+    traj, _, ref = make_molecule_traj(10, 500, seed=44)
+    input_ag = _AtomGroup(glob, ref.astype(np.float32))
+    align_ag = _AtomGroup(glob[:7], ref[:7].astype(np.float32))
+    feats = [pp.Feature("p1", "position", input_ag), pp.Feature("d1", "dihedral", _AtomGroup([4, 6, 8, 14])),
+             pp.Feature("a1", "angle", _AtomGroup([5, 6, 8])), pp.Feature("b1", "bond", _AtomGroup([1, 18]))]
+    layer = pp.PreprocessingANN(pp.AlignmentLayer(align_ag, input_ag), pp.FeatureLayer(feats, input_ag)).to(dev)
+    got = layer(torch.tensor(traj)).numpy()                  # CPU in, CPU out
+    local = {g: i for i, g in enumerate(glob)}
+    spec_feats = [("position", tuple(range(10))), ("dihedral", tuple(local[g] for g in [4, 6, 8, 14])),
+                  ("angle", tuple(local[g] for g in [5, 6, 8])), ("bond", (local[1], local[18]))]
+    torch.set_default_dtype(torch.float64)
+    want = AlignFeature(list(range(7)), ref[:7].astype(np.float32).astype(np.float64), spec_feats, False)(
+        torch.tensor(traj, dtype=torch.float64)).numpy()
+    assert got.shape == want.shape == (500, 34)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6 * np.abs(want).max())

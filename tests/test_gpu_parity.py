@@ -286,7 +286,7 @@ def test_fused_adam_matches_torch(dev):
         a = st["alone"]
         a["step"] += 1                                   # what the gradient kernel of a step does on the device
         _hip.check(lib.cvf_slab_reduce(_hip.ptr(rows), 3, n, _hip.ptr(a["grad"]), None, _hip.stream()), "reduce")
-        _hip.check(lib.cvf_adam_step(_hip.ptr(a["theta"]), _hip.ptr(a["grad"]), _hip.ptr(a["m"]), _hip.ptr(a["v"]), n, 1e-3, 0.9,
+        _hip.check(lib.cvf_adam_step(_hip.ptr(a["theta"]), _hip.ptr(a["grad"]), _hip.ptr(a["m"]), _hip.ptr(a["v"]), n, 1e-3, None, 0.9,
                                      0.999, 1e-8, _hip.ptr(a["step"]), None, None, _hip.stream()), "adam")
         f = st["fused"]
         f["step"] += 1

@@ -301,3 +301,21 @@ def test_export_twin_matches_oracle_and_scripts(tmp_path, angle_value):
     loaded = torch.jit.load(path)
     x32 = torch.tensor(traj, dtype=torch.float32)
     np.testing.assert_allclose(loaded(x32).detach().numpy(), cv(x32).detach().numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,bs,world", [(4000, 1000, 2), (3998, 1000, 8), (1000, 1001, 4), (80000, 20000, 8), (317, 100, 3)])
+def test_shard_batches_partitions_every_global_batch(n, bs, world):
+    """SURVEY 8e partitioning: every rank keeps only its slice of every static batch; the slices of one batch tile that
+    batch exactly, in order; the dropped tail (drop_last=True, core.py:474) is resident nowhere; a rank holds ~1/world."""
+    from colvarsfinder import _dist
+    bs = min(bs, n)
+    plans = [_dist.shard_batches(n, bs, r, world) for r in range(world)]
+    n_batches = n // bs
+    for j in range(n_batches):
+        rows = np.concatenate([pos[j * nb:(j + 1) * nb] for pos, nb in plans])
+        assert np.array_equal(rows, np.arange(j * bs, (j + 1) * bs))
+    total = sum(len(pos) for pos, _ in plans)
+    assert total == n_batches * bs
+    for pos, nb in plans:
+        assert len(pos) == n_batches * nb and abs(nb - bs / world) < 1
+    assert _dist.shard_batches(n, bs, 0, 1)[0].tolist() == list(range(n_batches * bs))

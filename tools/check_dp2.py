@@ -49,6 +49,9 @@ def run(kind, out_path):
         skip = ".4.bias" if kind in ("gen", "tr") else "\0"
         params = np.concatenate([p.detach().cpu().numpy().reshape(-1) for n, p in model.named_parameters() if not n.endswith(skip)])
         np.savez(out_path, losses=losses, params=params)
+    # frames this process keeps in HBM (the trajectory / feature rows and train()'s gathers), for the 1/world check
+    with open(out_path.replace(".npz", f"_r{_dist.rank()}.json"), "w") as fh:
+        json.dump(dict(resident_bytes=int(task.resident_bytes), world=_dist.world(), frames=5000, n_atoms=n_atoms), fh)
     if _dist.world() > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -78,8 +81,14 @@ def main():
         a, b = np.load(f"/tmp/dp2_{kind}_w1.npz"), np.load(f"/tmp/dp2_{kind}_w2.npz")
         dl = float(np.max(np.abs(a["losses"] - b["losses"]) / np.maximum(np.abs(a["losses"]), 1e-3)))
         dp = float(np.max(np.abs(a["params"] - b["params"])))
-        report[kind] = dict(steps=int(a["losses"].shape[0]), max_rel_loss_diff=dl, max_abs_param_diff=dp)
-        ok = ok and dl < 2e-4 and dp < 2e-3
+        # shard residency: a rank of the two-rank job holds about half of the frames the job touches - its slices
+        # of the static batches (+ their lagged partners in transfer mode) - never the whole trajectory
+        res = [json.load(open(f"/tmp/dp2_{kind}_w2_r{r}.json"))["resident_bytes"] for r in range(2)]
+        per_frame = {"gen": 22 * 12 + 4, "tr": 2 * (22 * 12 + 4), "ae": 66 * 4}[kind]
+        whole = 5000 * per_frame
+        report[kind] = dict(steps=int(a["losses"].shape[0]), max_rel_loss_diff=dl, max_abs_param_diff=dp,
+                            resident_bytes_per_rank=res, whole_set_bytes=whole)
+        ok = ok and dl < 2e-4 and dp < 2e-3 and all(0.35 * whole <= r <= 0.505 * whole for r in res)
     print(json.dumps(dict(check="two ranks (gloo, one GPU) vs one process", ok=ok, **report)))
     if not ok:
         raise SystemExit(1)
