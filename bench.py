@@ -7,8 +7,10 @@ generator mode with k = 3 nets [66,20,20,20,1], diffusion-weighted diag_coeff, a
 One "step" = one full train step on one batch resident in HBM: align+features (K1), nets forward and
 input gradients (K4a), q = J A J^T g (K2/K3), batch sums (K5), loss tail, parameter gradient (K4b),
 Adam (K6).  With N > 1 (one process per GPU, launched by torch.distributed.run) every rank owns its own
-shard of frames and the global batch is N x --batch frames (weak scaling); the two all-reduces of
-SURVEY.md section 8e (batch sums before the backward pass, flat gradient after it) run over RCCL.
+block of the frames and the two all-reduces of SURVEY.md section 8e (batch sums before the backward pass, flat gradient
+after it) run over RCCL.  N > 1 defaults to STRONG scaling on BASELINE config 4: 1 M frames in all (1/N resident per GPU), a
+fixed global batch (--global-batch, default 160 000 frames per step of the whole job); --scaling weak keeps --batch frames
+per GPU.  Every line also carries `scaling_table`: the same job at global batches 20 000 / 160 000 / 800 000 and the weak line.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = frames of all ranks / second.
 """
@@ -43,6 +45,13 @@ FLOP_FWD = 2 * K_NETS * (P_W + (P_W - 66 * 20) + 66 * 20)            # forward +
 FLOP_K1 = 2 * (12 + 12) * N_ATOMS + 1500              # covariance + aligned positions per atom, 3x3 eigen-solve
 FLOP_METRIC = 2 * K_NETS * 33 * N_ATOMS          # three passes of q = J A J^T g: ~33 fused multiply-adds per atom and net
 FLOP_BWD = 2 * K_NETS * (P_W + 800 + 2 * P_W)  # tangent chain, zbar chain, outer products (h and the d chain come from the forward kernel)
+FLOP_OF_CALL = {"cvf_ef_backward": FLOP_BWD, "cvf_ef_mlp_fwd": FLOP_FWD, "cvf_ef_fwd_metric_stats": FLOP_FWD + FLOP_METRIC,
+                "cvf_ef_align_fwd_metric_stats": FLOP_FWD + FLOP_METRIC + FLOP_K1}
+KERNEL_OF_CALL = {"cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
+                  "cvf_ef_fwd_metric_stats": "ef_fwd_metric_kernel", "cvf_ef_align_fwd_metric_stats": "ef_fwd_metric_kernel",
+                  "cvf_align_feature_fwd": "k1_align_quad_kernel", "cvf_align_feature_fwd@1M": "k1_stream_kernel",
+                  "cvf_align_feature_fwd@c5": "k1_large_slice_kernel"}
+PROFILE_TAG = "r2"   # profiles/<tag>_pmc_traffic.json is the committed PMC summary `roofline.traffic` is read from
 
 
 def make_shard(n_frames, rank, n_atoms=N_ATOMS, scale=2.0, sigma=0.3):
@@ -99,14 +108,81 @@ def cpu_baseline(x, w, ref, a, sd0, batch, budget_s):
                        f"first batch of {batch} frames, {el:.1f} s")
 
 
+def device_frames(n, ref, sigma, seed, dev, chunk=200_000):
+    """Synthetic frames x_b = Q_b (ref + sigma xi_b) + t_b generated ON the device (a random rotation and
+    translation of a noisy copy of the reference) + mean-normalised weights U(0.2, 2).  torch is plumbing here: it fills HBM."""
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    refd = torch.tensor(ref, device=dev, dtype=torch.float32)
+    x = torch.empty(n, refd.shape[0], 3, device=dev, dtype=torch.float32)
+    for s0 in range(0, n, chunk):
+        m = min(chunk, n - s0)
+        q = torch.randn(m, 4, device=dev, generator=g)
+        q = q / q.norm(dim=1, keepdim=True)
+        w_, x_, y_, z_ = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (y_ * y_ + z_ * z_), 2 * (x_ * y_ - z_ * w_), 2 * (x_ * z_ + y_ * w_),
+                         2 * (x_ * y_ + z_ * w_), 1 - 2 * (x_ * x_ + z_ * z_), 2 * (y_ * z_ - x_ * w_),
+                         2 * (x_ * z_ - y_ * w_), 2 * (y_ * z_ + x_ * w_), 1 - 2 * (x_ * x_ + y_ * y_)], dim=1).view(m, 3, 3)
+        noisy = refd[None] + sigma * torch.randn(m, refd.shape[0], 3, device=dev, generator=g)
+        x[s0:s0 + m] = torch.einsum("bij,baj->bai", R, noisy) + torch.randn(m, 1, 3, device=dev, generator=g)
+    w = 0.2 + 1.8 * torch.rand(n, device=dev, generator=g)
+    return x, (w / w.mean()).contiguous()
+
+
+def note(msg):
+    """Progress line on stderr (rank 0): a long run keeps talking, and a crash is located by the last line."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def run_steps(task, X, Wt, B, steps, warmup, tag, world, dev, max_batches=8):
+    """W untimed + EXACTLY K timed train steps of the product's own step path (EigenFunctionTask._graph_step: one hipGraph
+    replay per static batch) on this rank's resident rows, B frames per rank per step; the timed region is bracketed by a
+    barrier + device synchronisation on both sides.  Returns (max-over-ranks seconds, last loss vector)."""
+    n_batches = max(1, min(X.shape[0] // B, max_batches))
+    log = torch.zeros(n_batches, 3 + 2 * task.k, device=dev, dtype=torch.float64)
+
+    def step(i):
+        b = i % n_batches
+        s = b * B
+        task._graph_step((tag, b), lambda: task.train_step(X[s:s + B], Wt[s:s + B]), log[b])
+        return log[b]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(warmup, n_batches if task._use_graphs else 0)):   # (every batch's graph is captured before the clock starts)
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        lv = step(warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax)
+    assert np.isfinite(float(lv[0])), "training diverged"
+    return elapsed, lv, step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=20000, help="frames per GPU per step (reference notebook: 20000)")
-    ap.add_argument("--frames", type=int, default=100000, help="frames per GPU shard (config 3: 100k)")
+    ap.add_argument("--batch", type=int, default=20000,
+                    help="N=1 line: frames per step (reference notebook: 20000); --scaling weak: frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=100000, help="N=1 line: frames resident (config 3: 100k)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default=None,
+                    help="N>1: strong (default) = BASELINE config 4, --frames-total frames and --global-batch frames per step split "
+                         "over the ranks; weak = --batch frames per GPU per step")
+    ap.add_argument("--frames-total", type=int, default=1_000_000, help="config 4: frames of the whole job")
+    ap.add_argument("--global-batch", type=int, default=160_000, help="strong scaling: frames per step of the whole job")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 disables it)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other global batches, K1 rooflines)")
     ap.add_argument("--workload", choices=["c3", "c5", "c2", "regae"], default="c3",
                     help="c3 = the benchmark line; c5 = config-5 shape, c2 = config-2 AutoEncoderTask (extra measurements)")
     args = ap.parse_args()
@@ -117,7 +193,7 @@ def main():
     if args.workload == "c2":
         return main_c2(args)
 
-    from colvarsfinder import _dist, core, nn, pp
+    from colvarsfinder import _dist, _hip, core, nn, pp
     from tests.synth import Traj, diag_coeff_for
 
     _dist.init_from_env("nccl")
@@ -125,84 +201,65 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
 
-    x, w, ref = make_shard(args.frames, rank)
+    ref = np.random.RandomState(SEED).normal(scale=2.0, size=(N_ATOMS, 3))
     a = torch.tensor(diag_coeff_for(N_ATOMS, SEED), dtype=torch.float32)
     torch.manual_seed(SEED)
     model = nn.EigenFunctions(LAYERS, K_NETS)
     sd0 = {n: p.detach().clone() for n, p in model.state_dict().items()}
     layer = pp.AlignFeatureLayer(N_ATOMS, list(range(N_ATOMS)), ref, [("position", tuple(range(N_ATOMS)))])
-    task = core.EigenFunctionTask(Traj(x, w, 1.0), layer, model, "/tmp/cvf_bench", ALPHA, EIG_W, diag_coeff=a, beta=BETA,
+    # The task is built on a token trajectory: bench.py owns the resident frames (generated on the device) and drives the
+    # task's own step path on them, exactly as EigenFunctionTask.train() does on its resident batches.
+    tok = np.zeros((64, N_ATOMS, 3), dtype=np.float32) + ref[None].astype(np.float32)
+    task = core.EigenFunctionTask(Traj(tok, np.ones(64), 1.0), layer, model, "/tmp/cvf_bench", ALPHA, EIG_W, diag_coeff=a, beta=BETA,
                                   lag_tau=0, learning_rate=LR, k=K_NETS, batch_size=args.batch, device=dev, verbose=False,
                                   save_model_every_step=0)
-    B = min(args.batch, args.frames)
-    n_batches = args.frames // B
-    X, Wt = task._traj, task._weights
 
-    log = torch.zeros(n_batches, 3 + 2 * K_NETS, device=dev, dtype=torch.float64)
+    def restart():
+        """Same initial parameters and optimizer state for every measured configuration."""
+        model.load_state_dict(sd0)
+        task._flat.repack()
+        task.optimizer.exp_avg.zero_(); task.optimizer.exp_avg_sq.zero_(); task.optimizer.step_count.zero_()
 
-    pipeline = task._pipeline
-
-    def step(i):
-        # the product's own step path (EigenFunctionTask.train): whole-step hipGraph replay per (static) batch, and the
-        # alignment kernel of batch i+1 - which does not depend on the parameters - running beside step i
-        b = i % n_batches
-        s = b * B
-        if pipeline:
-            s2 = ((i + 1) % n_batches) * B
-            task._graph_step(("bench", b, i % 2, i > 0),
-                             lambda: task.train_step(X[s:s + B], Wt[s:s + B], slot=i % 2, aligned=i > 0, prefetch=(X[s2:s2 + B], None)),
-                             log[b])
-        else:
-            task._graph_step(("bench", b), lambda: task.train_step(X[s:s + B], Wt[s:s + B]), log[b])
-        return log[b]
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
+    # ---- the headline workload of this N
+    if world == 1 or scaling == "weak":
+        frames_rank, B = args.frames, min(args.batch, args.frames)
+        workload = ("BASELINE config 3: alanine-dipeptide-shaped EigenFunctionTask, generator mode, k=3, 22 atoms, align+position "
+                    "features d_r=66, nets [66,20,20,20,1], diag_coeff, Adam")
+    else:
+        assert args.global_batch % world == 0 and args.frames_total % world == 0
+        frames_rank, B = args.frames_total // world, args.global_batch // world
+        workload = (f"BASELINE config 4: config-3 model on {args.frames_total} frames sharded over {world} GPUs "
+                    f"({frames_rank} resident per GPU), global batch {args.global_batch} fixed (strong scaling), all-reduce of the "
+                    "batch sums + flat gradient per step")
+    X, Wt = device_frames(frames_rank, ref, 0.3, SEED + 1 + rank, dev)
+    note(f"headline: {frames_rank} frames resident per GPU, {B} per GPU per step, {world} GPU(s), {scaling} scaling")
+    elapsed, loss_vec, step = run_steps(task, X, Wt, B, args.steps, args.warmup, "bench", world, dev)
     graphs = task._use_graphs
-    if not graphs:
-        task._events = {}
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss_vec = step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if graphs:
-        # graph replay hides the individual launches: time them with HIP events around every C-ABI call over
-        # a second, eager pass of the same K steps (not part of `value`)
-        task._use_graphs, task._events, task._last_call = False, {}, {}
-        for i in range(args.steps):
-            # park the GPU while the host queues this step's launches, so that the events bracket back-to-back
-            # kernel executions rather than the host's launch latency
-            torch.cuda._sleep(2_000_000)
-            step(args.warmup + args.steps + i)
-        barrier()
-        task._use_graphs = True
+    final_loss = float(loss_vec[0])
+
+    # ---- per-kernel durations: HIP events around every C-ABI call over a second, eager pass of the same steps (not part
+    # of `value`); the GPU is parked while the host queues each step, so the events bracket back-to-back executions
+    note(f"timed region done: {elapsed / args.steps * 1e3:.4f} ms/step; per-call HIP-event pass")
+    task._use_graphs, task._events, task._last_call = False, {}, {}
+    for i in range(min(args.steps, 50)):
+        torch.cuda._sleep(2_000_000)
+        step(args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    task._use_graphs = graphs
     events, task._events = task._events, None
     last_calls, task._last_call = (task._last_call or {}), None
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax)
-    final_loss = float(loss_vec[0])
-    assert np.isfinite(final_loss), "training diverged"
-
-    # per-kernel average launch duration from the HIP events recorded inside the timed region
     kern_ms = {name: float(np.mean([s_.elapsed_time(e_) for s_, e_ in ev])) for name, ev in events.items()}
-    if rank != 0:
-        return
+
     dom = max(kern_ms, key=kern_ms.get)
     # The dominant call once more, 40 launches back to back inside ONE event pair (the GPU parked while they are queued):
     # an event pair around a single launch also times the bracket itself (~3 us here), which is why the per-call averages
     # above sit that much over rocprofv3's kernel durations; this figure is the one `roofline` uses.
     dom_b2b_ms = None
-    if dom in last_calls and dom != "cvf_ef_backward":      # (the backward call advances the optimiser's step counter)
+    if dom in last_calls and dom != "cvf_ef_backward" and world == 1:   # (before anything frees the buffers these launches point into)      # (the backward call advances the optimiser's step counter)
         fn_, args_ = last_calls[dom]
         reps_ = 40
         torch.cuda.synchronize()
@@ -215,25 +272,59 @@ def main():
         torch.cuda.synchronize()
         dom_b2b_ms = e0.elapsed_time(e1) / reps_
 
+
+    extras = {}
+    if not args.no_extras:
+        # ---- secondary: the config-4 job (1 M frames in all) at other global batches, and the weak-scaling line
+        combos = [("strong", g) for g in (20_000, 160_000, 800_000)] + [("weak", 20_000 * world)]
+        rows = {}
+        for kind, G in combos:
+            if kind == "strong":
+                fr = args.frames_total // world
+            else:
+                fr = 100_000
+            b = G // world
+            if b < 64 or b > fr or G % world:
+                continue
+            if kind == scaling and b == B and fr == frames_rank:
+                rows[f"{kind}:{G}"] = dict(global_batch=G, batch_per_gpu=b, frames_per_gpu=fr, ms_per_step=elapsed / args.steps * 1e3,
+                                           value=world * B * args.steps / elapsed)
+                continue
+            note(f"scaling table: {kind} global batch {G} ({b} per GPU, {fr} resident per GPU)")
+            restart()
+            if fr > X.shape[0]:
+                X, Wt = device_frames(fr, ref, 0.3, SEED + 1 + rank, dev)
+            k_steps = max(10, min(args.steps, int(4e6 // G)))
+            el, _, _ = run_steps(task, X[:fr], Wt[:fr], b, k_steps, 5, f"{kind}{G}", world, dev, max_batches=4)
+            rows[f"{kind}:{G}"] = dict(global_batch=G, batch_per_gpu=b, frames_per_gpu=fr, steps=k_steps, ms_per_step=el / k_steps * 1e3,
+                                       value=G * k_steps / el)
+            task._graphs.clear()
+            task._ws.clear()
+        extras["scaling_table"] = dict(
+            note=("same model and step; 'strong:G' = BASELINE config 4 (frames_total frames split over the ranks, G frames per step "
+                  "of the whole job, fixed as N grows); 'weak:G' = 20 000 frames per GPU per step.  value = frames/s of the whole job."),
+            frames_total=args.frames_total, rows=rows)
+
+    if rank != 0:
+        return
+    prof = PROFILE_TAG
+
     def pmc_traffic(call):
         """HBM bytes per launch of the kernel behind a C-ABI call, from the committed rocprofv3 PMC passes."""
-        kernel = {"cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
-                  "cvf_ef_fwd_metric_stats": "ef_fwd_metric_kernel", "cvf_ef_align_fwd_metric_stats": "ef_fwd_metric_kernel",
-                  "cvf_align_feature_fwd": "k1_align_quad_kernel", "cvf_align_feature_fwd@1M": "k1_stream_kernel"}.get(call)
-        path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if kernel is None or not os.path.exists(path) or B != 20000 or args.workload != "c3":
+        kernel = KERNEL_OF_CALL.get(call)
+        path = os.path.join(ROOT, "profiles", f"{prof}_pmc_traffic.json")
+        if kernel is None or not os.path.exists(path) or B != 20000 or world != 1:
             return None
         with open(path) as fh:
             c = json.load(fh)["kernels"].get(kernel)
         return None if c is None else (2.0 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024.0
 
-    if dom in ("cvf_ef_backward", "cvf_ef_mlp_fwd", "cvf_ef_fwd_metric_stats", "cvf_ef_align_fwd_metric_stats"):
-        flop = {"cvf_ef_backward": FLOP_BWD, "cvf_ef_mlp_fwd": FLOP_FWD, "cvf_ef_fwd_metric_stats": FLOP_FWD + FLOP_METRIC,
-                "cvf_ef_align_fwd_metric_stats": FLOP_FWD + FLOP_METRIC + FLOP_K1}[dom] * B
+    if dom in FLOP_OF_CALL:
+        flop = FLOP_OF_CALL[dom] * B
         dom_ms = dom_b2b_ms if dom_b2b_ms is not None else kern_ms[dom]
         ach = flop / (dom_ms * 1e-3) / 1e12
         roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS,
-                    traffic=pmc_traffic(dom), avg_launch_us=dom_ms * 1e3,
+                    traffic=pmc_traffic(dom), avg_launch_us=dom_ms * 1e3, flop_per_frame=FLOP_OF_CALL[dom], frames_per_launch=B,
                     timing=("40 back-to-back launches in one HIP-event pair" if dom_b2b_ms is not None else
                             "HIP-event pair per launch (includes the bracket)"),
                     note="fp32 work (VALU chains + f32-input MFMA weight gradients); peak = fp32 vector = fp32 MFMA rate")
@@ -241,36 +332,6 @@ def main():
         ach = K1_BYTES * B / (kern_ms[dom] * 1e-3) / 1e9
         roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                     traffic=pmc_traffic(dom), avg_launch_us=kern_ms[dom] * 1e3)
-    # The align+feature kernel alone.  Inside the step it is part of the fused launch (and at 20 000 frames any
-    # stand-alone launch is latency-bound), so its HBM roofline is taken where BASELINE.json's north star puts it: one
-    # launch over a 1 M-frame dipeptide trajectory resident in HBM (the shard repeated), HIP events per launch.
-    from colvarsfinder import _hip
-    lib, P = _hip.lib(), _hip.ptr
-
-    def time_k1(xs, n, with_aux, reps):
-        T_ = _hip.ntiles(n)
-        f_tmp = torch.empty(T_ * 66 * 64, device=dev)
-        a_tmp = torch.empty(T_ * 18 * 64, device=dev) if with_aux else None
-        evs = []
-        for _ in range(reps):
-            torch.cuda._sleep(200_000)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _hip.check(lib.cvf_align_feature_fwd(task._pp, P(xs), n, P(f_tmp), None, P(a_tmp), None, _hip.stream()), "k1")
-            e1.record()
-            evs.append((e0, e1))
-        torch.cuda.synchronize()
-        return float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs[5:]]))
-
-    k1_step = kern_ms["cvf_align_feature_fwd"] if "cvf_align_feature_fwd" in kern_ms else time_k1(X[:B].contiguous(), B, True, 30)
-    N1M = 1_000_000
-    x1m = X.repeat((N1M + X.shape[0] - 1) // X.shape[0], 1, 1)[:N1M].contiguous()
-    k1 = time_k1(x1m, N1M, True, 25)
-    k1_feat_only = time_k1(x1m, N1M, False, 25)
-    del x1m
-    k1_note = ("one launch over 1 000 000 frames (22 atoms) resident in HBM, features + the rotation/centroid/K^-1 rows of "
-               "generator mode (72 B/frame that the 532 B/frame count leaves out); features_only = the same without those rows")
-    k1_gbs = K1_BYTES * N1M / (k1 * 1e-3) / 1e9
     out = {
         "metric": "MD frames/sec through EigenFunctionTask train step",
         "value": world * B * args.steps / elapsed,
@@ -280,39 +341,94 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE config 3: alanine-dipeptide-shaped EigenFunctionTask, generator mode, k=3, "
-                               "22 atoms, align+position features d_r=66, nets [66,20,20,20,1], diag_coeff, Adam",
-                   "frames_per_gpu": args.frames, "batch_per_gpu": B, "global_batch": world * B,
+        "config": {"workload": workload, "frames_per_gpu": frames_rank, "batch_per_gpu": B, "global_batch": world * B,
                    "parallelism": f"dp{world} (frames sharded; all-reduce of batch sums + flat gradient)"},
         "roofline": roof,
-        "roofline_align_feature": {"kernel": "cvf_align_feature_fwd", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("cvf_align_feature_fwd@1M"),
-                                   "avg_launch_us": k1 * 1e3,
-                                   "bytes_per_frame": K1_BYTES, "frames_per_launch": N1M, "note": k1_note,
-                                   "features_only": {"avg_launch_us": k1_feat_only * 1e3,
-                                                     "achieved": K1_BYTES * N1M / (k1_feat_only * 1e-3) / 1e9,
-                                                     "frac": K1_BYTES * N1M / (k1_feat_only * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                                   "copy_ceiling_note": "a plain 16-byte copy kernel (tools/stream_probe.hip, 3 GB) moves 5.5 TB/s "
-                                                        "read+write on this GPU: 1:1 read/write traffic cannot exceed ~69 % of 8 TB/s",
-                                   "at_step_batch": {"frames_per_launch": B, "avg_launch_us": k1_step * 1e3,
-                                                     "achieved": K1_BYTES * B / (k1_step * 1e-3) / 1e9,
-                                                     "traffic": pmc_traffic("cvf_align_feature_fwd")}},
         "kernel_avg_us": {n: v * 1e3 for n, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
         "kernel_timing": ("HIP events around each C-ABI call over a second, eager pass of the same steps (the timed region "
-                          "replays one hipGraph per step)") if graphs else "HIP events around each C-ABI call in the timed region",
+                          "replays one hipGraph per step)") if graphs else "HIP events around each C-ABI call (eager pass)",
         "hip_graph": bool(graphs),
-        "pipelined_alignment": bool(pipeline),
-        "traffic_note": ("roofline.traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from profiles/r1_pmc_traffic.json "
+        "traffic_note": (f"roofline.traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from profiles/{prof}_pmc_traffic.json "
                          "(separate rocprofv3 --pmc passes of this command; gfx950 FETCH_SIZE halving corrected)"),
         "final_loss": final_loss,
     }
+    out.update(extras)
+    if world == 1 and not args.no_extras:
+        del X, Wt
+        task._graphs.clear(); task._ws.clear()
+        torch.cuda.empty_cache()
+        note("align+feature kernel alone, out of cache")
+        out["roofline_align_feature"] = align_feature_roofline(task, ref, dev, pmc_traffic)
     if world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(x, w, ref, a, sd0, B, args.cpu_seconds)
+        note("CPU baseline")
+        xb, wb = device_frames(B, ref, 0.3, SEED + 1, dev)
+        out["cpu_baseline"] = cpu_baseline(xb.cpu().numpy(), wb.cpu().numpy().astype(np.float64), ref, a, sd0, B, args.cpu_seconds)
     print(json.dumps(out))
+
+
+def align_feature_roofline(task, ref, dev, pmc_traffic):
+    """The align+feature kernel K1 alone, where BASELINE.json's north star puts its HBM roofline.  Inside the 20 000-frame step
+    it is part of the fused launch (and any stand-alone launch of that size is latency-bound), so it is timed at shard size,
+    OUT OF CACHE: (i) the dipeptide shape over 4 M frames (1.06 GB in, 1.06 GB out - four times the 256 MB Infinity Cache; the
+    1 M-frame launch of round 1 is kept beside it); (ii) BASELINE config 5's shape, 5000 atoms x 100 k frames (6 GB in), which is
+    the configuration BASELINE.json names 'HBM-bound align+feature path'.  HIP events per launch, on the launch stream."""
+    from colvarsfinder import _hip, pp
+    lib, P = _hip.lib(), _hip.ptr
+
+    def time_k1(desc, xs, n, d_r, with_aux, reps, scratch=None):
+        T_ = _hip.ntiles(n)
+        f_tmp = torch.empty(T_ * d_r * 64, device=dev)
+        a_tmp = torch.empty(T_ * 18 * 64, device=dev) if with_aux else None
+        evs = []
+        for _ in range(reps):
+            torch.cuda._sleep(200_000)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _hip.check(lib.cvf_align_feature_fwd(desc, P(xs), n, P(f_tmp), None, P(a_tmp), P(scratch), _hip.stream()), "k1")
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        return float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs[3:]]))
+
+    res = {}
+    for label, n in (("dipeptide_4M", 4_000_000), ("dipeptide_1M", 1_000_000)):
+        xs, _ = device_frames(n, ref, 0.3, SEED + 77, dev)
+        t_all = time_k1(task._pp, xs, n, 66, True, 15)
+        t_feat = time_k1(task._pp, xs, n, 66, False, 15)
+        del xs
+        res[label] = dict(frames_per_launch=n, bytes_per_frame=K1_BYTES, footprint_MB=(264 + 264) * n / 1e6,
+                          features_only=dict(avg_launch_us=t_feat * 1e3, achieved=K1_BYTES * n / (t_feat * 1e-3) / 1e9,
+                                             frac=K1_BYTES * n / (t_feat * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                          generator_outputs=dict(avg_launch_us=t_all * 1e3, achieved=K1_BYTES * n / (t_all * 1e-3) / 1e9,
+                                                 frac=K1_BYTES * n / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 note="+ rotation/centroid/K^-1 rows (72 B/frame the 532 B/frame count leaves out)"))
+    # config-5 shape
+    n5, na5 = 100_000, C5["n_atoms"]
+    ref5 = np.random.RandomState(SEED).normal(scale=2.0, size=(na5, 3))
+    layer5 = pp.AlignFeatureLayer(na5, list(range(na5)), ref5, c5_features(na5)).to(dev)
+    d5 = layer5.pp_desc()
+    x5, _ = device_frames(n5, ref5, 0.05, SEED + 78, dev, chunk=5000)
+    bpf5 = 12 * na5 + 4 + 4 * layer5.d_r
+    t5 = time_k1(d5, x5, n5, layer5.d_r, False, 8)
+    sc5 = _hip.align_scratch(d5, n5, dev)
+    t5g = time_k1(d5, x5, n5, layer5.d_r, True, 8, scratch=sc5)
+    del x5, sc5
+    res["config5_100k"] = dict(frames_per_launch=n5, n_atoms=na5, d_r=layer5.d_r, bytes_per_frame=bpf5, footprint_MB=bpf5 * n5 / 1e6,
+                               features_only=dict(avg_launch_us=t5 * 1e3, achieved=bpf5 * n5 / (t5 * 1e-3) / 1e9,
+                                                  frac=bpf5 * n5 / (t5 * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                               generator_outputs=dict(avg_launch_us=t5g * 1e3, achieved=bpf5 * n5 / (t5g * 1e-3) / 1e9,
+                                                      frac=bpf5 * n5 / (t5g * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                      note="+ rotation/centroid rows and the slot copy the derivative kernel reads"))
+    head = res["config5_100k"]["features_only"]
+    return {"kernel": "cvf_align_feature_fwd", "bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": head["frac"], "avg_launch_us": head["avg_launch_us"], "bytes_per_frame": bpf5, "frames_per_launch": n5,
+            "traffic": pmc_traffic("cvf_align_feature_fwd@c5"),
+            "workload": "BASELINE config 5 shape (5000 atoms, d_r=384), 100 000 frames resident = 6.2 GB per launch, out of cache",
+            "cases": res}
 
 
 def main_c5(args):

@@ -82,7 +82,7 @@ def test_colvar_model_takes_cpu_tensors_like_the_notebooks(dev, tmp_path):
         got = out.detach().numpy()
         on_gpu = cv_model(x_cpu.to(dev))                 # device tensors keep working and stay on the device
         assert on_gpu.device.type == "cuda"
-        np.testing.assert_allclose(got, on_gpu.cpu().numpy(), rtol=0, atol=0)
+        np.testing.assert_allclose(got, on_gpu.detach().cpu().numpy(), rtol=0, atol=0)
         np.testing.assert_allclose(plotter.calls[-1][1], got, rtol=0, atol=0)   # the last callback saw the final model
         # float64 input (text trajectories, np.loadtxt): answered in float64
         assert cv_model(torch.tensor(traj, dtype=torch.float64)).dtype == torch.float64

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Achieved parity errors of the HIP path against every reference-generated fixture -> profiles/<tag>_parity_errors.json.
+
+north_star: "per-step loss and learned-CV outputs within 1e-5 relative" of the reference's CPU path.  The tests state
+tolerances; this script records the DISTANCES: for each fixture (the reference's own fp32 run and its fp64 run, written by
+tools/gen_golden.py) the maximum relative error of
+  * the loss and the eigenvalues of one loss_func call (known-answer fixtures),
+  * every per-step loss of a training trace (train and test rows, column 0),
+  * the learned-CV outputs on the probe frames after training (relative to the largest |CV|; eigenfunction CVs up to the
+    additive constant the loss does not determine, as in tests/test_gpu_parity.py).
+It also records the reference's own fp32-vs-fp64 distance on the same quantity, which is the noise floor a comparison with
+its fp32 run cannot go below.  Runs on the GPU box:  python tools/parity_errors.py [tag]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "colvars-finder_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+from tests import goldens  # noqa: E402
+from tests.synth import Traj  # noqa: E402
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+def rel_scale(a, b):
+    """max |a - b| / max |b| (for vectors with entries near zero)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def main():
+    tag_out = sys.argv[1] if len(sys.argv) > 1 else "r2"
+    from tests.test_gpu_parity import build_task, make_layer
+    from colvarsfinder import core, nn
+    dev = torch.device("cuda:0")
+    out = {"_what": "max relative error of the MI355X path vs the reference's own runs (fixtures of tools/gen_golden.py); "
+                    "ref_f32_vs_f64 = the same distance between the reference's fp32 and fp64 runs (its own noise floor)",
+           "_north_star_tolerance": 1e-5, "kat": {}, "ef_train": {}, "ae_train": {}}
+
+    for name in goldens.KAT_CASES:
+        row = {}
+        g32, g64 = goldens.load(name, "f32"), goldens.load(name, "f64")
+        for tag, g in (("f32", g32), ("f64", g64)):
+            task, _ = build_task(g, dev)
+            lag = int(g["lag_idx"])
+            traj, w = np.array(g["traj"]), np.array(g["w"])
+            B = traj.shape[0] - lag
+            Xl = torch.tensor(traj[lag:lag + B]) if lag else None
+            wl = torch.tensor(w[lag:lag + B]) if lag else None
+            loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj[:B]), torch.tensor(w[:B]), Xl, wl)
+            row[f"loss_vs_{tag}"] = rel(float(loss), float(g["loss"]))
+            row[f"eig_vs_{tag}"] = rel(eig.numpy(), g["eig"])
+        row["ref_f32_vs_f64_loss"] = rel(float(g32["loss"]), float(g64["loss"]))
+        row["ref_f32_vs_f64_eig"] = rel(g32["eig"], g64["eig"])
+        out["kat"][name] = row
+
+    for name in goldens.EF_TRAIN_CASES:
+        row = {}
+        g32, g64 = goldens.load(name, "f32"), goldens.load(name, "f64")
+        for tag, g in (("f32", g32), ("f64", g64)):
+            task, _ = build_task(g, dev)
+            np.random.seed(int(g["seed"]))
+            task.train()
+            tr = np.stack([e[0].numpy() for e in task.loss_list])
+            te = np.stack([e[1].numpy() for e in task.loss_list])
+            row[f"step_loss_vs_{tag}"] = max(rel(tr[..., 0], np.array(g["train_loss"])[..., 0]), rel(te[..., 0], np.array(g["test_loss"])[..., 0]))
+            cv = task.colvar_model()(torch.tensor(np.array(g["traj"])[:64], dtype=torch.float32)).detach().numpy()
+            rc = np.array(g["colvar_probe"])
+            row[f"cv_vs_{tag}"] = rel_scale(cv - cv.mean(0), rc - rc.mean(0))
+            row["steps"] = int(tr.shape[0] * tr.shape[1])
+        row["ref_f32_vs_f64_step_loss"] = rel(np.array(g32["train_loss"])[..., 0], np.array(g64["train_loss"])[..., 0])
+        a, b = np.array(g32["colvar_probe"]), np.array(g64["colvar_probe"])
+        row["ref_f32_vs_f64_cv"] = rel_scale(a - a.mean(0), b - b.mean(0))
+        out["ef_train"][name] = row
+
+    for name in goldens.AE_TRAIN_CASES:
+        row = {}
+        g32, g64 = goldens.load(name, "f32"), goldens.load(name, "f64")
+        for tag, g in (("f32", g32), ("f64", g64)):
+            e_dims, d_dims = [int(d) for d in g["e_dims"]], [int(d) for d in g["d_dims"]]
+            model = nn.AutoEncoder(e_dims, d_dims)
+            model.load_state_dict(goldens.state_dict(g, dtype=torch.float32))
+            traj = np.array(g["traj"])
+            layer = make_layer(goldens.pp_spec(g), traj.shape[1] if traj.ndim == 3 else 0, dev)
+            task = core.AutoEncoderTask(Traj(traj, np.array(g["w"]), 0.5), layer, model, "/tmp/cvf_parity", learning_rate=float(g["lr"]),
+                                        batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]), device=dev, verbose=False,
+                                        save_model_every_step=0)
+            np.random.seed(int(g["seed"]))
+            task.train()
+            tr = np.stack([e[0].numpy() for e in task.loss_list])
+            te = np.stack([e[1].numpy() for e in task.loss_list])
+            row[f"step_loss_vs_{tag}"] = max(rel(tr, g["train_loss"]), rel(te, g["test_loss"]))
+            cv = task.colvar_model()(torch.tensor(traj[:64], dtype=torch.float32)).detach().numpy()
+            row[f"cv_vs_{tag}"] = rel_scale(cv, g["colvar_probe"])
+            row["steps"] = int(tr.size)
+        row["ref_f32_vs_f64_step_loss"] = rel(g32["train_loss"], g64["train_loss"])
+        row["ref_f32_vs_f64_cv"] = rel_scale(g32["colvar_probe"], g64["colvar_probe"])
+        out["ae_train"][name] = row
+
+    def worst(key):
+        return max(r[key] for sec in ("kat", "ef_train", "ae_train") for r in out[sec].values() if key in r)
+
+    out["_summary"] = {"worst_loss_vs_f64_single_call": worst("loss_vs_f64"), "worst_step_loss_vs_f64_traces": worst("step_loss_vs_f64"),
+                       "worst_step_loss_vs_f32_traces": worst("step_loss_vs_f32"), "worst_cv_vs_f64": worst("cv_vs_f64"),
+                       "worst_cv_vs_f32": worst("cv_vs_f32"),
+                       "reference_own_f32_vs_f64_worst_step_loss": worst("ref_f32_vs_f64_step_loss"),
+                       "reference_own_f32_vs_f64_worst_cv": worst("ref_f32_vs_f64_cv")}
+    path = os.path.join(ROOT, "gpurun_out", f"{tag_out}_parity_errors.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out["_summary"]))
+
+
+if __name__ == "__main__":
+    main()
