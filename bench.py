@@ -45,9 +45,9 @@ FLOP_FWD = 2 * K_NETS * (P_W + (P_W - 66 * 20) + 66 * 20)            # forward +
 FLOP_K1 = 2 * (12 + 12) * N_ATOMS + 1500              # covariance + aligned positions per atom, 3x3 eigen-solve
 FLOP_METRIC = 2 * K_NETS * 33 * N_ATOMS          # three passes of q = J A J^T g: ~33 fused multiply-adds per atom and net
 FLOP_BWD = 2 * K_NETS * (P_W + 800 + 2 * P_W)  # tangent chain, zbar chain, outer products (h and the d chain come from the forward kernel)
-FLOP_OF_CALL = {"cvf_ef_backward": FLOP_BWD, "cvf_ef_mlp_fwd": FLOP_FWD, "cvf_ef_fwd_metric_stats": FLOP_FWD + FLOP_METRIC,
+FLOP_OF_CALL = {"cvf_ef16_front": FLOP_FWD + FLOP_METRIC + FLOP_K1, "cvf_ef16_backward": FLOP_BWD, "cvf_ef_backward": FLOP_BWD, "cvf_ef_mlp_fwd": FLOP_FWD, "cvf_ef_fwd_metric_stats": FLOP_FWD + FLOP_METRIC,
                 "cvf_ef_align_fwd_metric_stats": FLOP_FWD + FLOP_METRIC + FLOP_K1}
-KERNEL_OF_CALL = {"cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
+KERNEL_OF_CALL = {"cvf_ef16_front": "ef16_front_kernel", "cvf_ef16_backward": "ef_bwd_mfma_kernel", "cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
                   "cvf_ef_fwd_metric_stats": "ef_fwd_metric_kernel", "cvf_ef_align_fwd_metric_stats": "ef_fwd_metric_kernel",
                   "cvf_align_feature_fwd": "k1_align_quad_kernel", "cvf_align_feature_fwd@1M": "k1_stream_kernel",
                   "cvf_align_feature_fwd@c5": "k1_large_slice_kernel"}
@@ -259,7 +259,7 @@ def main():
     # an event pair around a single launch also times the bracket itself (~3 us here), which is why the per-call averages
     # above sit that much over rocprofv3's kernel durations; this figure is the one `roofline` uses.
     dom_b2b_ms = None
-    if dom in last_calls and dom != "cvf_ef_backward" and world == 1:   # (before anything frees the buffers these launches point into)      # (the backward call advances the optimiser's step counter)
+    if dom in last_calls and dom not in ("cvf_ef_backward", "cvf_ef16_backward") and world == 1:   # (before anything frees the buffers these launches point into)      # (the backward call advances the optimiser's step counter)
         fn_, args_ = last_calls[dom]
         reps_ = 40
         torch.cuda.synchronize()

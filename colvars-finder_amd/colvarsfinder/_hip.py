@@ -79,6 +79,15 @@ _SIGNATURES = {
     "cvf_ef_fwd_metric_stats": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PPDesc), C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(EFCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_ef16_supported": (C.c_int, [C.POINTER(MLPDesc), C.POINTER(PPDesc)]),
+    "cvf_ef16_scratch_doubles": (C.c_int64, [C.c_int64, C.c_int]),
+    "cvf_ef16_saved_floats": (C.c_int64, [C.POINTER(MLPDesc), C.c_int64]),
+    "cvf_ef16_front": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PPDesc), C.c_void_p, C.c_int64,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(EFCfg), C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_ef16_backward": (C.c_int, [C.POINTER(EFCfg), C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "cvf_ef_stats_scratch_doubles": (C.c_int64, [C.c_int, C.c_int]),
     "cvf_ef_stats": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

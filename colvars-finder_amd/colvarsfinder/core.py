@@ -387,7 +387,7 @@ class TrainingTask(ABC):
 class _EFWorkspace:
     """Device buffers of one batch size (all sizes follow include/cvf.h)."""
 
-    def __init__(self, B, k, d_r, n_params, lag, mlp_desc, device):
+    def __init__(self, B, k, d_r, n_params, lag, mlp_desc, device, ef16=False):
         lib = _hip.lib()
         T = _hip.ntiles(B)
         Tt = 2 * T if lag > 0 else T
@@ -401,19 +401,20 @@ class _EFWorkspace:
         self._aux = [torch.empty(T * _hip.AUX_ROWS * _hip.TILE, **f32) for _ in range(2)]
         self.y = torch.empty(Tt * k * _hip.TILE, **f32)
         if lag == 0:
-            self.g = torch.empty(T * k * d_r * _hip.TILE, **f32)
+            self.g = None if ef16 else torch.empty(T * k * d_r * _hip.TILE, **f32)   # (the 16-frame step keeps g on the chip)
             self.q = torch.empty(T * k * d_r * _hip.TILE, **f32)
             self.e = torch.empty(T * k * _hip.TILE, **f32)
         else:
             self.g = self.q = self.e = None
-        self.scratch = torch.zeros(lib.cvf_metric_stats_scratch_doubles(B, k) if lag == 0 else
+        self.scratch = torch.zeros(lib.cvf_ef16_scratch_doubles(B, k) if ef16 else
+                                   lib.cvf_metric_stats_scratch_doubles(B, k) if lag == 0 else
                                    lib.cvf_ef_stats_scratch_doubles(k, lag), **f64)
         self.stats = torch.empty(lib.cvf_ef_nstats(k, lag), **f64)
         self.loss_vec = torch.empty(3 + 2 * k, **f64)
         self.coef = torch.empty(4 * k + k * k, **f64)
         self._k1_scratch, self.k1_scratch_checked = [None, None], False   # large-molecule alignment scratch, sized on first use
         # hidden activations handed from the forward kernel to the backward kernel (0 floats: shape without hand-off)
-        n_saved = lib.cvf_ef_saved_floats(mlp_desc, Tt)
+        n_saved = lib.cvf_ef16_saved_floats(mlp_desc, Tt) if ef16 else lib.cvf_ef_saved_floats(mlp_desc, Tt)
         self.saved = torch.empty(n_saved, **f32) if n_saved > 0 else None
         self.slab_rows = lib.cvf_ef_backward_slab_rows(Tt)
         self.slab = torch.empty(self.slab_rows * n_params, **f32)
@@ -504,6 +505,7 @@ class EigenFunctionTask(TrainingTask):
         # CVF_PIPELINE=1: the next batch's alignment (independent of the parameters) runs on this stream beside the
         # current step's backward kernel.  Off by default: at 20 000 frames per step it measured 133 us/step against
         # 126 serial - the two-branch graph costs more at the fork/join than the 14 us kernel it hides.
+        self._ef16 = None
         self._fused_fm = self._fused_k1 = self._fused_tr = None   # decided on first use: cvf_ef_[align_]fwd_metric_supported(nets, layer)
         self._side = torch.cuda.Stream(device=self.device)
         self._pipeline = os.environ.get("CVF_PIPELINE", "0") == "1"
@@ -528,8 +530,16 @@ class EigenFunctionTask(TrainingTask):
     def _workspace(self, B):
         ws = self._ws.get(B)
         if ws is None:
-            ws = self._ws[B] = _EFWorkspace(B, self.k, self._pp.d_r, self._flat.n, self.lag_idx, self._flat.desc, self.device)
+            ws = self._ws[B] = _EFWorkspace(B, self.k, self._pp.d_r, self._flat.n, self.lag_idx, self._flat.desc, self.device,
+                                            ef16=self._use_ef16())
         return ws
+
+    def _use_ef16(self):
+        """Generator mode on the fast layout: the 16-frames-per-wave step (csrc/ef16.hip), decided once."""
+        if self._ef16 is None:
+            self._ef16 = (self.lag_idx == 0 and not self._pipeline and
+                          bool(_hip.lib().cvf_ef16_supported(self._flat.desc, self._pp)))
+        return self._ef16
 
     def _align(self, ws, slot, X, X_lag):
         """K1 of one batch (and of its lagged partner) into feature buffer ``slot``."""
@@ -551,6 +561,18 @@ class EigenFunctionTask(TrainingTask):
         ws.slot = slot
         fl, k, d_r = self._flat, self.k, self._pp.d_r
         lag = self.lag_idx
+        single = not _dist.collectives()   # no cross-rank reduction: the loss tail runs inside the stats launch
+        lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
+        if self._use_ef16() and not aligned:
+            # coordinates -> features, y, hidden activations, q = J A J^T g, E and the batch sums in one launch, 16 frames per
+            # wave (+ the short launch that adds the units' rows and evaluates the loss tail)
+            self._call("cvf_ef16_front", lib.cvf_ef16_front, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), self._pp, P(X), B,
+                       P(self._diag_coeff), P(ws.y), P(ws.saved), P(ws.q), P(ws.e), self._cfg, P(w), P(ws.scratch), P(ws.stats),
+                       lv, cf, s)
+            if not single:
+                _dist.allreduce_sum_(ws.stats)                                           # collective #1
+                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_vec), P(ws.coef), s)
+            return ws
         if not ws.k1_scratch_checked:
             ws._k1_scratch = [_hip.align_scratch(self._pp, B, self.device) for _ in range(2)]
             ws.k1_scratch_checked = True
@@ -564,8 +586,6 @@ class EigenFunctionTask(TrainingTask):
         with_tr = self._fused_tr and not aligned
         if not aligned and not with_k1 and not with_tr:
             self._align(ws, slot, X, X_lag)
-        single = not _dist.collectives()   # no cross-rank reduction: the loss tail runs inside the stats launch
-        lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
         if self._fused_fm:   # [alignment,] nets forward, q = J A J^T g, E and the batch sums in one launch: g never leaves the chip
             name, fn = (("cvf_ef_align_fwd_metric_stats", lib.cvf_ef_align_fwd_metric_stats) if with_k1 else
                         ("cvf_ef_fwd_metric_stats", lib.cvf_ef_fwd_metric_stats))
@@ -604,9 +624,14 @@ class EigenFunctionTask(TrainingTask):
         (the kernel advances the device step counter).  ``fuse_adam``: single-process training - the kernel
         that sums the per-block partial gradients applies the Adam update in the same launch."""
         lib, fl, P = _hip.lib(), self._flat, _hip.ptr
-        self._call("cvf_ef_backward", lib.cvf_ef_backward, self._cfg, fl.desc, P(fl.theta), P(fl.packed), ws.B, P(w), P(w_lag),
-                   P(ws.feat), P(ws.y), P(ws.q) if self.lag_idx == 0 else None, P(ws.coef), P(ws.slab),
-                   P(self.optimizer.step_count) if advance else None, P(ws.saved), _hip.stream())
+        if self._use_ef16():
+            self._call("cvf_ef16_backward", lib.cvf_ef16_backward, self._cfg, fl.desc, P(fl.theta), P(fl.packed), ws.B, P(w),
+                       P(ws.feat), P(ws.y), P(ws.q), P(ws.coef), P(ws.slab),
+                       P(self.optimizer.step_count) if advance else None, P(ws.saved), _hip.stream())
+        else:
+            self._call("cvf_ef_backward", lib.cvf_ef_backward, self._cfg, fl.desc, P(fl.theta), P(fl.packed), ws.B, P(w), P(w_lag),
+                       P(ws.feat), P(ws.y), P(ws.q) if self.lag_idx == 0 else None, P(ws.coef), P(ws.slab),
+                       P(self.optimizer.step_count) if advance else None, P(ws.saved), _hip.stream())
         adam = self.optimizer.fused_args() if fuse_adam else None
         self._call("cvf_slab_reduce", lib.cvf_slab_reduce, P(ws.slab), ws.slab_rows, fl.n, P(fl.grad), adam, _hip.stream())
         if not fuse_adam:

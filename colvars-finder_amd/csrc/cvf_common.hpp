@@ -81,11 +81,14 @@ __device__ __forceinline__ float cvf_tanh(float x) {
 // Developer aid: the tools/*.hip probes compile a kernel file with -DCVF_STAMPS to read s_memtime at phase
 // boundaries of one wave per block; in the shipped library the macro is empty.
 #ifdef CVF_STAMPS
+#ifndef CVF_STAMP_WPB
+#define CVF_STAMP_WPB 2   // waves per block that get a stamp row of their own
+#endif
 static __device__ unsigned long long g_stamps[64 * 4096];
 #define CVF_STAMP(i)                                                                              \
   do {                                                                                            \
-    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 4096)                          \
-      g_stamps[(blockIdx.x * 2 + (threadIdx.x >> 6)) % 4096 * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 4096 && (threadIdx.x >> 6) < CVF_STAMP_WPB)   \
+      g_stamps[(blockIdx.x * CVF_STAMP_WPB + (threadIdx.x >> 6)) % 4096 * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define CVF_STAMP(i) do {} while (0)

@@ -109,7 +109,7 @@ __device__ __forceinline__ void load_hfrag(HFrag<H>& f, const float* __restrict_
 #pragma unroll
   for (int s = 0; s < Hid<H>::NG; ++s)
 #pragma unroll
-    for (int rt = 0; rt < Hid<H>::RT; ++rt) f.a[s][rt] = pk[(s * Hid<H>::RT + rt) * 64 + lane];
+    for (int rt = 0; rt < Hid<H>::RT; ++rt) f.a[s][rt] = pk[(unsigned)((s * Hid<H>::RT + rt) * 64) + (unsigned)lane];   // (unsigned: uniform base + 32-bit lane offset)
 }
 // Y += op(W) X with the fragments already in registers
 template <int H, int FT>
@@ -299,6 +299,43 @@ __device__ __forceinline__ float sum_over_q(float v) {
   v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
   return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Rows of 64 floats (weight fragments, hand-off vectors) addressed as  uniform base + uniform row offset + lane:  a buffer
+// resource in four SGPRs, the lane's byte offset in ONE VGPR, the row offset in an SGPR / the instruction's immediate
+// (buffer_load_dword v, v_lane4, s[rsrc], s_off offen).  With plain pointer arithmetic the compiler folds the lane into
+// the base first and then keeps one 64-bit VGPR address per row alive (36 registers for the first layer's fragments of
+// one net, spilled when they are needed twice).  Reads past `n_floats` return 0 - which also masks a vector's padding.
+// ------------------------------------------------------------------------------------------------------------------
+struct URows {
+  __amdgpu_buffer_rsrc_t r;
+  int lane4;
+  __device__ __forceinline__ float ld(int float_off) const {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane4, float_off * 4, 0));
+  }
+  __device__ __forceinline__ void st(int float_off, float v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, lane4, float_off * 4, 0);
+  }
+};
+__device__ __forceinline__ URows urows(const void* base, int n_floats, int lane) {
+  return URows{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n_floats * 4, 0x00020000), lane * 4};
+}
+template <int H>
+__device__ __forceinline__ void load_hfrag_u(HFrag<H>& f, const URows& u, int off) {
+#pragma unroll
+  for (int s = 0; s < Hid<H>::NG; ++s)
+#pragma unroll
+    for (int rt = 0; rt < Hid<H>::RT; ++rt) f.a[s][rt] = u.ld(off + (s * Hid<H>::RT + rt) * 64);
+}
+// per-lane copy of a length-H vector in hidden order (c[rt][r] = v[4 (4 rt + r) + q], 0 past H): `u` = urows(v, H, q),
+// i.e. the lane offset is q and the feature's group a constant of the instruction
+template <int H>
+__device__ __forceinline__ void load_hid_const_u(const URows& u, float (&c)[Hid<H>::RT][4]) {
+#pragma unroll
+  for (int rt = 0; rt < Hid<H>::RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[rt][r] = u.ld(4 * (4 * rt + r));
 }
 
 // One 16x16 tile of a weight gradient over the block's 64 frames:  A (rows 16*rt..) x B (rows 16*ct..),

@@ -802,8 +802,11 @@ struct EfBwdArgs {
 // 4*col + w*FT .. + FT-1 (FT = 4/WPB) for the register-resident chains, and every WPB-th 16x16 tile of
 // each weight-gradient product.  Splitting the tile over waves shortens each wave's dependent chain and
 // puts two waves on every SIMD, which is what hides the LDS / L2 latencies at small batch sizes.
-template <int H, int NH, int WPB, bool SAVED>
-__global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp_desc mlp,
+// WPB = 4 (cvf_ef16_backward): wave w owns the 16 CONSECUTIVE frames 16 w .. 16 w + 15 of the tile - the unit whose activations
+// the 16-frames-per-wave front kernel (ef16.hip) left behind (SAVED = 2: its hand-off layout) - a quarter of the dependent
+// chain per wave, four blocks of four waves per CU.
+template <int H, int NH, int WPB, int SAVED>
+__global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp_desc mlp,
                                                                const float* __restrict__ theta,
                                                                const float* __restrict__ packed,
                                                                const float* __restrict__ w, const float* __restrict__ w_lag,
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
   float* SB2 = SB1 + (H + 1) * kPitch;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, q = lane >> 4, row16 = col, r0 = 4 * q;
-  const int ft0 = wave * FT, fo = 4 * col + ft0;
+  const int ft0 = wave * FT, fo = WPB == 4 ? 16 * wave + col : 4 * col + ft0;   // first frame (of the tile) this lane owns
   const int net = blockIdx.y;
   const int k = args.k;
   const int D = mlp.dims[0];
@@ -925,10 +928,21 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
       // the forward kernel left h_1..h_NH for this (tile, net): 15 coalesced 8-byte loads instead of recomputing the
       // forward chain (68 + 40 matrix instructions behind just-in-time weight loads).  (Handing over the d chain too
       // was measured: 10 MB more traffic each way and no change in this kernel's time.)
-      static_assert(!SAVED || FT == 2, "the saved layout pairs the frame groups of a two-wave block");
+      static_assert(SAVED != 1 || FT == 2, "the saved layout pairs the frame groups of a two-wave block");
+      static_assert(SAVED != 2 || FT == 1, "the 16-frame hand-off belongs to the four-wave block");
       const float* sv = saved + (tile * k + net) * (int64_t)(NH * saved_per_vec<H>());
+      if constexpr (SAVED == 2) {   // [vector][group g][unit = wave][lane]: one coalesced 256-byte row per (vector, g)
 #pragma unroll
-      for (int l = 0; l < NH; ++l) load_vec<H>(sv + l * saved_per_vec<H>(), h[l], wave, lane);
+        for (int l = 0; l < NH; ++l) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) h[l].v[rt][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int g = 0; g < Hid<H>::NG; ++g) h[l].v[g >> 2][0][g & 3] = sv[((l * Hid<H>::NG + g) * 4 + wave) * 64 + lane];
+        }
+      } else if constexpr (SAVED == 1) {
+#pragma unroll
+        for (int l = 0; l < NH; ++l) load_vec<H>(sv + l * saved_per_vec<H>(), h[l], wave, lane);
+      }
     } else {
       chain_forward<H, NH, FT, true>(mlp, theta, pk, L, net, f_tile + fo, lane, h);
     }
@@ -937,7 +951,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
       // SAVED: the hidden layers' fragments (W^T for the d chain, W for the tangent chain) are requested here, ahead of
       // the first-layer product, instead of just in time at each layer (registers are free without the recompute)
       HFrag<H> tfr[NH > 1 ? NH - 1 : 1], ffr[NH > 1 ? NH - 1 : 1];
-      if (SAVED) {
+      if (SAVED == 1) {
 #pragma unroll
         for (int l = 1; l < NH; ++l) {
           load_hfrag<H>(tfr[l - 1], pk + L.th(l), lane);
@@ -947,7 +961,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
       // the tangent chain's first operands (weights, q rows) are requested before the d chain runs: one memory round trip
       // of this wave's dependent chain overlaps that chain's matrix instructions (18.3 k -> 17.0 k cycles for this phase)
       L0Chunk<H, FT, 3> tc0;
-      if (SAVED) load_l0chunk<H, FT, 3>(tc0, pk + L.f0(), D, (D + 3) >> 2, q_tile + fo, 0, lane);
+      if (SAVED == 1) load_l0chunk<H, FT, 3>(tc0, pk + L.f0(), D, (D + 3) >> 2, q_tile + fo, 0, lane);
       {
         Vec<H, FT> d;
 #pragma unroll
@@ -962,7 +976,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
 #pragma unroll
         for (int l = NH - 1; l >= 1; --l) {
           init_bias<H, FT>(e[l - 1], nullptr, q);
-          if (SAVED) hidden_mul<H, FT>(e[l - 1], tfr[l - 1], d);
+          if (SAVED == 1) hidden_mul<H, FT>(e[l - 1], tfr[l - 1], d);
           else hidden_apply<H, FT>(e[l - 1], pk + L.th(l), d, lane);
           tangent_of<H, FT>(d, h[l - 1], e[l - 1]);   // d_{l-1} = (1 - h^2) .* e_{l-1}
         }
@@ -970,7 +984,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
       init_bias<H, FT>(t[0], nullptr, q);
       // (batches of 4 / 6 / 9 k-steps: 20.1 / 20.6 / 22.0 k cycles for this phase against 18.3 k - spills; requesting the
       //  first layer's first column tile of B operands at the end of the layer-1 step: 73.7 k vs 69.0 k cycles in all - spills)
-      if (SAVED) layer0_apply_from<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane, tc0);
+      if (SAVED == 1) layer0_apply_from<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane, tc0);
       else layer0_apply<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -983,7 +997,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
         Vec<H, FT> td;
         tangent_of<H, FT>(td, h[l - 1], t[l - 1]);
         init_bias<H, FT>(t[l], nullptr, q);
-        if (SAVED) hidden_mul<H, FT>(t[l], ffr[l - 1], td);
+        if (SAVED == 1) hidden_mul<H, FT>(t[l], ffr[l - 1], td);
         else hidden_apply<H, FT>(t[l], pk + L.fh(l), td, lane);
       }
     }
@@ -1077,7 +1091,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
         // A wave owns whole column tiles (both row tiles reuse the B registers); an odd last column tile is split by
         // row tile.  (Fetching the next column tile during the current one's MFMAs was tried: the 32 extra live
         // registers spill elsewhere in the kernel and cost more than the overlap gains.)
-        static_assert(WPB == 2, "the column-tile schedule below is written for two waves per block");
+        static_assert(WPB == 2 || WPB == 4, "the column-tile schedules below are written for two or four waves per block");
         // column tile `ct` for the row tiles rt0, rt0 + rstep, ...: first the [f ; 1] half of the contraction for
         // all of them, then the q half - sixteen B registers live at a time
         auto outer0 = [&](int ct, int rt0, int rstep) {
@@ -1089,7 +1103,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
           // the q half's operands are requested together with the feature half's (SAVED: the registers the forward
           // recompute used to hold are free): one memory round trip per column tile instead of two
           float4 bq[4];
-          if (SAVED && tangent) {
+          if (SAVED == 1 && tangent) {
             const float4* qb = reinterpret_cast<const float4*>(q_tile + (int64_t)ic * CVF_TILE + 4 * q);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bq[j] = qb[4 * j];
@@ -1118,7 +1132,7 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
             }
           }
           if (tangent) {
-            if (!SAVED) {
+            if (SAVED != 1) {
               const float4* qb = reinterpret_cast<const float4*>(q_tile + (int64_t)ic * CVF_TILE + 4 * q);
 #pragma unroll
               for (int j = 0; j < 4; ++j) bq[j] = qb[4 * j];
@@ -1145,9 +1159,13 @@ __global__ __launch_bounds__(64 * WPB, WPB) void ef_bwd_mfma_kernel(EfBwdArgs ar
           for (int rt = 0; rt < RTO; ++rt)
             if (rt >= rt0 && (rt - rt0) % rstep == 0) add_tile(0, H, D, rt, ct, acc[rt]);
         };
-        const int nfull = CT1 & ~1;
-        for (int ct = wave; ct < nfull; ct += WPB) outer0(ct, 0, 1);
-        if (CT1 & 1) outer0(CT1 - 1, wave, WPB);
+        if constexpr (WPB == 2) {
+          const int nfull = CT1 & ~1;
+          for (int ct = wave; ct < nfull; ct += WPB) outer0(ct, 0, 1);
+          if (CT1 & 1) outer0(CT1 - 1, wave, WPB);
+        } else {   // four waves: the (column tile, row tile) pairs dealt round-robin
+          for (int pr = wave; pr < RTO * CT1; pr += WPB) outer0(pr / RTO, pr % RTO, RTO);
+        }
         __syncthreads();
       }
     }
@@ -1448,10 +1466,10 @@ extern "C" int cvf_ef_align_fwd_metric_stats(const cvf_mlp_desc* mlp, const floa
 
 extern "C" int64_t cvf_ef_backward_slab_rows(int64_t n_tiles) { return bwd_grid(n_tiles); }
 
-extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
-                               int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
-                               const float* y_tiled, const float* q_tiled, const double* coef, float* slab,
-                               int32_t* step_count, const float* saved, void* stream) {
+static int ef_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
+                            int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
+                            const float* y_tiled, const float* q_tiled, const double* coef, float* slab,
+                            int32_t* step_count, const float* saved, void* stream) {
   CVF_REQUIRE(cfg && mlp && theta && packed && w && feat_tiled && y_tiled && coef && slab && B > 0,
               "cvf_ef_backward: bad argument");
   CVF_REQUIRE(cfg->lag_idx > 0 || q_tiled, "cvf_ef_backward: generator mode needs q");
@@ -1481,14 +1499,22 @@ extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, c
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
     if (saved != nullptr)
-      hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2, true>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta,
+      hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2, 1>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta,
                          packed, w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved);
     else
-      hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2, false>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta,
+      hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2, 0>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta,
                          packed, w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved);
   });
   CVF_REQUIRE(launched, "cvf_ef_backward: no kernel instance for hidden width %d x %d layers", H, NH);
   return cvf_check_launch("ef_bwd_mfma_kernel");
+}
+
+extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
+                               int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
+                               const float* y_tiled, const float* q_tiled, const double* coef, float* slab,
+                               int32_t* step_count, const float* saved, void* stream) {
+  return ef_backward_impl(cfg, mlp, theta, packed, B, w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved,
+                          stream);
 }
 
 int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,

@@ -201,6 +201,26 @@ int cvf_ef_align_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, c
                                   const float* w, double* scratch, double* stats, double* loss_vec, double* coef,
                                   void* stream);
 
+/* --- The generator-mode step with SIXTEEN frames per wave (csrc/ef16.hip), for the shapes of cvf_ef16_supported(): pure position
+ * features on a contiguous align set, d_r <= 72 (the dipeptide-sized configurations 3 and 4).  Same mathematics and the same
+ * outputs as cvf_ef_align_fwd_metric_stats + cvf_ef_backward; what differs is the decomposition: a wave owns 16 frames (the
+ * matrix instruction's N), so the launch has four times the waves of a quarter of the dependent chain each, 3-5 waves per SIMD.
+ *  cvf_ef16_front   : x [B][n_coord] -> feat_tiled [T][d_r][64], y_tiled [T][k][64], saved (cvf_ef16_saved_floats(); opaque
+ *                     hand-off of the hidden activations), q_tiled [T][k][d_r][64], e_tiled [T][k][64], stats (+ loss_vec, coef
+ *                     when non-NULL: cvf_ef_loss in the same call).  Replaces pp_layer(X), model(...), the k autograd.grad calls
+ *                     and the batch sums of core.py:403-452.  scratch: cvf_ef16_scratch_doubles(B, k) doubles.
+ *  cvf_ef16_backward: flat parameter gradient as slab rows, as cvf_ef_backward (core.py:517); follow with cvf_slab_reduce. */
+int cvf_ef16_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp);
+int64_t cvf_ef16_scratch_doubles(int64_t B, int k);
+int64_t cvf_ef16_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles);
+int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled, const cvf_pp_desc* pp,
+                   const float* x, int64_t B, const float* a, float* y_tiled, float* saved, float* q_tiled, float* e_tiled,
+                   const cvf_ef_cfg* cfg, const float* w, double* scratch, double* stats, double* loss_vec, double* coef,
+                   void* stream);
+int cvf_ef16_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed, int64_t B,
+                      const float* w, const float* feat_tiled, const float* y_tiled, const float* q_tiled, const double* coef,
+                      float* slab, int32_t* step_count, const float* saved, void* stream);
+
 /* --- K5: batch statistics (core.py:406-416,426,428,446-452), fp64, fixed-order two
  * stage reduction.  w [B]; y_tiled [T][k][64]; generator: e_tiled [T][k][64];
  * transfer: y_lag_tiled, w_lag.  scratch: cvf_ef_stats_scratch_doubles() doubles. */

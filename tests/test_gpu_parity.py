@@ -506,19 +506,25 @@ def test_fused_metric_stats_equals_two_launch_path(dev, n_atoms, n_pos, B, k):
     for _ in range(3):
         task.loss_func(X, wt, None, None)
         assert torch.equal(ws.stats, fused[0]) and torch.equal(ws.loss_vec, fused[1])
-    # the separate launches (nets forward, derivative kernel, two-stage sums) on the same features
+    # the separate launches (alignment, nets forward, derivative kernel, two-stage sums) from the same coordinates: the task's
+    # own step is one fused launch (16 frames per wave where cvf_ef16_supported(), else the 64-frame fused kernels) that
+    # keeps g on the chip, so these buffers are the test's own
     lib, P = _hip.lib(), _hip.ptr
     Xd, wd = X.to(dev).float().contiguous(), wt.to(dev).float().contiguous()
     fl = task._flat
-    y2 = torch.empty_like(ws.y)
-    _hip.check(lib.cvf_ef_mlp_fwd(fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), ws.Tt, P(y2), P(ws.g), None, _hip.stream()),
+    feat2, aux2 = torch.empty_like(ws.feat), torch.empty(ws.T * _hip.AUX_ROWS * _hip.TILE, device=dev)
+    _hip.check(lib.cvf_align_feature_fwd(task._pp, P(Xd), B, P(feat2), None, P(aux2), None, _hip.stream()), "cvf_align_feature_fwd")
+    # (columns past the batch in the last tile are padding: replicas of the last frame in both paths)
+    np.testing.assert_allclose(ws.feat.cpu().numpy(), feat2.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(feat2.abs().max()))
+    y2, g2 = torch.empty_like(ws.y), torch.empty(ws.T * k * layer.d_r * _hip.TILE, device=dev)
+    _hip.check(lib.cvf_ef_mlp_fwd(fl.desc, P(fl.theta), P(fl.packed), P(feat2), ws.Tt, P(y2), P(g2), None, _hip.stream()),
                "cvf_ef_mlp_fwd")
     torch.cuda.synchronize()
-    np.testing.assert_allclose(y2.cpu().numpy(), ws.y.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(y2.cpu().numpy(), ws.y.cpu().numpy(), rtol=1e-5, atol=1e-6)
     q2, e2 = torch.empty_like(ws.q), torch.empty_like(ws.e)
     stats2, lv2, cf2 = torch.empty_like(ws.stats), torch.empty_like(ws.loss_vec), torch.empty_like(ws.coef)
     scratch2 = torch.zeros(lib.cvf_ef_stats_scratch_doubles(k, 0), device=dev, dtype=torch.float64)
-    _hip.check(lib.cvf_metric_apply(task._pp, P(Xd), B, P(ws.aux), P(task._diag_coeff), k, P(ws.g), P(q2), P(e2), None, None,
+    _hip.check(lib.cvf_metric_apply(task._pp, P(Xd), B, P(aux2), P(task._diag_coeff), k, P(g2), P(q2), P(e2), None, None,
                                     _hip.stream()), "cvf_metric_apply")
     _hip.check(lib.cvf_ef_stats(task._cfg, B, P(wd), P(y2), P(e2), None, None, P(scratch2), P(stats2), P(lv2), P(cf2),
                                 _hip.stream()), "cvf_ef_stats")
