@@ -42,7 +42,7 @@ __device__ __forceinline__ double quad_sumd16(double v) {
 }
 
 struct Front16Lds {   // offsets in floats
-  int ref, a, aux, w, y, e, feat, g, total;
+  int ref, a, aux, w, rs, y, e, feat, g, total;
 };
 __host__ __device__ inline Front16Lds front16_lds(int nc, int nal, int k) {
   Front16Lds L;
@@ -51,7 +51,8 @@ __host__ __device__ inline Front16Lds front16_lds(int nc, int nal, int k) {
   L.a = L.ref + 3 * nal;
   L.aux = (L.a + nc + 3) & ~3;
   L.w = L.aux + ((kU * kAuxP + 3) & ~3);
-  L.y = L.w + kU;
+  L.rs = L.w + kU;      // sum of the (centred) reference over the align atoms: 3 floats (+ 1 pad)
+  L.y = L.rs + 4;
   L.e = L.y + k * kU;
   L.feat = L.e + k * kU;              // 16-byte aligned: every term above is a multiple of 4 floats
   L.g = L.feat + kU * kImgP;
@@ -62,7 +63,7 @@ __host__ __device__ inline Front16Lds front16_lds(int nc, int nal, int k) {
 // ------------------------------------------------------------------------------------------------------------------
 // front
 // ------------------------------------------------------------------------------------------------------------------
-template <int H, int NH>
+template <int H, int NH, int NIT>
 __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                              const float* __restrict__ packed, cvf_pp_desc pp,
                                                              const float* __restrict__ x, int64_t B,
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
   float* aL = lds + Lo.a;
   float* auxL = lds + Lo.aux;
   float* wL = lds + Lo.w;
+  float* rsL = lds + Lo.rs;
   float* yL = lds + Lo.y;
   float* eL = lds + Lo.e;
   float* featI = lds + Lo.feat;
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
 #pragma unroll
     for (int i = 0; i < kAuxP; ++i)
       if ((i & 3) == p) auxL[f * kAuxP + i] = av[i];   // the four lanes of a frame hold the same record: each writes a quarter
+    if (lane < 3) rsL[lane] = (float)(lane == 0 ? acc[12] : lane == 1 ? acc[13] : acc[14]);
   }
   lds_barrier();
   CVF_STAMP(22);
@@ -168,16 +171,14 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
       c.hi[i] = ar[9 + i];
       c.lo[i] = ar[18 + i];
     }
-    float* ft = feat_tiled + tile * (int64_t)D * CVF_TILE + kU * sub + f;
+    // (LDS only here: the tiled copy for the backward kernel leaves at the end of the kernel - vector-memory operations
+    //  return in issue order, so global stores at this point would sit in front of every weight fragment requested above)
     for (int at = p + 4 * wave; at < N; at += 4 * nw) {
       const V3 al = row_times(centred(my, at, c), R);
       float* fi = featI + f * kImgP + 3 * at;
       fi[0] = al.x;
       fi[1] = al.y;
       fi[2] = al.z;
-      ft[(3 * at) * CVF_TILE] = al.x;
-      ft[(3 * at + 1) * CVF_TILE] = al.y;
-      ft[(3 * at + 2) * CVF_TILE] = al.z;
     }
   }
   lds_barrier();
@@ -228,14 +229,13 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
   HFrag<H> tf[NH > 1 ? NH - 1 : 1];
 #pragma unroll
   for (int l = 1; l < NH; ++l) load_hfrag_u<H>(tf[l - 1], pk, L.th(l));
+
   // hand-off to the backward kernel, per (tile, net): 2 NH vectors in the register layout both kernels use, as
   // [vector][group g][unit of the tile][lane] (every (vector, g, unit) one coalesced 256-byte row):
   //   h_1..h_NH | e_1..e_{NH-1} (e_l = W_{l+1}^T d_{l+1}: the d chain) | s = W_1 q (the tangent chain's first product)
+  // (stored after g below: vector-memory operations return in issue order, and the fragment loads of the d chain and of g -
+  //  which the compiler places just in time - must not queue behind 25 stores)
   const URows sv = urows(saved + (tile * k + net) * (int64_t)(kHand<NH>() * NG * 256) + sub * 64, kHand<NH>() * NG * 256 - sub * 64, lane);
-#pragma unroll
-  for (int l = 0; l < NH; ++l)
-#pragma unroll
-    for (int g = 0; g < NG; ++g) sv.st((l * NG + g) * 256, h[l].v[g >> 2][0][g & 3]);
   {
     float part = 0.0f;
 #pragma unroll
@@ -243,14 +243,16 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
 #pragma unroll
       for (int r = 0; r < 4; ++r) part = fmaf(wl[rt][r], h[NH - 1].v[rt][0][r], part);
     const float yv = sum_over_q(part) + bL;
-    if (q == 0) {
-      yL[net * kU + col] = yv;
-      y_tiled[(tile * k + net) * CVF_TILE + kU * sub + col] = yv;
-    }
+    // (all four q groups hold the same value and store it to the same place: no lane-divergent branch around a store,
+    //  behind which the compiler could no longer count the outstanding memory operations and would drain them all)
+    yL[net * kU + col] = yv;
+    y_tiled[(tile * k + net) * CVF_TILE + kU * sub + col] = yv;
   }
   CVF_STAMP(25);
   // ---- d chain and g = W_1^T d_1 -> this wave's image [frame][feature]
   {
+    // (requested behind the hand-off stores of h - vector-memory operations return in issue order - but the d chain below
+    //  runs on fragments requested before them and covers that)
     float t0[CTMAX][NG];
 #pragma unroll
     for (int rt = 0; rt < CTMAX; ++rt)
@@ -264,14 +266,12 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
         const float hv = h[NH - 1].v[rt][0][r];
         d.v[rt][0][r] = wl[rt][r] * (1.0f - hv * hv);
       }
+    Vec<H, 1> ev[NH > 1 ? NH - 1 : 1];
 #pragma unroll
     for (int l = NH - 1; l >= 1; --l) {
-      Vec<H, 1> e;
-      init_bias<H, 1>(e, nullptr, q);
-      hidden_mul<H, 1>(e, tf[l - 1], d);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) sv.st(((NH + l - 1) * NG + g) * 256, e.v[g >> 2][0][g & 3]);   // e_l of the hand-off
-      tangent_of<H, 1>(d, h[l - 1], e);
+      init_bias<H, 1>(ev[l - 1], nullptr, q);
+      hidden_mul<H, 1>(ev[l - 1], tf[l - 1], d);
+      tangent_of<H, 1>(d, h[l - 1], ev[l - 1]);
     }
 #pragma unroll
     for (int rt = 0; rt < CTMAX; ++rt) {
@@ -283,34 +283,50 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
         if (16 * rt + 4 * q < D) *reinterpret_cast<float4*>(gI + col * kImgP + 16 * rt + 4 * q) = float4{acc[0], acc[1], acc[2], acc[3]};
       }
     }
+    // the hand-off rows h_1..h_NH and e_1..e_{NH-1}
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) sv.st((l * NG + g) * 256, h[l].v[g >> 2][0][g & 3]);
+#pragma unroll
+    for (int l = 1; l < NH; ++l)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) sv.st(((NH + l - 1) * NG + g) * 256, ev[l - 1].v[g >> 2][0][g & 3]);
   }
   CVF_STAMP(26);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is this wave's own: LDS keeps a wave's accesses in order
 
   float f0b[SMAX][RT];   // the first layer's fragments once more, for s = W_1 q after the passes
-  // ---- q = J A J^T g and E with four lanes per frame (the three passes of cvf_metric.hpp, atoms = p mod 4 per lane)
+  // ---- q = J A J^T g and E with four lanes per frame (the three passes of cvf_metric.hpp; lane p of a frame takes the atoms
+  // p, p + 4, ..).  NIT = ceil(N / 4) rounded up to 2 / 4 / 6 is a template parameter: the lane's g rows and centred
+  // coordinates are read from LDS ONCE into registers (clamped index + mask for the ragged end, no branches), u = a .* G
+  // replaces g in those registers and q is formed from them - one LDS round trip for the three passes instead of three.
   {
-    float R[9], Kinv[6];
+    float R[9];
     const float* ar = auxL + f * kAuxP;
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = ar[i];
     const Centre c = centre_of(ar[9], ar[10], ar[11]);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Kinv[i] = ar[12 + i];
     float* Ul = gI + f * kImgP;
-    // pass 1: sum_b R g_b and M = sum_b (x_b - c) (x) g_b
-    const MatCols Rc = mat_cols(R);
-    f2 sump_xy = {0.0f, 0.0f};
-    float sump_z = 0.0f;
+    V3 gv[NIT];
+    // pass 1: sum_b g_b and M = sum_b (x_b - c) (x) g_b
+    V3 gsum = v3(0.0f, 0.0f, 0.0f);
     Outer3 Mo = {{{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}}, {0.0f, 0.0f, 0.0f}};
-#pragma unroll 2
-    for (int at = p; at < N; at += 4) {
-      const V3 g = v3(Ul[3 * at], Ul[3 * at + 1], Ul[3 * at + 2]);
-      mat_times_acc(Rc, g, sump_xy, sump_z);
-      outer_acc(Mo, centred(my, at, c), g);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int at = p + 4 * it;
+      asm volatile("" : "+v"(at));   // (opaque: the atom's addresses are formed here, not hoisted and kept across the passes)
+      const int ac = at < N ? at : N - 1;
+      const float lv = at < N ? 1.0f : 0.0f;
+      // (a lane past the last atom works on a DUPLICATE of atom N - 1 - masked out of every sum, but carried through so that
+      //  it computes and stores the same u and q as that atom's owner: no lane-divergent branch around the stores)
+      gv[it] = v3(Ul[3 * ac], Ul[3 * ac + 1], Ul[3 * ac + 2]);
+      gsum = gsum + lv * gv[it];
+      outer_acc(Mo, centred(my, ac, c), lv * gv[it]);
     }
     CVF_STAMP(27);
-    const V3 sump = v3(quad_sumf16(sump_xy.x), quad_sumf16(sump_xy.y), quad_sumf16(sump_z));
+    gsum = v3(quad_sumf16(gsum.x), quad_sumf16(gsum.y), quad_sumf16(gsum.z));
+    const V3 sump = mat_times(R, gsum);   // sum_b R g_b
     float M[9];
     outer_to_array(Mo, M);
 #pragma unroll
@@ -320,6 +336,9 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * M[j] + R[3 + i] * M[3 + j] + R[6 + i] * M[6 + j];
+    float Kinv[6];   // (read where it is used, twice: six registers less across the atom loops)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Kinv[i] = ar[12 + i];
     const V3 s = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -329,47 +348,45 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     }
     const float inv_nal = 1.0f / (float)nal;
     const V3 shift = inv_nal * sump;
-    // pass 2: G = R g (+ Z ref - shift on the align atoms), u = a .* G, E = u . G; u replaces g in the image
-    const MatCols Zc = mat_cols(Z);
+    // pass 2: G = R g (+ Z ref - shift on the align atoms), u = a .* G, E = u . G; u replaces g in the registers
+    const MatCols Rc = mat_cols(R), Zc = mat_cols(Z);
     f2 E2 = {0.0f, 0.0f};
     float Ez = 0.0f;
-    f2 usum_xy = {0.0f, 0.0f}, rsum_xy = {0.0f, 0.0f};
-    float usum_z = 0.0f, rsum_z = 0.0f;
+    f2 usum_xy = {0.0f, 0.0f};
+    float usum_z = 0.0f;
     Outer3 dHo = {{{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}}, {0.0f, 0.0f, 0.0f}};
-#pragma unroll 2
-    for (int at = p; at < N; at += 4) {
-      const V3 g = v3(Ul[3 * at], Ul[3 * at + 1], Ul[3 * at + 2]);
-      const bool al = at < nal;
-      const int ar_ = al ? at : 0;
-      const float m = al ? 1.0f : 0.0f;
-      const V3 rf = v3(m * refL[3 * ar_], m * refL[3 * ar_ + 1], m * refL[3 * ar_ + 2]);
-      f2 Gxy = f2{-m * shift.x, -m * shift.y};
-      float Gz = -m * shift.z;
-      mat_times_acc(Rc, g, Gxy, Gz);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int at = p + 4 * it;
+      asm volatile("" : "+v"(at));   // (opaque: the atom's addresses are formed here, not hoisted and kept across the passes)
+      const int ac = at < N ? at : N - 1;
+      const float ma = ac < nal ? 1.0f : 0.0f;         // align atom: carries the rotation's and the centroid's derivative
+      const float lv = at < N ? 1.0f : 0.0f;           // alive (not a duplicate): counts in the sums
+      const float m = ma * lv;
+      const int ar_ = ac < nal ? ac : 0;
+      const V3 rf = v3(ma * refL[3 * ar_], ma * refL[3 * ar_ + 1], ma * refL[3 * ar_ + 2]);
+      f2 Gxy = f2{-ma * shift.x, -ma * shift.y};
+      float Gz = -ma * shift.z;
+      mat_times_acc(Rc, gv[it], Gxy, Gz);
       mat_times_acc(Zc, rf, Gxy, Gz);
-      const f2 uxy = f2{aL[3 * at], aL[3 * at + 1]} * Gxy;
-      const float uz = aL[3 * at + 2] * Gz;
-      E2 = fma2(uxy, Gxy, E2);
-      Ez = fmaf(uz, Gz, Ez);
-      Ul[3 * at] = uxy.x;
-      Ul[3 * at + 1] = uxy.y;
-      Ul[3 * at + 2] = uz;
+      const f2 uxy = f2{aL[3 * ac], aL[3 * ac + 1]} * Gxy;
+      const float uz = aL[3 * ac + 2] * Gz;
+      E2 = fma2(lv * uxy, Gxy, E2);
+      Ez = fmaf(lv * uz, Gz, Ez);
+      gv[it] = v3(uxy.x, uxy.y, uz);
       usum_xy += m * uxy; usum_z += m * uz;
-      rsum_xy += f2{rf.x, rf.y}; rsum_z += rf.z;
       outer_acc(dHo, v3(m * uxy.x, m * uxy.y, m * uz), rf);
     }
     CVF_STAMP(28);
     const float E = quad_sumf16((E2.x + E2.y) + Ez);
     const V3 usum = v3(quad_sumf16(usum_xy.x), quad_sumf16(usum_xy.y), quad_sumf16(usum_z));
-    const V3 rsum = v3(quad_sumf16(rsum_xy.x), quad_sumf16(rsum_xy.y), quad_sumf16(rsum_z));
+    const V3 rsum = v3(rsL[0], rsL[1], rsL[2]);   // sum of the reference over the align atoms (the fp32 residue of its centring)
     float dH[9];
     outer_to_array(dHo, dH);
 #pragma unroll
     for (int i = 0; i < 9; ++i) dH[i] = quad_sumf16(dH[i]);
-    if (p == 0) {
-      eL[net * kU + f] = E;
-      e_tiled[(tile * k + net) * CVF_TILE + kU * sub + f] = E;
-    }
+    eL[net * kU + f] = E;   // (the four lanes of a frame hold the same sum and store it to the same place)
+    e_tiled[(tile * k + net) * CVF_TILE + kU * sub + f] = E;
     const V3 ubar = inv_nal * usum;
     dH[0] -= ubar.x * rsum.x; dH[1] -= ubar.x * rsum.y; dH[2] -= ubar.x * rsum.z;
     dH[3] -= ubar.y * rsum.x; dH[4] -= ubar.y * rsum.y; dH[5] -= ubar.y * rsum.z;
@@ -378,6 +395,9 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * dH[j] + R[3 + i] * dH[3 + j] + R[6 + i] * dH[6 + j];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Kinv[i] = ar[12 + i];
     const V3 om = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
     float dR[9];
 #pragma unroll
@@ -386,49 +406,70 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
       dR[3 * i + 1] = -R[3 * i + 0] * om.z + R[3 * i + 2] * om.x;
       dR[3 * i + 2] = R[3 * i + 0] * om.y - R[3 * i + 1] * om.x;
     }
-    // pass 3: q_b = (u_b - ubar) R + (x_b - c) dR
-    // (requested here: the third pass covers the round trip)
+    // pass 3: q_b = (u_b - ubar) R + (x_b - c) dR  -> in place of g, this wave's image (the B operand of s = W_1 q below)
+    CVF_STAMP(31);
+    const MatRows Rr = mat_rows(R), dRr = mat_rows(dR);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int at = p + 4 * it;
+      asm volatile("" : "+v"(at));   // (opaque: the atom's addresses are formed here, not hoisted and kept across the passes)
+      const int ac = at < N ? at : N - 1;
+      f2 qxy = {0.0f, 0.0f};
+      float qz = 0.0f;
+      row_times_acc(Rr, gv[it] - ubar, qxy, qz);
+      row_times_acc(dRr, centred(my, ac, c), qxy, qz);
+      gv[it] = v3(qxy.x, qxy.y, qz);   // (kept: q leaves for global memory at the very end, behind every load of this kernel)
+      Ul[3 * ac] = qxy.x;
+      Ul[3 * ac + 1] = qxy.y;
+      Ul[3 * ac + 2] = qz;
+    }
+    CVF_STAMP(32);
+    asm volatile("" ::: "memory");   // (not earlier: 36 more live registers during the passes spill, and a spill's reload
+                                     //  drains every outstanding store)
 #pragma unroll
     for (int s_ = 0; s_ < SMAX; ++s_) {
       const int se = s_ < S ? s_ : S - 1;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) f0b[s_][rt] = pk.ld(L.f0() + (se * RT + rt) * 64);
     }
-    const MatRows Rr = mat_rows(R), dRr = mat_rows(dR);
+    // ---- s = W_1 q (what the backward kernel's tangent chain starts from, up to the per-frame factor 2 w dL/dE it only
+    // knows after the batch sums are reduced): the first layer's fragments once more, q from this wave's image
+    {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      Vec<H, 1> sv0;
+      init_bias<H, 1>(sv0, nullptr, q);
+      const float* qr = gI + col * kImgP;
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) {
+        if (s < S) {   // wave-uniform
+          const int kf = 4 * s + q;
+          const float b = qr[kf < D ? kf : D - 1];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) sv0.v[rt][0] = mfma4(f0b[s][rt], b, sv0.v[rt][0]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) sv.st(((2 * NH - 1) * NG + g) * 256, sv0.v[g >> 2][0][g & 3]);
+    }
+    CVF_STAMP(33);
+    // ---- q -> the tiled hand-off (the first layer's weight-gradient operand of the backward kernel)
     float* qt = q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + kU * sub + f;
-#pragma unroll 2
-    for (int at = p; at < N; at += 4) {
-      const V3 u = v3(Ul[3 * at], Ul[3 * at + 1], Ul[3 * at + 2]);
-      f2 qxy = {0.0f, 0.0f};
-      float qz = 0.0f;
-      row_times_acc(Rr, u - ubar, qxy, qz);
-      row_times_acc(dRr, centred(my, at, c), qxy, qz);
-      qt[(3 * at) * CVF_TILE] = qxy.x;
-      qt[(3 * at + 1) * CVF_TILE] = qxy.y;
-      qt[(3 * at + 2) * CVF_TILE] = qz;
-      Ul[3 * at] = qxy.x;       // q replaces u in the image: the B operand of s = W_1 q below
-      Ul[3 * at + 1] = qxy.y;
-      Ul[3 * at + 2] = qz;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int at = p + 4 * it;
+      asm volatile("" : "+v"(at));
+      const int ac = at < N ? at : N - 1;
+      qt[(3 * ac) * CVF_TILE] = gv[it].x;
+      qt[(3 * ac + 1) * CVF_TILE] = gv[it].y;
+      qt[(3 * ac + 2) * CVF_TILE] = gv[it].z;
     }
   }
-  // ---- s = W_1 q (what the backward kernel's tangent chain starts from, up to the per-frame factor 2 w dL/dE it only
-  // knows after the batch sums are reduced): the first layer's fragments once more, q from this wave's image
+  CVF_STAMP(34);
+  // ---- the feature tile for the backward kernel (the first layer's weight-gradient operand), from the LDS image
   {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    Vec<H, 1> sv0;
-    init_bias<H, 1>(sv0, nullptr, q);
-    const float* qr = gI + col * kImgP;
-#pragma unroll
-    for (int s = 0; s < SMAX; ++s) {
-      if (s < S) {   // wave-uniform
-        const int kf = 4 * s + q;
-        const float b = qr[kf < D ? kf : D - 1];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) sv0.v[rt][0] = mfma4(f0b[s][rt], b, sv0.v[rt][0]);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) sv.st(((2 * NH - 1) * NG + g) * 256, sv0.v[g >> 2][0][g & 3]);
+    float* ft = feat_tiled + tile * (int64_t)D * CVF_TILE + kU * sub + f;
+    const float* fi = featI + f * kImgP;
+    for (int j = p + 4 * wave; j < D; j += 4 * nw) ft[j * CVF_TILE] = fi[j];
   }
   CVF_STAMP(29);
   if (partial == nullptr) return;   // (uniform) large batches: the caller reduces y / E with cvf_ef_stats
@@ -481,8 +522,8 @@ struct Back16Args {
   int64_t n_tiles;
 };
 
-template <int H, int NH>
-__global__ __launch_bounds__(256, 3) void ef16_back_kernel(Back16Args args, cvf_mlp_desc mlp, const float* __restrict__ theta,
+template <int H, int NH, bool MULTI>
+__global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                             const float* __restrict__ packed, const float* __restrict__ w,
                                                             const float* __restrict__ feat, const float* __restrict__ y_tiled,
                                                             const float* __restrict__ q_tiled, const double* __restrict__ coef,
@@ -494,7 +535,7 @@ __global__ __launch_bounds__(256, 3) void ef16_back_kernel(Back16Args args, cvf_
   constexpr int NT = 256, WPB = 4;
   constexpr int kRows = 2 * H + 2 * (H + 1) + 16;   // packed images: reads past an image's rows meet finite values whose products are discarded
   __shared__ __attribute__((aligned(16))) float IMG[kRows * kPitch];
-  extern __shared__ float GI[];  // this block's partial gradient of `net` (flat parameter order)
+  extern __shared__ float GI[];  // MULTI (a block walks several tiles): its partial gradient of `net`, flat parameter order
   float* SA1 = IMG;
   float* SA2 = SA1 + H * kPitch;
   float* SB1 = SA2 + H * kPitch;
@@ -507,40 +548,49 @@ __global__ __launch_bounds__(256, 3) void ef16_back_kernel(Back16Args args, cvf_
   const int CT1 = (D + 1 + 15) / 16;
   const int gbase = mlp.w_off[net][0];
   const int gspan = mlp.b_off[net][NH] + 1 - gbase;
+  float* out = slab + (int64_t)blockIdx.x * mlp.n_params + gbase;   // this block's slab row, this net's span
 
   for (int i = tid; i < kRows * kPitch; i += NT) IMG[i] = 0.0f;
-  for (int i = tid; i < gspan; i += NT) GI[i] = 0.0f;
+  if (MULTI)
+    for (int i = tid; i < gspan; i += NT) GI[i] = 0.0f;
   __syncthreads();
   if (tid < 64) SB1[H * kPitch + tid] = 1.0f;  // bias column of [h ; 1]  (row H of SB2 stays 0)
 
   const PackLayout L = pack_layout(H, NH, D);
   const URows pk = urows(packed + (int64_t)net * L.per_net, L.per_net, lane);   // this net's fragments (see URows)
-  // the tangent chain's weight fragments W_l, l = 2..NH, once per block (the hbar chain's W_l^T are requested at the top
-  // of each reverse step, a phase of outer products ahead of their use)
-  HFrag<H> ffr[NH > 1 ? NH - 1 : 1];
-#pragma unroll
-  for (int l = 1; l < NH; ++l) load_hfrag_u<H>(ffr[l - 1], pk, L.fh(l));
   float wl[RT][4];
   load_hid_const_u<H>(urows(theta + mlp.w_off[net][NH], H, q), wl);
   const double gS1n = coef[net], gEtn = coef[k + k * k + net];
   const float one[1] = {1.0f};
 
-  auto add_tile = [&](int l, int n_out, int n_in, int rt, int ct, const f32x4& acc) {
+  // a finished 16x16 tile of layer `l` (rows = outputs, columns = inputs + bias).  Every tile of the gradient is produced
+  // by exactly one wave, so a block that handles ONE tile of frames stores it straight into its slab row; a block that
+  // walks several accumulates in the LDS image and flushes at the end.
+  auto emit_tile = [&](int l, int n_out, int n_in, int rt, int ct, const f32x4& acc) {
     const int wo = mlp.w_off[net][l] - gbase, bo = mlp.b_off[net][l] - gbase;
     const int i = 16 * ct + row16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int o = 16 * rt + r0 + r;
-      if (o < n_out) {
-        if (i < n_in) GI[wo + o * n_in + i] += acc[r];
-        else if (i == n_in) GI[bo + o] += acc[r];
+      const bool isw = o < n_out && i < n_in, isb = o < n_out && i == n_in;
+      const int idx = isw ? wo + o * n_in + i : bo + (o < n_out ? o : 0);
+      if (isw || isb) {
+        if (MULTI) GI[idx] += acc[r];
+        else out[idx] = acc[r];
       }
     }
+  };
+  // one 16x16 tile of  A1 B1^T + A2 B2^T  over the tile's 64 frames, operands in LDS images (eight 16-byte reads at a time)
+  auto outer2 = [&](const float* A1, const float* B1, const float* A2, const float* B2, int rt, int ct) {
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    acc = outer_half(A1, B1, rt, ct, lane, acc);
+    acc = outer_half(A2, B2, rt, ct, lane, acc);
+    return acc;
   };
 
   for (int64_t tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x) {
     CVF_STAMP(8);
-    // ---- everything this tile needs from memory is requested here
+    // ---- everything the chains need from memory is requested here
     const int64_t frame = tile * CVF_TILE + fo;
     const bool valid = frame < args.B;
     const float wraw = w[valid ? frame : args.B - 1];
@@ -567,24 +617,13 @@ __global__ __launch_bounds__(256, 3) void ef16_back_kernel(Back16Args args, cvf_
     for (int rt = 0; rt < RT; ++rt) t[0].v[rt][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int g = 0; g < NG; ++g) t[0].v[g >> 2][0][g & 3] = sv.ld(((2 * NH - 1) * NG + g) * 256);
-    // the first layer's weight gradient has the feature tile (+ ones row) and q as its B operands, straight from memory:
-    // wave w owns column tile w (both row tiles reuse the registers); k-slot kq of k-step (j, c) is frame 16 j + 4 kq + c,
-    // so a lane's sixteen values of one operand row are four 16-byte loads
+    // the tangent chain's weight fragments W_l, l = 2..NH, with the same round trip (the hbar chain's W_l^T are requested at
+    // the top of each reverse step, a phase of outer products ahead of their use)
+    HFrag<H> ffr[NH > 1 ? NH - 1 : 1];
+#pragma unroll
+    for (int l = 1; l < NH; ++l) load_hfrag_u<H>(ffr[l - 1], pk, L.fh(l));
     const float* f_tile = feat + tile * (int64_t)D * CVF_TILE;
     const float* q_tile = q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE;
-    float4 bF[4], bQ[4];   // requested one reverse step ahead of the first layer's (below)
-    auto request_b = [&]() {
-      const int i = 16 * wave + row16;
-      const int ic = i < D ? i : D - 1;
-      const float4* fb = reinterpret_cast<const float4*>(f_tile + (int64_t)ic * CVF_TILE + 4 * q);
-      const float4* qb = reinterpret_cast<const float4*>(q_tile + (int64_t)ic * CVF_TILE + 4 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bF[j] = fb[4 * j];
-        bQ[j] = qb[4 * j];
-      }
-    };
-    if (NH == 1) request_b();
     // ---- per-frame coefficients
     const float wb = valid ? wraw : 0.0f;
     float alpha, gamma;
@@ -622,12 +661,15 @@ __global__ __launch_bounds__(256, 3) void ef16_back_kernel(Back16Args args, cvf_
       store_image<H, 1, false>(SB2, td, one, lane, fo);
       __syncthreads();
       for (int ct = wave; ct < CTH; ct += WPB) {
-        const f32x4 acc = outer_tile(SA1, SB1, SA2, SB2, 0, ct, true, lane);
+        const f32x4 acc = outer2(SA1, SB1, SA2, SB2, 0, ct);
         if (q == 0) {  // output row 0 lives in register 0 of lanes 0..15
           const int wo = mlp.w_off[net][NH] - gbase, bo = mlp.b_off[net][NH] - gbase;
           const int i = 16 * ct + row16;
-          if (i < H) GI[wo + i] += acc[0];
-          else if (i == H) GI[bo] += acc[0];
+          if (i <= H) {
+            const int idx = i < H ? wo + i : bo;
+            if (MULTI) GI[idx] += acc[0];
+            else out[idx] = acc[0];
+          }
         }
       }
       __syncthreads();
@@ -642,9 +684,19 @@ __global__ __launch_bounds__(256, 3) void ef16_back_kernel(Back16Args args, cvf_
 #pragma unroll
     for (int l = NH - 1; l >= 0; --l) {
       CVF_STAMP(13 + (NH - 1 - l));
-      if (NH > 1 && l == 1) request_b();
       HFrag<H> tfl;
       if (l > 0) load_hfrag_u<H>(tfl, pk, L.th(l));
+      // the first layer's B operands come straight from memory (the feature tile + ones row, then q): wave w owns column
+      // tile w; k-slot kq of k-step (j, c) is frame 16 j + 4 kq + c, so a lane's sixteen values of one operand row are four
+      // 16-byte loads.  The [f ; 1] rows are requested here, q's after the barrier, behind the matrix instructions of the first half.
+      float4 bA[4], bB[4];
+      auto request = [&](float4 (&dst)[4], const float* src_tile, int ct) {
+        const int i = 16 * ct + row16;
+        const float4* p = reinterpret_cast<const float4*>(src_tile + (int64_t)(i < D ? i : D - 1) * CVF_TILE + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = p[4 * j];
+      };
+      if (l == 0) request(bA, f_tile, wave);
       Vec<H, 1> zbar, dl;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -670,7 +722,7 @@ __global__ __launch_bounds__(256, 3) void ef16_back_kernel(Back16Args args, cvf_
         __syncthreads();
         for (int pr = wave; pr < RTO * CTH; pr += WPB) {
           const int rt = pr / CTH, ct = pr - rt * CTH;
-          add_tile(l, H, H, rt, ct, outer_tile(SA1, SB1, SA2, SB2, rt, ct, true, lane));
+          emit_tile(l, H, H, rt, ct, outer2(SA1, SB1, SA2, SB2, rt, ct));
         }
         // hbar_{l-1} = W_l^T zbar_l  (registers; overlaps the other waves' outer products)
         init_bias<H, 1>(hbar, nullptr, q);
@@ -678,82 +730,64 @@ __global__ __launch_bounds__(256, 3) void ef16_back_kernel(Back16Args args, cvf_
         __syncthreads();
       } else {
         __syncthreads();
-        // column tile `ct` x row tiles rt0, rt0 + rstep, ..: the [f ; 1] half, then the q half, B operands in registers
-        auto outer0 = [&](int ct, int rt0, int rstep, const float4 (&bf)[4], const float4 (&bq)[4]) {
+        // one half of the contraction of column tile `ct` for the row tiles rt0, rt0 + rstep, ..: A rows from the LDS image
+        // `SA`, B rows in registers; columns: features, then the ones (bias) column when `ones`, zeros past it
+        // (no MFMA under lane-divergent control flow: operand values are selected per lane, the MFMAs are uniform)
+        auto half0 = [&](f32x4 (&acc)[RTO], const float* SA, const float4 (&b)[4], int ct, int rt0, int rstep, bool ones) {
           const int i = 16 * ct + row16;
-          const float pad1 = i == D ? 1.0f : 0.0f;   // bias column; columns past it stay 0
-          // (no MFMA under lane-divergent control flow: operand values are selected per lane, the MFMAs are uniform)
+          const float pad = (ones && i == D) ? 1.0f : 0.0f;
 #pragma unroll
           for (int rt = 0; rt < RTO; ++rt) {
             if (rt >= rt0 && (rt - rt0) % rstep == 0) {
-              f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-              const float4* a1 = reinterpret_cast<const float4*>(SA1 + (16 * rt + row16) * kPitch + 4 * q);
-              const float4* a2 = reinterpret_cast<const float4*>(SA2 + (16 * rt + row16) * kPitch + 4 * q);
-              float4 av[4], aw[4];
+              const float4* a1 = reinterpret_cast<const float4*>(SA + (16 * rt + row16) * kPitch + 4 * q);
+              float4 av[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) av[j] = a1[4 * j];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                av[j] = a1[4 * j];
-                aw[j] = a2[4 * j];
+                acc[rt] = mfma4(av[j].x, i < D ? b[j].x : pad, acc[rt]);
+                acc[rt] = mfma4(av[j].y, i < D ? b[j].y : pad, acc[rt]);
+                acc[rt] = mfma4(av[j].z, i < D ? b[j].z : pad, acc[rt]);
+                acc[rt] = mfma4(av[j].w, i < D ? b[j].w : pad, acc[rt]);
               }
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                acc = mfma4(av[j].x, i < D ? bf[j].x : pad1, acc);
-                acc = mfma4(av[j].y, i < D ? bf[j].y : pad1, acc);
-                acc = mfma4(av[j].z, i < D ? bf[j].z : pad1, acc);
-                acc = mfma4(av[j].w, i < D ? bf[j].w : pad1, acc);
-              }
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                acc = mfma4(aw[j].x, i < D ? bq[j].x : 0.0f, acc);
-                acc = mfma4(aw[j].y, i < D ? bq[j].y : 0.0f, acc);
-                acc = mfma4(aw[j].z, i < D ? bq[j].z : 0.0f, acc);
-                acc = mfma4(aw[j].w, i < D ? bq[j].w : 0.0f, acc);
-              }
-              add_tile(0, H, D, rt, ct, acc);
             }
           }
         };
         // column tiles beyond the first four (a fifth, ragged one for D = 66: two features and the bias column) are dealt
-        // by (column tile, row tile) pairs; their operands are requested before this wave's own tile is multiplied
-        const int extra = (CT1 - WPB) * RTO;   // pairs left after every wave took its own column tile
-        const int my_pr = wave < extra ? wave : -1;
-        float4 xF[4], xQ[4];
-        const int xct = WPB + (my_pr >= 0 ? my_pr / RTO : 0), xrt = my_pr >= 0 ? my_pr % RTO : 0;
-        {
-          const int i = 16 * xct + row16;
-          const int ic = i < D ? i : D - 1;
-          const float4* fb = reinterpret_cast<const float4*>(f_tile + (int64_t)ic * CVF_TILE + 4 * q);
-          const float4* qb = reinterpret_cast<const float4*>(q_tile + (int64_t)ic * CVF_TILE + 4 * q);
+        // by (column tile, row tile) pairs: pair p -> wave p % 4
+        const int extra = (CT1 - WPB) * RTO;
+        f32x4 acc[RTO];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            xF[j] = fb[4 * j];
-            xQ[j] = qb[4 * j];
-          }
+        for (int rt = 0; rt < RTO; ++rt) acc[rt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (wave < CT1) {   // wave-uniform
+          request(bB, q_tile, wave);
+          half0(acc, SA1, bA, wave, 0, 1, true);
+          if (wave < extra) request(bA, f_tile, WPB + wave / RTO);   // the extra pair's rows, behind the second half
+          half0(acc, SA2, bB, wave, 0, 1, false);
+#pragma unroll
+          for (int rt = 0; rt < RTO; ++rt) emit_tile(0, H, D, rt, wave, acc[rt]);
         }
-        if (wave < CT1) outer0(wave, 0, 1, bF, bQ);
-        if (my_pr >= 0) outer0(xct, xrt, RTO, xF, xQ);
-        for (int pr = WPB + wave; pr < extra; pr += WPB) {   // (wider first layers: more than eight column tiles)
+        for (int pr = wave; pr < extra; pr += WPB) {
           const int ct = WPB + pr / RTO, rt = pr % RTO;
-          const int i = 16 * ct + row16;
-          const int ic = i < D ? i : D - 1;
-          const float4* fb = reinterpret_cast<const float4*>(f_tile + (int64_t)ic * CVF_TILE + 4 * q);
-          const float4* qb = reinterpret_cast<const float4*>(q_tile + (int64_t)ic * CVF_TILE + 4 * q);
+          if (pr != wave || wave >= CT1) request(bA, f_tile, ct);
+          request(bB, q_tile, ct);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            xF[j] = fb[4 * j];
-            xQ[j] = qb[4 * j];
-          }
-          outer0(ct, rt, RTO, xF, xQ);
+          for (int r_ = 0; r_ < RTO; ++r_) acc[r_] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          half0(acc, SA1, bA, ct, rt, RTO, true);
+          half0(acc, SA2, bB, ct, rt, RTO, false);
+#pragma unroll
+          for (int r_ = 0; r_ < RTO; ++r_)
+            if (r_ == rt) emit_tile(0, H, D, r_, ct, acc[r_]);
         }
         __syncthreads();
       }
     }
   }
   CVF_STAMP(17);
-  // ---- flush this block's partial gradient of `net` into its slab row
-  __syncthreads();
-  float* out = slab + (int64_t)blockIdx.x * mlp.n_params + gbase;
-  for (int i = tid; i < gspan; i += NT) out[i] = GI[i];
+  if (MULTI) {   // flush this block's partial gradient of `net` into its slab row
+    __syncthreads();
+    for (int i = tid; i < gspan; i += NT) out[i] = GI[i];
+  }
   // one gradient per optimiser step: advance the step counter read by the Adam that follows
   if (step != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *step += 1;
   CVF_STAMP(18);
@@ -834,10 +868,15 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
   const size_t lds = (size_t)front16_lds(pp->n_coord, pp->n_align, k).total * sizeof(float);
   ef16_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    auto kernel = ef16_front_kernel<kH, kNH>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, *pp, x, B, a, w,
-                       feat_tiled, y_tiled, saved, q_tiled, e_tiled, rows ? scratch : nullptr, ns);
+    auto go = [&](auto kernel) {
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, *pp, x, B, a, w,
+                         feat_tiled, y_tiled, saved, q_tiled, e_tiled, rows ? scratch : nullptr, ns);
+    };
+    const int nit = (pp->n_rec + 3) / 4;   // atoms per lane in the four-lanes-per-frame passes
+    if (nit <= 2) go(ef16_front_kernel<kH, kNH, 2>);
+    else if (nit <= 4) go(ef16_front_kernel<kH, kNH, 4>);
+    else go(ef16_front_kernel<kH, kNH, 6>);
   });
   int rc = cvf_check_launch("ef16_front_kernel");
   if (rc) return rc;
@@ -874,8 +913,12 @@ extern "C" int cvf_ef16_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp,
   const int64_t G = cvf_ef16_backward_slab_rows(a.n_tiles);
   const bool launched = ef16_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    hipLaunchKernelGGL((ef16_back_kernel<kH, kNH>), dim3((unsigned)G, cfg->k), dim3(256), (size_t)span * sizeof(float),
-                       (hipStream_t)stream, a, *mlp, theta, packed, w, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved);
+    if (a.n_tiles > G)   // blocks walk several tiles: partial gradient in LDS, flushed once
+      hipLaunchKernelGGL((ef16_back_kernel<kH, kNH, true>), dim3((unsigned)G, cfg->k), dim3(256), (size_t)span * sizeof(float),
+                         (hipStream_t)stream, a, *mlp, theta, packed, w, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved);
+    else                 // one tile per block: every gradient tile goes straight to the block's slab row
+      hipLaunchKernelGGL((ef16_back_kernel<kH, kNH, false>), dim3((unsigned)G, cfg->k), dim3(256), 0,
+                         (hipStream_t)stream, a, *mlp, theta, packed, w, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved);
   });
   CVF_REQUIRE(launched, "cvf_ef16_backward: no kernel instance for hidden width %d x %d layers", H, NH);
   return cvf_check_launch("ef16_back_kernel");

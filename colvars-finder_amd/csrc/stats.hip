@@ -109,7 +109,9 @@ __global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, i
                                                                double* __restrict__ coef) {
   __shared__ double fin[kMaxStats];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  constexpr int kRows = 8;
+  // (24 row loads in flight per lane: the 1250 unit rows of a 20 000-frame batch (csrc/ef16.hip) are ONE round trip per
+  //  statistic; with eight it was three dependent ones, 9 us for this launch)
+  constexpr int kRows = 24;
   for (int i = wave; i < ns; i += nw) {
     double acc = 0.0;
     for (int g0 = lane; g0 < n_rows; g0 += CVF_WAVE * kRows) {

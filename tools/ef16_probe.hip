@@ -119,6 +119,19 @@ int main(int argc, char** argv) {
       printf("-- front B=%d wave %d (%d units sampled)\n", B, wv, n);
       for (int i = 0; i < 10; ++i) { printf("   %-34s %8.0f cycles\n", fn[i], acc[i] / n); tot += acc[i] / n; }
       printf("   total %8.0f cycles\n", tot);
+      {  // pass 3 in detail
+        double d3[5] = {0};
+        int n3 = 0;
+        for (int u = 0; u < units && u * 4 + wv < 4096; ++u) {
+          const unsigned long long* s = &st[(size_t)(u * 4 + wv) * 64];
+          if (s[28] == 0 || s[34] == 0) continue;
+          d3[0] += double(s[31] - s[28]); d3[1] += double(s[32] - s[31]); d3[2] += double(s[33] - s[32]); d3[3] += double(s[34] - s[33]);
+          d3[4] += double(s[29] - s[34]);
+          ++n3;
+        }
+        printf("   pass 3 split: sums+dR %.0f | q loop %.0f | W1 q (loads, MFMA, stores) %.0f | q stores %.0f | feature copy %.0f\n",
+               d3[0] / n3, d3[1] / n3, d3[2] / n3, d3[3] / n3, d3[4] / n3);
+      }
     }
     std::fill(st.begin(), st.end(), 0ull);
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), st.data(), st.size() * 8));
