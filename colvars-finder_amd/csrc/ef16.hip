@@ -499,7 +499,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
       v += dpp_movd<0x112, 0xf>(v);   // row_shr:2
       v += dpp_movd<0x114, 0xf>(v);   // row_shr:4
       v += dpp_movd<0x118, 0xf>(v);   // row_shr:8 -> lane 15 of the row holds the sum of its 16 frames
-      if (fr == 15 && t < ns) partial[unit * (int64_t)ns + t] = v;
+      if (fr == 15 && t < ns) partial[t * (int64_t)gridDim.x + unit] = v;   // [statistic][unit]: coalesced for the finishing launch
     }
   }
   CVF_STAMP(30);
@@ -696,7 +696,10 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = p[4 * j];
       };
-      if (l == 0) request(bA, f_tile, wave);
+      if (l == 0) {
+        request(bA, f_tile, wave);
+        request(bB, q_tile, wave);
+      }
       Vec<H, 1> zbar, dl;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -760,7 +763,6 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
 #pragma unroll
         for (int rt = 0; rt < RTO; ++rt) acc[rt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         if (wave < CT1) {   // wave-uniform
-          request(bB, q_tile, wave);
           half0(acc, SA1, bA, wave, 0, 1, true);
           if (wave < extra) request(bA, f_tile, WPB + wave / RTO);   // the extra pair's rows, behind the second half
           half0(acc, SA2, bB, wave, 0, 1, false);
@@ -823,8 +825,8 @@ bool ef16_dispatch(int H, int NH, F&& f) {
 
 }  // namespace
 
-int cvf_ef_stats_finish(const cvf_ef_cfg* cfg, int n_rows, const double* partial, double* stats, double* loss_vec, double* coef,
-                        hipStream_t s);
+int cvf_ef_stats_finish_impl(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
+                             double* loss_vec, double* coef, hipStream_t s);
 
 extern "C" int cvf_ef16_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp) {
   int H, NH;
@@ -880,7 +882,7 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
   });
   int rc = cvf_check_launch("ef16_front_kernel");
   if (rc) return rc;
-  if (rows) return cvf_ef_stats_finish(cfg, (int)units, scratch, stats, loss_vec, coef, (hipStream_t)stream);
+  if (rows) return cvf_ef_stats_finish_impl(cfg, (int)units, 1, scratch, stats, loss_vec, coef, (hipStream_t)stream);
   return cvf_ef_stats(cfg, B, w, y_tiled, e_tiled, nullptr, nullptr, scratch, stats, loss_vec, coef, stream);
 }
 

@@ -103,7 +103,7 @@ __global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats,
 // launch.  Stat i is summed by one wave: lane l adds rows l, l+64, ... (loads issued eight at a time), the 64 lane
 // sums are combined by the fixed-order DPP reduction -> bitwise reproducible for a given number of rows.
 template <int KT>
-__global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, int ns, int n_rows,
+__global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, int ns, int n_rows, int stat_major,
                                                                const double* __restrict__ partial,
                                                                double* __restrict__ stats, double* __restrict__ loss_vec,
                                                                double* __restrict__ coef) {
@@ -111,7 +111,10 @@ __global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, i
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // (24 row loads in flight per lane: the 1250 unit rows of a 20 000-frame batch (csrc/ef16.hip) are ONE round trip per
   //  statistic; with eight it was three dependent ones, 9 us for this launch)
+  // stat_major: partial is [statistic][row] - a wave's 64 lanes read 512 consecutive bytes per load instead of one 8-byte
+  // word in each of 64 rows (64 cache lines per instruction: with 1250 rows that access pattern alone was 8 us)
   constexpr int kRows = 24;
+  const int64_t rs = stat_major ? 1 : ns, is = stat_major ? n_rows : 1;
   for (int i = wave; i < ns; i += nw) {
     double acc = 0.0;
     for (int g0 = lane; g0 < n_rows; g0 += CVF_WAVE * kRows) {
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, i
 #pragma unroll
       for (int b = 0; b < kRows; ++b) {
         const int g = g0 + CVF_WAVE * b;
-        v[b] = partial[(int64_t)(g < n_rows ? g : n_rows - 1) * ns + i];
+        v[b] = partial[(int64_t)(g < n_rows ? g : n_rows - 1) * rs + i * is];
       }
 #pragma unroll
       for (int b = 0; b < kRows; ++b) acc += (g0 + CVF_WAVE * b < n_rows) ? v[b] : 0.0;
@@ -173,14 +176,20 @@ static bool k_dispatch(int k, F&& f) {
 }
 
 // rows of per-block (or per-tile, see k1_align.hip) partial sums -> stats [+ loss_vec, coef]
+int cvf_ef_stats_finish_impl(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
+                             double* loss_vec, double* coef, hipStream_t s);
 int cvf_ef_stats_finish(const cvf_ef_cfg* cfg, int n_rows, const double* partial, double* stats, double* loss_vec, double* coef,
                         hipStream_t s) {
+  return cvf_ef_stats_finish_impl(cfg, n_rows, 0, partial, stats, loss_vec, coef, s);
+}
+int cvf_ef_stats_finish_impl(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
+                             double* loss_vec, double* coef, hipStream_t s) {
   const int ns = cvf_ef_nstats(cfg->k, cfg->lag_idx);
   const int waves = ns < 16 ? ns : 16;
   k_dispatch(cfg->k, [&](auto kc) {
     constexpr int K = decltype(kc)::value;
-    hipLaunchKernelGGL((ef_stats_finish_kernel<K>), dim3(1), dim3(64 * waves), 0, s, *cfg, ns, n_rows, partial, stats, loss_vec,
-                       coef);
+    hipLaunchKernelGGL((ef_stats_finish_kernel<K>), dim3(1), dim3(64 * waves), 0, s, *cfg, ns, n_rows, stat_major, partial, stats,
+                       loss_vec, coef);
   });
   return cvf_check_launch("ef_stats_finish_kernel");
 }

@@ -483,6 +483,52 @@ def test_large_molecule_generator_step_vs_oracle(dev, n_atoms, B, contig, k):
     np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
 
 
+def test_config5_shape_generator_step_vs_oracle(dev):
+    """BASELINE config 5's shape - 5000 atoms, d_r = 384 (32 positions + 96 dihedrals + 96 bonds, the feature list of
+    bench.c5_features), k = 6 nets [384,20,20,20,1], alignment on all atoms - on 48 frames: the streaming alignment
+    kernel's rows (k1_large_slice_kernel at N = 5000), then one generator-mode step (metric_large at k = 6, the backward
+    kernel at d_r = 384): loss, eigenvalues, ordering and every parameter gradient against the fp64 oracle (autograd
+    through linalg.svd over all 5000 atoms)."""
+    import bench
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    n_atoms, B, k = 5000, 48, 6   # (the oracle's double-backward graph through the SVD of 5000-atom frames takes ~1.1 GB of host memory per frame)
+    traj, w, ref = make_molecule_traj(n_atoms, B, seed=5005, scale=2.0, sigma=0.05)   # nm-like units, as bench.py --workload c5
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=bench.c5_features(n_atoms), use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    assert layer.d_r == 384
+    # K1-large rows vs the oracle
+    got_rows = layer(torch.tensor(traj, device=dev)).cpu().numpy()
+    torch.set_default_dtype(torch.float64)
+    want_rows = oracle_layer(spec)(torch.tensor(traj, dtype=torch.float64)).numpy()
+    torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(got_rows, want_rows, rtol=2e-5, atol=3e-6 * np.abs(want_rows).max())
+    dims = [384, 20, 20, 20, 1]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(55))
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    a = torch.tensor(diag_coeff_for(n_atoms, 5), dtype=torch.float32)
+    eig_w = [1.0, 0.9, 0.8, 0.7, 0.6, 0.5]
+    task = core.EigenFunctionTask(Traj(traj, w, 1.0), layer, model, "/tmp/cvf_test", 20.0, eig_w, diag_coeff=a, beta=1.0, lag_tau=0,
+                                  k=k, device=dev, verbose=False, save_model_every_step=0)
+    assert task._dense is not None    # the streaming (large-molecule) path
+    loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+    X = torch.tensor(traj, dtype=torch.float64, requires_grad=True)
+    lo, eo, no, po, co = losses.ef_loss(sd, k, oracle_layer(spec), X, torch.tensor(w), alpha=20.0, eig_w=eig_w,
+                                        diag_coeff=a.double(), beta=1.0)
+    lo.backward()
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(float(npl), float(no.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=RTOL64)
+    assert list(cvec) == list(co)
+    want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+
+
 @pytest.mark.parametrize("n_atoms,n_pos,B,k", [(22, 22, 1000, 3), (22, 22, 64, 1), (12, 9, 333, 2)])
 def test_fused_metric_stats_equals_two_launch_path(dev, n_atoms, n_pos, B, k):
     """cvf_metric_apply_stats (batch sums + loss tail in the derivative kernel's epilogue) against cvf_metric_apply +
