@@ -11,6 +11,7 @@
 //             feature launch re-fetched more sectors from HBM than the frame itself holds).
 //   flush     features of the 16 frames are staged in LDS and leave as full 64-byte segments of the tiled layout.
 #include "cvf_kabsch.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
 // Per frame a wave reduces its twelve partial sums through a small wave-private LDS transpose (4 values a round:
 // 4 writes, one 16-byte read, four DPP steps) instead of twelve full-wave butterflies.
 // ---------------------------------------------------------------------------------------------------------
-template <int NI>
+template <int NI, bool NT>
 __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
                                                                      float* __restrict__ feat_tiled,
                                                                      float* __restrict__ feat_rows,
@@ -416,14 +417,16 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc
 #pragma unroll 1
   for (int j = 0; j < kGroup; ++j) {
     const int64_t frame = f0 + j < B ? f0 + j : B - 1;
-    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + frame * nc);
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    const nt4* __restrict__ x4 = reinterpret_cast<const nt4*>(x + frame * nc);
     float* capL = dyn + (size_t)j * nslot * 3;
-    float4 a[NI], b[NI], c[NI];
+    nt4 a[NI], b[NI], c[NI];
+    // NT (off by default, see the launch code): non-temporal loads for the once-read coordinate stream
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      a[i] = x4[3 * gi[i]];
-      b[i] = x4[3 * gi[i] + 1];
-      c[i] = x4[3 * gi[i] + 2];
+      a[i] = NT ? __builtin_nontemporal_load(x4 + 3 * gi[i]) : x4[3 * gi[i]];
+      b[i] = NT ? __builtin_nontemporal_load(x4 + 3 * gi[i] + 1) : x4[3 * gi[i] + 1];
+      c[i] = NT ? __builtin_nontemporal_load(x4 + 3 * gi[i] + 2) : x4[3 * gi[i] + 2];
     }
     float s[12];
 #pragma unroll
@@ -521,10 +524,20 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
           hipLaunchKernelGGL(kernel, dim3((unsigned)groups), dim3(64 * kGroup), ldsc, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled,
                              slot_xyz);
         };
-        if (ni == 1) go(k1_large_slice_kernel<1>);
-        else if (ni == 2) go(k1_large_slice_kernel<2>);
-        else if (ni == 3) go(k1_large_slice_kernel<3>);
-        else go(k1_large_slice_kernel<4>);
+        // non-temporal coordinate loads, a developer switch: measured 1592 us against 1065 us (0.48 vs 0.72 of 8 TB/s) for
+        // 100 000 frames of 5000 atoms (tools/bench_k1_c5.py) - the plain loads stay the default
+        static const bool nt = getenv("CVF_K1_NT") != nullptr && atoi(getenv("CVF_K1_NT")) != 0;
+        if (nt) {
+          if (ni == 1) go(k1_large_slice_kernel<1, true>);
+          else if (ni == 2) go(k1_large_slice_kernel<2, true>);
+          else if (ni == 3) go(k1_large_slice_kernel<3, true>);
+          else go(k1_large_slice_kernel<4, true>);
+        } else {
+          if (ni == 1) go(k1_large_slice_kernel<1, false>);
+          else if (ni == 2) go(k1_large_slice_kernel<2, false>);
+          else if (ni == 3) go(k1_large_slice_kernel<3, false>);
+          else go(k1_large_slice_kernel<4, false>);
+        }
         return cvf_check_launch("k1_large_slice_kernel");
       }
       if (vec4)
