@@ -47,7 +47,7 @@ FLOP_METRIC = 2 * K_NETS * 33 * N_ATOMS          # three passes of q = J A J^T g
 FLOP_BWD = 2 * K_NETS * (P_W + 800 + 2 * P_W)  # tangent chain, zbar chain, outer products (h and the d chain come from the forward kernel)
 FLOP_OF_CALL = {"cvf_ef16_front": FLOP_FWD + FLOP_METRIC + FLOP_K1, "cvf_ef16_backward": FLOP_BWD, "cvf_ef_backward": FLOP_BWD, "cvf_ef_mlp_fwd": FLOP_FWD, "cvf_ef_fwd_metric_stats": FLOP_FWD + FLOP_METRIC,
                 "cvf_ef_align_fwd_metric_stats": FLOP_FWD + FLOP_METRIC + FLOP_K1}
-KERNEL_OF_CALL = {"cvf_ef16_front": "ef16_front_kernel", "cvf_ef16_backward": "ef_bwd_mfma_kernel", "cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
+KERNEL_OF_CALL = {"cvf_ef16_front": "ef16_front_kernel", "cvf_ef16_backward": "ef16_back_kernel", "cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
                   "cvf_ef_fwd_metric_stats": "ef_fwd_metric_kernel", "cvf_ef_align_fwd_metric_stats": "ef_fwd_metric_kernel",
                   "cvf_align_feature_fwd": "k1_align_quad_kernel", "cvf_align_feature_fwd@1M": "k1_stream_kernel",
                   "cvf_align_feature_fwd@c5": "k1_large_slice_kernel"}
@@ -309,15 +309,16 @@ def main():
         return
     prof = PROFILE_TAG
 
-    def pmc_traffic(call):
-        """HBM bytes per launch of the kernel behind a C-ABI call, from the committed rocprofv3 PMC passes."""
+    def pmc_traffic(call, scale=1):
+        """HBM bytes per launch of the kernel behind a C-ABI call, from the committed rocprofv3 PMC passes (entries that name
+        their frames_per_launch are scaled to `scale` frames)."""
         kernel = KERNEL_OF_CALL.get(call)
         path = os.path.join(ROOT, "profiles", f"{prof}_pmc_traffic.json")
         if kernel is None or not os.path.exists(path) or B != 20000 or world != 1:
             return None
         with open(path) as fh:
             c = json.load(fh)["kernels"].get(kernel)
-        return None if c is None else (2.0 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024.0
+        return None if c is None else (2.0 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024.0 * scale / c.get("frames_per_launch", scale)
 
     if dom in FLOP_OF_CALL:
         flop = FLOP_OF_CALL[dom] * B
@@ -426,7 +427,7 @@ def align_feature_roofline(task, ref, dev, pmc_traffic):
     head = res["config5_100k"]["features_only"]
     return {"kernel": "cvf_align_feature_fwd", "bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": head["frac"], "avg_launch_us": head["avg_launch_us"], "bytes_per_frame": bpf5, "frames_per_launch": n5,
-            "traffic": pmc_traffic("cvf_align_feature_fwd@c5"),
+            "traffic": pmc_traffic("cvf_align_feature_fwd@c5", n5),
             "workload": "BASELINE config 5 shape (5000 atoms, d_r=384), 100 000 frames resident = 6.2 GB per launch, out of cache",
             "cases": res}
 

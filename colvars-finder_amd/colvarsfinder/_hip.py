@@ -82,6 +82,8 @@ _SIGNATURES = {
     "cvf_ef16_supported": (C.c_int, [C.POINTER(MLPDesc), C.POINTER(PPDesc)]),
     "cvf_ef16_scratch_doubles": (C.c_int64, [C.c_int64, C.c_int]),
     "cvf_ef16_saved_floats": (C.c_int64, [C.POINTER(MLPDesc), C.c_int64]),
+    "cvf_ef16_rows": (C.c_int64, [C.c_int64]),
+    "cvf_ef16_finish": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef16_front": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PPDesc), C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(EFCfg), C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

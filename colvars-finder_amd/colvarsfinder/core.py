@@ -144,6 +144,9 @@ class _FlatParams:
     def __init__(self, model, device):
         model.to(device=device, dtype=torch.float32)
         self.model = model
+        self._views = None
+        if isinstance(model, EigenFunctions) and self._init_padded(model, device):
+            return
         lay = mlp_layout(model)
         self.n = lay["n_params"]
         self.theta = torch.empty(self.n, device=device, dtype=torch.float32)
@@ -172,8 +175,61 @@ class _FlatParams:
         self.packed = torch.zeros(n_pack, device=device, dtype=torch.float32) if n_pack > 0 else None
         self.repack()
 
+    def _init_padded(self, model, device):
+        """EigenFunctions whose hidden widths are NOT one of the kernels' widths (csrc/ef_mfma.hip: d0 -> H -> .. -> H -> 1 with
+        H in _hip.EF_HIDDEN_WIDTHS): lay the nets out with every hidden layer padded to the next kernel width H.  The padding
+        rows / columns hold zeros, and stay zero: a padded unit's pre-activation is 0, tanh(0) = 0, its outgoing weights are 0,
+        so every gradient entry that touches the padding is exactly 0 and Adam / SGD leave a 0 with zero moments where it is.
+        The module's parameters alias the unpadded sub-blocks (strided views), so state_dict(), load_state_dict(), forward and
+        the per-CV text export see the nets the user built.  Returns False when no padding is needed or possible."""
+        from .nn import _chain_layers
+        chains = [_chain_layers(net) for net in model.eigen_funcs]
+        L = len(chains[0])
+        dims = [chains[0][0][0].in_features] + [lin.out_features for lin, _ in chains[0]]
+        hidden = dims[1:-1]
+        if not (2 <= L <= 4) or dims[-1] != 1 or not hidden or max(hidden) > max(_hip.EF_HIDDEN_WIDTHS):
+            return False
+        for c in chains:
+            if [c[0][0].in_features] + [lin.out_features for lin, _ in c] != dims or [a for _, a in c] != [True] * (L - 1) + [False]:
+                return False
+        H = min(w for w in _hip.EF_HIDDEN_WIDTHS if w >= max(hidden) and (w < 24 or L - 1 >= 2))
+        if all(h == H for h in hidden):
+            return False                      # already a kernel shape: plain layout
+        pdims = [dims[0]] + [H] * (L - 1) + [1]
+        per_net = sum(pdims[l + 1] * pdims[l] + pdims[l + 1] for l in range(L))
+        assert len(chains) <= _hip.MAX_NETS, f"between 1 and {_hip.MAX_NETS} nets are supported, got {len(chains)}"
+        self.n = per_net * len(chains)
+        self.theta = torch.zeros(self.n, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.n, device=device, dtype=torch.float32)
+        d = _hip.MLPDesc()
+        d.n_nets, d.n_layers, d.n_params = len(chains), L, self.n
+        for l in range(L):
+            d.dims[l], d.dims[l + 1], d.act[l] = pdims[l], pdims[l + 1], int(l < L - 1)
+        self._views, pos = [], 0
+        for i, chain in enumerate(chains):
+            for l, (lin, _) in enumerate(chain):
+                fo, fi = pdims[l + 1], pdims[l]
+                d.w_off[i][l], d.b_off[i][l] = pos, pos + fo * fi
+                for prm, off, shape in ((lin.weight, pos, (fo, fi)), (lin.bias, pos + fo * fi, (fo,))):
+                    sl = tuple(slice(0, n_) for n_ in prm.shape)
+                    tv = self.theta[off:off + int(np.prod(shape))].view(shape)[sl]
+                    gv = self.grad[off:off + int(np.prod(shape))].view(shape)[sl]
+                    tv.copy_(prm.data)
+                    prm.data = tv                       # the module aliases its sub-block of the padded layer
+                    self._views.append((prm, gv))
+                pos += fo * fi + fo
+        # (grad_views() must follow model.parameters() order for the optimizer's param_groups; both walk nets, then layers)
+        assert [id(p_) for p_, _ in self._views] == [id(p_) for p_ in model.parameters()]
+        self.desc = d
+        n_pack = _hip.lib().cvf_ef_pack_floats(d)
+        self.packed = torch.zeros(n_pack, device=device, dtype=torch.float32) if n_pack > 0 else None
+        self.repack()
+        return True
+
     def grad_views(self):
         """[(module parameter, its slice of the flat gradient)] in flat order."""
+        if self._views is not None:
+            return list(self._views)
         out, pos = [], 0
         for p in self.model.parameters():
             out.append((p, self.grad[pos:pos + p.numel()].view(p.shape)))
@@ -459,9 +515,9 @@ class EigenFunctionTask(TrainingTask):
             d = self._flat.desc
             raise NotImplementedError(
                 "EigenFunctionTask on MI355X: no kernel instance for nets with layer widths "
-                f"{[d.dims[i] for i in range(d.n_layers + 1)]}. Supported: d0 -> H -> .. -> H -> 1 with ONE hidden width "
-                f"H in {_hip.EF_HIDDEN_WIDTHS}, 1 to 3 hidden layers (H = 24, 32: 2 or 3), Tanh between layers, k <= "
-                f"{_hip.MAX_NETS} (csrc/ef_mfma.hip: ef_shape / ef_dispatch).")
+                f"{[d.dims[i] for i in range(d.n_layers + 1)]}. Supported: 1 to 3 hidden layers of at most "
+                f"{max(_hip.EF_HIDDEN_WIDTHS)} units each (kernel widths {_hip.EF_HIDDEN_WIDTHS}; other widths are zero-padded to "
+                f"the next one), scalar output, Tanh between layers, k <= {_hip.MAX_NETS} (csrc/ef_mfma.hip: ef_shape / ef_dispatch).")
 
         # The frames stay resident in HBM (core.py:343-344 keeps CPU copies and moves every batch, core.py:500).  One process:
         # the whole trajectory.  Data-parallel job (one process per GPU): NOT here - train() uploads only the rows of this
@@ -566,9 +622,12 @@ class EigenFunctionTask(TrainingTask):
         if self._use_ef16() and not aligned:
             # coordinates -> features, y, hidden activations, q = J A J^T g, E and the batch sums in one launch, 16 frames per
             # wave (+ the short launch that adds the units' rows and evaluates the loss tail)
+            rows = lib.cvf_ef16_rows(B) > 0   # the units' rows of batch sums are added by a second, short launch
             self._call("cvf_ef16_front", lib.cvf_ef16_front, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), self._pp, P(X), B,
-                       P(self._diag_coeff), P(ws.y), P(ws.saved), P(ws.q), P(ws.e), self._cfg, P(w), P(ws.scratch), P(ws.stats),
-                       lv, cf, s)
+                       P(self._diag_coeff), P(ws.y), P(ws.saved), P(ws.q), P(ws.e), self._cfg, P(w), P(ws.scratch),
+                       None if rows else P(ws.stats), lv, cf, s)
+            if rows:
+                self._call("cvf_ef16_finish", lib.cvf_ef16_finish, self._cfg, B, P(ws.scratch), P(ws.stats), lv, cf, s)
             if not single:
                 _dist.allreduce_sum_(ws.stats)                                           # collective #1
                 self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_vec), P(ws.coef), s)
@@ -706,10 +765,8 @@ class EigenFunctionTask(TrainingTask):
         """Parameter gradient of the last :meth:`loss_func` call -> ``p.grad`` of the model's parameters."""
         ws, w, w_lag = self._last
         self._backward(ws, w, w_lag)
-        pos = 0
-        for p in self.model.parameters():
-            p.grad = self._flat.grad[pos:pos + p.numel()].view(p.shape).clone()
-            pos += p.numel()
+        for p, gv in self._flat.grad_views():
+            p.grad = gv.clone()
 
     # ---------------------------------------------------------------- training loop
     def train(self):

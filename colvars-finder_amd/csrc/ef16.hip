@@ -846,6 +846,19 @@ extern "C" int64_t cvf_ef16_scratch_doubles(int64_t B, int k) {
   return rows * cvf_ef_nstats(k, 0) + cvf_ef_stats_scratch_doubles(k, 0);
 }
 
+// units whose rows of batch sums cvf_ef16_front leaves in `scratch` for cvf_ef16_finish (0: the batch is too large for one
+// finishing launch - give cvf_ef16_front `stats` and it runs the two-stage reduction itself)
+extern "C" int64_t cvf_ef16_rows(int64_t B) {
+  const int64_t units = 4 * cvf_ntiles(B);
+  return units <= kMaxRows16 ? units : 0;
+}
+extern "C" int cvf_ef16_finish(const cvf_ef_cfg* cfg, int64_t B, const double* scratch, double* stats, double* loss_vec, double* coef,
+                               void* stream) {
+  CVF_REQUIRE(cfg && scratch && stats && cvf_ef16_rows(B) > 0, "cvf_ef16_finish: bad argument");
+  CVF_REQUIRE(loss_vec == nullptr || coef != nullptr, "cvf_ef16_finish: loss_vec without coef");
+  return cvf_ef_stats_finish_impl(cfg, (int)cvf_ef16_rows(B), 1, scratch, stats, loss_vec, coef, (hipStream_t)stream);
+}
+
 extern "C" int64_t cvf_ef16_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles) {
   int H, NH;
   if (!mlp || !ef16_shape(mlp, &H, &NH)) return 0;
@@ -857,8 +870,9 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
                               float* q_tiled, float* e_tiled, const cvf_ef_cfg* cfg, const float* w, double* scratch, double* stats,
                               double* loss_vec, double* coef, void* stream) {
   CVF_REQUIRE(cvf_ef16_supported(mlp, pp), "cvf_ef16_front: shape not covered (cvf_ef16_supported() == 0)");
-  CVF_REQUIRE(theta && packed && feat_tiled && x && a && y_tiled && saved && q_tiled && e_tiled && cfg && w && scratch && stats && B > 0,
+  CVF_REQUIRE(theta && packed && feat_tiled && x && a && y_tiled && saved && q_tiled && e_tiled && cfg && w && scratch && B > 0,
               "cvf_ef16_front: bad argument");
+  CVF_REQUIRE(stats != nullptr || cvf_ef16_rows(B) > 0, "cvf_ef16_front: stats == NULL (rows left for cvf_ef16_finish) needs cvf_ef16_rows(B) > 0");
   CVF_REQUIRE(cfg->k == mlp->n_nets && cfg->lag_idx == 0, "cvf_ef16_front: generator mode only, cfg.k must equal the number of nets");
   CVF_REQUIRE(loss_vec == nullptr || coef != nullptr, "cvf_ef16_front: loss_vec without coef");
   int H, NH;
@@ -881,7 +895,7 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
     else go(ef16_front_kernel<kH, kNH, 6>);
   });
   int rc = cvf_check_launch("ef16_front_kernel");
-  if (rc) return rc;
+  if (rc || stats == nullptr) return rc;   // stats == NULL: the caller adds the units' rows itself (cvf_ef16_finish)
   if (rows) return cvf_ef_stats_finish_impl(cfg, (int)units, 1, scratch, stats, loss_vec, coef, (hipStream_t)stream);
   return cvf_ef_stats(cfg, B, w, y_tiled, e_tiled, nullptr, nullptr, scratch, stats, loss_vec, coef, stream);
 }

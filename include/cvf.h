@@ -213,6 +213,12 @@ int cvf_ef_align_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, c
 int cvf_ef16_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp);
 int64_t cvf_ef16_scratch_doubles(int64_t B, int k);
 int64_t cvf_ef16_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles);
+/* With stats == NULL cvf_ef16_front stops after leaving cvf_ef16_rows(B) (> 0 required) rows of per-unit batch sums in `scratch`;
+ * cvf_ef16_finish adds them in a fixed order (and evaluates cvf_ef_loss when loss_vec != NULL).  Two calls = two launches that
+ * can be timed apart; one call with stats != NULL does both. */
+int64_t cvf_ef16_rows(int64_t B);
+int cvf_ef16_finish(const cvf_ef_cfg* cfg, int64_t B, const double* scratch, double* stats, double* loss_vec, double* coef,
+                    void* stream);
 int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled, const cvf_pp_desc* pp,
                    const float* x, int64_t B, const float* a, float* y_tiled, float* saved, float* q_tiled, float* e_tiled,
                    const cvf_ef_cfg* cfg, const float* w, double* scratch, double* stats, double* loss_vec, double* coef,

@@ -217,7 +217,7 @@ def test_restart_from_model_file_and_optimizer_state(dev, tmp_path):
 def test_unsupported_net_shape_is_rejected_at_construction(dev, tmp_path):
     from colvarsfinder import core, nn
     traj, w, ref = make_molecule_traj(10, 100, seed=1)
-    for dims in ([30, 64, 64, 1], [30, 20, 10, 1]):
+    for dims in ([30, 64, 64, 1], [30, 20, 20, 20, 20, 1]):
         model = nn.EigenFunctions(dims, 2)
         with pytest.raises(NotImplementedError, match="no kernel instance"):
             core.EigenFunctionTask(Traj(traj, w, 1.0), _position_layer(10, ref, dev), model, str(tmp_path), 10.0, [1.0, 0.5], k=2,
@@ -280,3 +280,54 @@ def test_molann_style_layer_runs_on_the_gpu_vs_oracle(dev):
         torch.tensor(traj, dtype=torch.float64)).numpy()
     assert got.shape == want.shape == (500, 34)
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6 * np.abs(want).max())
+
+
+def test_nonuniform_hidden_widths_are_padded_and_match_the_oracle(dev, tmp_path):
+    """The reference takes any layer_dims (nn.py:29-59); the kernels are instantiated for one hidden width per net.  Nets with
+    other / mixed hidden widths (here [30, 20, 10, 1]) are laid out zero-padded to the next kernel width: loss, eigenvalues
+    and every parameter gradient must equal the fp64 oracle's on the UNPADDED nets, the padding must stay exactly zero
+    through training, and state_dict() must keep the shapes the user built."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    from oracle.pp import AlignFeature
+    n_atoms, B, k, dims = 10, 300, 2, [30, 20, 10, 1]
+    traj, w, ref = make_molecule_traj(n_atoms, B, seed=321)
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(9))
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    a = torch.tensor(diag_coeff_for(n_atoms, 2), dtype=torch.float32)
+    task = core.EigenFunctionTask(Traj(traj, w, 1.0), _position_layer(n_atoms, ref, dev), model, str(tmp_path), 12.0, [1.0, 0.5],
+                                  diag_coeff=a, beta=1.0, lag_tau=0, learning_rate=2e-3, k=k, batch_size=100, num_epochs=3,
+                                  device=dev, verbose=False, save_model_every_step=0)
+    assert task._flat._views is not None and task._flat.desc.dims[2] == 20          # padded 10 -> 20
+    assert {n: tuple(p.shape) for n, p in model.state_dict().items()} == {n: tuple(p.shape) for n, p in sd0.items()}
+    loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+    feats = [("position", tuple(range(n_atoms)))]
+    X = torch.tensor(traj, dtype=torch.float64, requires_grad=True)
+    lo, eo, no, po, co = losses.ef_loss(sd, k, AlignFeature(list(range(n_atoms)), ref, feats, False), X, torch.tensor(w), alpha=12.0,
+                                        eig_w=[1.0, 0.5], diag_coeff=a.double(), beta=1.0)
+    lo.backward()
+    torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=2e-5)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=2e-5)
+    assert list(cvec) == list(co)
+    want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=4e-4, atol=4e-4 * np.abs(want).max())
+    # training keeps the padding at exactly zero
+    np.random.seed(2)
+    task.train()
+    real = torch.zeros_like(task._flat.theta, dtype=torch.bool)
+    for p, _ in task._flat.grad_views():
+        pass
+    mask = torch.ones_like(task._flat.theta)
+    saved = {n: p.detach().clone() for n, p in model.named_parameters()}
+    for p in model.parameters():
+        p.data.zero_()                                  # zero the real entries through the views ...
+    assert float(task._flat.theta.abs().max()) == 0.0   # ... and nothing is left: the padding never moved
+    for n, p in model.named_parameters():
+        p.data.copy_(saved[n])
+    assert np.isfinite(np.stack([e[0].numpy() for e in task.loss_list])).all()

@@ -144,6 +144,35 @@ void run_copy(const f4* x, f4* y, size_t n_vec, int blocks, const char* tag) {
          2.0 * n_vec * 16.0 * reps / (ms * 1e-3) * 1e-9);
 }
 
+// the plainest copy there is: every thread moves NV float4, one chunk per block (no persistent loop) - the shape behind
+// the 6.29 TB/s "float4 copy" of MI355X_MICROARCH.md, to reconcile with the persistent-grid figures above
+template <int NV, int THREADS>
+__global__ __launch_bounds__(THREADS) void copy_once_kernel(const f4* __restrict__ x, f4* __restrict__ y, size_t n_vec) {
+  const size_t base = (size_t)blockIdx.x * THREADS * NV + threadIdx.x;
+  f4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = base + (size_t)THREADS * i < n_vec ? x[base + (size_t)THREADS * i] : f4{0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (base + (size_t)THREADS * i < n_vec) y[base + (size_t)THREADS * i] = v[i];
+}
+template <int NV, int THREADS>
+void run_copy_once(const f4* x, f4* y, size_t n_vec) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const unsigned blocks = (unsigned)((n_vec + (size_t)THREADS * NV - 1) / ((size_t)THREADS * NV));
+  for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((copy_once_kernel<NV, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, x, y, n_vec);
+  (void)hipEventRecord(e0, 0);
+  const int reps = 10;
+  for (int it = 0; it < reps; ++it) hipLaunchKernelGGL((copy_once_kernel<NV, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, x, y, n_vec);
+  (void)hipEventRecord(e1, 0);
+  (void)hipDeviceSynchronize();
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("copy one chunk per block       %5zu MB threads=%4d float4/thread=%2d blocks=%8u  %7.0f GB/s (read + write)\n", n_vec * 16 >> 20,
+         THREADS, NV, blocks, 2.0 * n_vec * 16.0 * reps / (ms * 1e-3) * 1e-9);
+}
+
 template <int NLOAD, bool NT>
 void run(const f4* x, size_t n_vec, float* out, int blocks, const char* tag) {
   hipEvent_t e0, e1;
@@ -177,6 +206,11 @@ int main() {
       run_copy<8, false, true>(x, y, nv, 256 * 8, "nt store");
       run_copy<8, true, true>(x, y, nv, 256 * 8, "nt load+store");
       run_copy<16, true, true>(x, y, nv, 256 * 8, "nt load+store");
+      run_copy_once<1, 256>(x, y, nv);
+      run_copy_once<2, 256>(x, y, nv);
+      run_copy_once<4, 256>(x, y, nv);
+      run_copy_once<1, 1024>(x, y, nv);
+      run_copy_once<4, 1024>(x, y, nv);
     }
     (void)hipFree(y);
     if (getenv("COPY_ONLY")) return 0;
