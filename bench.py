@@ -135,31 +135,46 @@ def note(msg):
 
 
 def run_steps(task, X, Wt, B, steps, warmup, tag, world, dev, max_batches=8):
-    """W untimed + EXACTLY K timed train steps of the product's own step path (EigenFunctionTask._graph_step: one hipGraph
-    replay per static batch) on this rank's resident rows, B frames per rank per step; the timed region is bracketed by a
-    barrier + device synchronisation on both sides.  Returns (max-over-ranks seconds, last loss vector)."""
+    """W untimed + EXACTLY K timed train steps of the product's own step path on this rank's resident rows, B frames per rank
+    per step.  As EigenFunctionTask.train() replays one hipGraph per EPOCH (all its static batches), the steps run in chunks of
+    C = the number of distinct resident batches (<= max_batches) through task._graph_call - one graph replay per chunk - and the
+    remainder K mod C as single-step replays.  The timed region is bracketed by a barrier + device synchronisation on both
+    sides.  Returns (max-over-ranks seconds, last loss vector, single-step function)."""
     n_batches = max(1, min(X.shape[0] // B, max_batches))
     log = torch.zeros(n_batches, 3 + 2 * task.k, device=dev, dtype=torch.float64)
 
+    def one(b):
+        s = b * B
+        return task.train_step(X[s:s + B], Wt[s:s + B], out=log[b])
+
     def step(i):
         b = i % n_batches
-        s = b * B
-        task._graph_step((tag, b), lambda: task.train_step(X[s:s + B], Wt[s:s + B]), log[b])
+        task._graph_step((tag, b), lambda o: one(b), log[b], takes_out=True)
         return log[b]
+
+    def chunk():
+        task._graph_call((tag, "chunk"), lambda: [one(b) for b in range(n_batches)])
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(max(warmup, n_batches if task._use_graphs else 0)):   # (every batch's graph is captured before the clock starts)
+    n_chunks, rest = divmod(steps, n_batches)
+    for i in range(max(1, (warmup + n_batches - 1) // n_batches) + 1):   # (captures the chunk graph before the clock starts)
+        chunk()
+    for i in range(rest if task._use_graphs else 0):                       # (and the single-step graphs the remainder uses)
+        step(i)
         step(i)
     barrier()
     t0 = time.perf_counter()
-    for i in range(steps):
-        lv = step(warmup + i)
+    for _ in range(n_chunks):
+        chunk()
+    for i in range(rest):
+        step(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    lv = log[(rest - 1) % n_batches if rest else n_batches - 1]
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -353,6 +368,7 @@ def main():
         "kernel_timing": ("HIP events around each C-ABI call over a second, eager pass of the same steps (the timed region "
                           "replays one hipGraph per step)") if graphs else "HIP events around each C-ABI call (eager pass)",
         "hip_graph": bool(graphs),
+        "graph_granularity": "one hipGraph replay per chunk of the resident static batches (as train() replays one per epoch)",
         "traffic_note": (f"roofline.traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from profiles/{prof}_pmc_traffic.json "
                          "(separate rocprofv3 --pmc passes of this command; gfx950 FETCH_SIZE halving corrected)"),
         "final_loss": final_loss,
@@ -457,7 +473,7 @@ def main_c5(args):
 
     def step(i):
         b = i % n_batches
-        task._graph_step(("bench", b), lambda: task.train_step(X[b * B:(b + 1) * B], Wt[b * B:(b + 1) * B]), log[b])
+        task._graph_step(("bench", b), lambda o: task.train_step(X[b * B:(b + 1) * B], Wt[b * B:(b + 1) * B], out=o), log[b], takes_out=True)
         return log[b]
 
     for i in range(args.warmup):

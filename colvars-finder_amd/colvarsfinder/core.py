@@ -608,9 +608,11 @@ class EigenFunctionTask(TrainingTask):
             self._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self._pp, P(X_lag), B, P(feat_lag), None, None,
                        P(ws._k1_scratch[slot]), _hip.stream())
 
-    def _forward(self, X, w, X_lag=None, w_lag=None, slot=0, aligned=False):
+    def _forward(self, X, w, X_lag=None, w_lag=None, slot=0, aligned=False, out=None):
         """Everything up to the loss for one (local) batch; leaves loss_vec / coef on the device.
-        ``aligned``: buffer ``slot`` already holds this batch's features (a previous step prefetched them)."""
+        ``aligned``: buffer ``slot`` already holds this batch's features (a previous step prefetched them).
+        ``out``: fp64 device row of length 3 + 2k that receives the loss vector instead of ``ws.loss_vec`` (the training
+        loops pass the step's slot of the epoch log: no copy kernel per step)."""
         lib, s, P = _hip.lib(), _hip.stream(), _hip.ptr
         B = X.shape[0]
         ws = self._workspace(B)
@@ -618,7 +620,9 @@ class EigenFunctionTask(TrainingTask):
         fl, k, d_r = self._flat, self.k, self._pp.d_r
         lag = self.lag_idx
         single = not _dist.collectives()   # no cross-rank reduction: the loss tail runs inside the stats launch
-        lv, cf = (P(ws.loss_vec), P(ws.coef)) if single else (None, None)
+        ws.loss_out = ws.loss_vec if out is None else out
+        assert ws.loss_out.is_contiguous() and ws.loss_out.dtype == torch.float64 and ws.loss_out.numel() == 3 + 2 * k
+        lv, cf = (P(ws.loss_out), P(ws.coef)) if single else (None, None)
         if self._use_ef16() and not aligned:
             # coordinates -> features, y, hidden activations, q = J A J^T g, E and the batch sums in one launch, 16 frames per
             # wave (+ the short launch that adds the units' rows and evaluates the loss tail)
@@ -630,7 +634,7 @@ class EigenFunctionTask(TrainingTask):
                 self._call("cvf_ef16_finish", lib.cvf_ef16_finish, self._cfg, B, P(ws.scratch), P(ws.stats), lv, cf, s)
             if not single:
                 _dist.allreduce_sum_(ws.stats)                                           # collective #1
-                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_vec), P(ws.coef), s)
+                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
             return ws
         if not ws.k1_scratch_checked:
             ws._k1_scratch = [_hip.align_scratch(self._pp, B, self.device) for _ in range(2)]
@@ -657,7 +661,7 @@ class EigenFunctionTask(TrainingTask):
                            lv, cf, s)
             if not single:
                 _dist.allreduce_sum_(ws.stats)                                           # collective #1
-                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_vec), P(ws.coef), s)
+                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
             return ws
         if with_tr:
             self._call("cvf_ef_align_fwd", lib.cvf_ef_align_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), self._pp, P(X),
@@ -675,7 +679,7 @@ class EigenFunctionTask(TrainingTask):
                        P(ws.scratch), P(ws.stats), lv, cf, s)
         if not single:
             _dist.allreduce_sum_(ws.stats)                                               # collective #1
-            self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_vec), P(ws.coef), s)
+            self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
         return ws
 
     def _backward(self, ws, w, w_lag=None, advance=False, fuse_adam=False):
@@ -697,12 +701,12 @@ class EigenFunctionTask(TrainingTask):
             _dist.allreduce_sum_(fl.grad)                                                # collective #2
         return adam is not None
 
-    def train_step(self, X, w, X_lag=None, w_lag=None, slot=0, aligned=False, prefetch=None):
+    def train_step(self, X, w, X_lag=None, w_lag=None, slot=0, aligned=False, prefetch=None, out=None):
         """One optimisation step on device tensors; returns the device vector
         ``[loss, npl, pen, eig_1..k, cvec_1..k]`` (fp64) without synchronising the host.
         ``prefetch = (X_next, X_lag_next)``: align that batch into the other feature buffer on a side stream while this
         step's backward kernel runs; the next call then passes ``slot ^ 1, aligned=True``."""
-        ws = self._forward(X, w, X_lag, w_lag, slot, aligned)
+        ws = self._forward(X, w, X_lag, w_lag, slot, aligned, out=out)
         if prefetch is not None:   # beside the backward kernel, which leaves SIMD slots and LDS free at these sizes
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
@@ -712,24 +716,30 @@ class EigenFunctionTask(TrainingTask):
             self.optimizer.step(advance=False)
         if prefetch is not None:
             torch.cuda.current_stream().wait_stream(self._side)
-        return ws.loss_vec
+        return ws.loss_out
 
     # -- hipGraph replay of a whole step: batches are static (shuffle=False, core.py:472-481), so every
     #    (batch, kind) pair is captured once and replayed in all later epochs: one host call per step
-    def _graph_step(self, key, fn, out_slot):
+    def _graph_step(self, key, fn, out_slot, takes_out=False):
         """Run ``fn()`` (a step that returns the device loss vector) and copy its result into ``out_slot``;
         captured into a hipGraph on first use when graphs are enabled."""
+        def run():
+            # (steps that take the slot write their loss vector there themselves; others return a tensor to copy)
+            got = fn(out_slot) if takes_out else fn()
+            if got is not out_slot and got.data_ptr() != out_slot.data_ptr():
+                out_slot.copy_(got)
+
         if not self._use_graphs:
-            out_slot.copy_(fn())
+            run()
             return
         g = self._graphs.get(key)
         if g is None:
-            out_slot.copy_(fn())                      # eager warm-up: allocates the workspace of this batch size
+            run()                                     # eager warm-up: allocates the workspace of this batch size
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(g):
-                    out_slot.copy_(fn())
+                    run()
             except Exception as exc:                   # e.g. a collective that cannot be captured on this stack
                 if not _dist.collectives():
                     raise
@@ -742,6 +752,37 @@ class EigenFunctionTask(TrainingTask):
             self._graphs[key] = g
             return                                     # the warm-up call already did this step's work once... see note
         self.optimizer.sync_lr()                       # the captured kernels read the learning rate from a device scalar
+        g.replay()
+
+    def _graph_call(self, key, body):
+        """Run ``body()`` - any sequence of steps on static batches that writes its results into fixed device buffers, e.g.
+        a whole epoch - through ONE hipGraph: captured on first use (after an eager run that allocates the workspaces),
+        replayed afterwards.  One replay per epoch instead of one per step: the ~9 us the GPU idles between two graph
+        launches (rocprofv3 kernel trace of bench.py) is paid once per epoch."""
+        if not self._use_graphs:
+            body()
+            return
+        g = self._graphs.get(key)
+        if g is None:
+            body()
+            torch.cuda.current_stream().synchronize()
+            self.optimizer.sync_lr()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    body()
+            except Exception as exc:                   # e.g. a collective that cannot be captured on this stack
+                if not _dist.collectives():
+                    raise
+                self._use_graphs = False
+                self._graphs.clear()
+                torch.cuda.synchronize()
+                print(f"[colvarsfinder] hipGraph capture of the data-parallel epoch failed ({type(exc).__name__}: {exc}); "
+                      "continuing with eager launches", flush=True)
+                return
+            self._graphs[key] = g
+            return                                     # (the eager run above already did this call's work)
+        self.optimizer.sync_lr()
         g.replay()
 
     def _dev(self, t, dtype=torch.float32):
@@ -843,20 +884,21 @@ class EigenFunctionTask(TrainingTask):
 
         elog = _AsyncEpochLog(log_tr, log_te, len(tr_batches), len(te_batches), on_epoch)
 
-        for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
-            self.model.train()
+        def epoch_body():
             for it, (a, b) in enumerate(tr_batches):
                 X, w, Xl, wl = sl(Xtr, a, b)
                 nxt = None
                 if self._pipeline and it + 1 < len(tr_batches):
                     Xn, _, Xln, _ = sl(Xtr, *tr_batches[it + 1])
                     nxt = (Xn, Xln)
-                self._graph_step(("train", it), lambda: self.train_step(X, w, Xl, wl, slot=it % 2,
-                                                                          aligned=self._pipeline and it > 0, prefetch=nxt),
-                                 log_tr[it])
+                self.train_step(X, w, Xl, wl, slot=it % 2, aligned=self._pipeline and it > 0, prefetch=nxt, out=log_tr[it])
             for it, (a, b) in enumerate(te_batches):              # core.py:535-551 (same loss, no update)
                 X, w, Xl, wl = sl(Xte, a, b)
-                self._graph_step(("test", it), lambda: self._forward(X, w, Xl, wl).loss_vec, log_te[it])
+                self._forward(X, w, Xl, wl, out=log_te[it])
+
+        for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
+            self.model.train()
+            self._graph_call(("epoch",), epoch_body)   # every step of the epoch (static batches): one hipGraph replay
             elog.push(epoch)        # (the host reads the epoch's numbers later; epochs that save or plot flush first)
             saving = self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1
             plotting = self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1

@@ -103,7 +103,7 @@ __global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats,
 // launch.  Stat i is summed by one wave: lane l adds rows l, l+64, ... (loads issued eight at a time), the 64 lane
 // sums are combined by the fixed-order DPP reduction -> bitwise reproducible for a given number of rows.
 template <int KT>
-__global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, int ns, int n_rows, int stat_major,
+__global__ __launch_bounds__(KT <= 5 ? 1024 : 512) void ef_stats_finish_kernel(cvf_ef_cfg cfg, int ns, int n_rows, int stat_major,
                                                                const double* __restrict__ partial,
                                                                double* __restrict__ stats, double* __restrict__ loss_vec,
                                                                double* __restrict__ coef) {
@@ -185,7 +185,8 @@ int cvf_ef_stats_finish(const cvf_ef_cfg* cfg, int n_rows, const double* partial
 int cvf_ef_stats_finish_impl(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
                              double* loss_vec, double* coef, hipStream_t s) {
   const int ns = cvf_ef_nstats(cfg->k, cfg->lag_idx);
-  const int waves = ns < 16 ? ns : 16;
+  const int wmax = cfg->k <= 5 ? 16 : 8;   // (k > 5: 512 threads at most - the register-resident loss tail wants up to 256 VGPRs at k = 8)
+  const int waves = ns < wmax ? ns : wmax;
   k_dispatch(cfg->k, [&](auto kc) {
     constexpr int K = decltype(kc)::value;
     hipLaunchKernelGGL((ef_stats_finish_kernel<K>), dim3(1), dim3(64 * waves), 0, s, *cfg, ns, n_rows, stat_major, partial, stats,
