@@ -63,7 +63,9 @@ __host__ __device__ inline Front16Lds front16_lds(int nc, int nal, int k) {
 // ------------------------------------------------------------------------------------------------------------------
 // front
 // ------------------------------------------------------------------------------------------------------------------
-template <int H, int NH, int NIT>
+// NIT = ceil(N / 4) exactly (atoms per lane in the four-lanes-per-frame passes): every iteration but the last is complete, so
+// only the last one carries the masks of the ragged end.  ALLAL: every feature atom is an align atom (n_align == n_rec).
+template <int H, int NH, int NIT, bool ALLAL>
 __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                              const float* __restrict__ packed, cvf_pp_desc pp,
                                                              const float* __restrict__ x, int64_t B,
@@ -316,13 +318,15 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     for (int it = 0; it < NIT; ++it) {
       int at = p + 4 * it;
       asm volatile("" : "+v"(at));   // (opaque: the atom's addresses are formed here, not hoisted and kept across the passes)
-      const int ac = at < N ? at : N - 1;
-      const float lv = at < N ? 1.0f : 0.0f;
+      const bool last = it == NIT - 1;           // (compile-time: the only iteration that can run past the last atom)
+      const int ac = (last && at >= N) ? N - 1 : at;
+      const float lv = (last && at >= N) ? 0.0f : 1.0f;
       // (a lane past the last atom works on a DUPLICATE of atom N - 1 - masked out of every sum, but carried through so that
       //  it computes and stores the same u and q as that atom's owner: no lane-divergent branch around the stores)
       gv[it] = v3(Ul[3 * ac], Ul[3 * ac + 1], Ul[3 * ac + 2]);
-      gsum = gsum + lv * gv[it];
-      outer_acc(Mo, centred(my, ac, c), lv * gv[it]);
+      const V3 gm = last ? lv * gv[it] : gv[it];
+      gsum = gsum + gm;
+      outer_acc(Mo, centred(my, ac, c), gm);
     }
     CVF_STAMP(27);
     gsum = v3(quad_sumf16(gsum.x), quad_sumf16(gsum.y), quad_sumf16(gsum.z));
@@ -359,23 +363,28 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     for (int it = 0; it < NIT; ++it) {
       int at = p + 4 * it;
       asm volatile("" : "+v"(at));   // (opaque: the atom's addresses are formed here, not hoisted and kept across the passes)
-      const int ac = at < N ? at : N - 1;
-      const float ma = ac < nal ? 1.0f : 0.0f;         // align atom: carries the rotation's and the centroid's derivative
-      const float lv = at < N ? 1.0f : 0.0f;           // alive (not a duplicate): counts in the sums
-      const float m = ma * lv;
-      const int ar_ = ac < nal ? ac : 0;
-      const V3 rf = v3(ma * refL[3 * ar_], ma * refL[3 * ar_ + 1], ma * refL[3 * ar_ + 2]);
-      f2 Gxy = f2{-ma * shift.x, -ma * shift.y};
-      float Gz = -ma * shift.z;
+      const bool last = it == NIT - 1;
+      const int ac = (last && at >= N) ? N - 1 : at;
+      const float lv = (last && at >= N) ? 0.0f : 1.0f;             // alive (not a duplicate): counts in the sums
+      const float ma = ALLAL ? 1.0f : (ac < nal ? 1.0f : 0.0f);      // align atom: carries the rotation's and the centroid's derivative
+      const int ar_ = ALLAL ? ac : (ac < nal ? ac : 0);
+      V3 rf = v3(refL[3 * ar_], refL[3 * ar_ + 1], refL[3 * ar_ + 2]);
+      if (!ALLAL) rf = ma * rf;
+      f2 Gxy = ALLAL ? f2{-shift.x, -shift.y} : f2{-ma * shift.x, -ma * shift.y};
+      float Gz = ALLAL ? -shift.z : -ma * shift.z;
       mat_times_acc(Rc, gv[it], Gxy, Gz);
       mat_times_acc(Zc, rf, Gxy, Gz);
       const f2 uxy = f2{aL[3 * ac], aL[3 * ac + 1]} * Gxy;
       const float uz = aL[3 * ac + 2] * Gz;
-      E2 = fma2(lv * uxy, Gxy, E2);
-      Ez = fmaf(lv * uz, Gz, Ez);
       gv[it] = v3(uxy.x, uxy.y, uz);
-      usum_xy += m * uxy; usum_z += m * uz;
-      outer_acc(dHo, v3(m * uxy.x, m * uxy.y, m * uz), rf);
+      const bool masked = last || !ALLAL;                            // (compile-time)
+      const float m = ma * lv;
+      const f2 uxm = masked ? m * uxy : uxy;
+      const float uzm = masked ? m * uz : uz;
+      E2 = fma2(last ? lv * uxy : uxy, Gxy, E2);
+      Ez = fmaf(last ? lv * uz : uz, Gz, Ez);
+      usum_xy += uxm; usum_z += uzm;
+      outer_acc(dHo, v3(uxm.x, uxm.y, uzm), rf);
     }
     CVF_STAMP(28);
     const float E = quad_sumf16((E2.x + E2.y) + Ez);
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     for (int it = 0; it < NIT; ++it) {
       int at = p + 4 * it;
       asm volatile("" : "+v"(at));   // (opaque: the atom's addresses are formed here, not hoisted and kept across the passes)
-      const int ac = at < N ? at : N - 1;
+      const int ac = (it == NIT - 1 && at >= N) ? N - 1 : at;
       f2 qxy = {0.0f, 0.0f};
       float qz = 0.0f;
       row_times_acc(Rr, gv[it] - ubar, qxy, qz);
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     for (int it = 0; it < NIT; ++it) {
       int at = p + 4 * it;
       asm volatile("" : "+v"(at));
-      const int ac = at < N ? at : N - 1;
+      const int ac = (it == NIT - 1 && at >= N) ? N - 1 : at;
       qt[(3 * ac) * CVF_TILE] = gv[it].x;
       qt[(3 * ac + 1) * CVF_TILE] = gv[it].y;
       qt[(3 * ac + 2) * CVF_TILE] = gv[it].z;
@@ -889,10 +898,20 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
       hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, *pp, x, B, a, w,
                          feat_tiled, y_tiled, saved, q_tiled, e_tiled, rows ? scratch : nullptr, ns);
     };
-    const int nit = (pp->n_rec + 3) / 4;   // atoms per lane in the four-lanes-per-frame passes
-    if (nit <= 2) go(ef16_front_kernel<kH, kNH, 2>);
-    else if (nit <= 4) go(ef16_front_kernel<kH, kNH, 4>);
-    else go(ef16_front_kernel<kH, kNH, 6>);
+    const int nit = (pp->n_rec + 3) / 4;   // atoms per lane in the four-lanes-per-frame passes (1..6: d_r <= 72)
+    const bool allal = pp->n_align == pp->n_rec;
+#define EF16_GO(NIT_)                                                  \
+    case NIT_:                                                          \
+      if (allal) go(ef16_front_kernel<kH, kNH, NIT_, true>);            \
+      else go(ef16_front_kernel<kH, kNH, NIT_, false>);                 \
+      break;
+    switch (nit) {
+      EF16_GO(1) EF16_GO(2) EF16_GO(3) EF16_GO(4) EF16_GO(5)
+      default:
+        if (allal) go(ef16_front_kernel<kH, kNH, 6, true>);
+        else go(ef16_front_kernel<kH, kNH, 6, false>);
+    }
+#undef EF16_GO
   });
   int rc = cvf_check_launch("ef16_front_kernel");
   if (rc || stats == nullptr) return rc;   // stats == NULL: the caller adds the units' rows itself (cvf_ef16_finish)

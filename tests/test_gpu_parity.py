@@ -692,6 +692,12 @@ def test_large_batch_paths_by_duplication(dev):
     assert c1 == c2
     np.testing.assert_allclose(v2, v1, rtol=2e-6)
     np.testing.assert_allclose(g2, g1, rtol=1e-4, atol=2e-6 * np.abs(g1).max())
+    # eight copies = 281 600 frames = 17 600 sixteen-frame units: past the 16 384 rows one finishing launch adds, the
+    # 16-frames-per-wave front kernel leaves y / E and the batch sums take the two-stage cvf_ef_stats reduction
+    v8, g8, c8 = run(torch.cat([X] * 8), torch.cat([W] * 8))
+    assert c1 == c8
+    np.testing.assert_allclose(v8, v1, rtol=2e-6)
+    np.testing.assert_allclose(g8, g1, rtol=1e-4, atol=2e-6 * np.abs(g1).max())
 
 
 def test_regae_three_regularisers_three_latents_vs_oracle(dev):
