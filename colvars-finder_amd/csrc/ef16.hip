@@ -100,7 +100,17 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
 
   CVF_STAMP(20);
   // ---- stage the unit's coordinates (16 x nc floats, one contiguous run), the tables and the weights
-  load_x_tile<6>(x, B, nc, unit, xt, tid, nthreads, kU);
+  if (stride == nc && (unit + 1) * kU <= B && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    // the unit as it lies in memory (3N = 2 mod 4: plain copy, 16 x 3N floats = a whole number of 16-byte pieces; at most two
+    // per thread here) - the general stager's index arithmetic (integer divisions by 3N) was a tenth of this kernel's
+    // vector instructions
+    const float4* src = reinterpret_cast<const float4*>(x + unit * (int64_t)(kU * nc));
+    float4* dst = reinterpret_cast<float4*>(xt);
+    const int n4 = (kU * nc) >> 2;
+    for (int v = tid; v < n4; v += nthreads) dst[v] = src[v];
+  } else {
+    load_x_tile<6>(x, B, nc, unit, xt, tid, nthreads, kU);
+  }
   for (int j = tid; j < 3 * nal + nc; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : a[j - 3 * nal];   // refL | aL
   if (tid < kU) {
     const int64_t frame = unit * kU + tid;
