@@ -29,7 +29,7 @@ class PPDesc(C.Structure):
                 ("d_r", C.c_int32), ("use_angle_value", C.c_int32), ("has_position", C.c_int32), ("flags", C.c_int32),
                 ("align_idx", C.c_void_p), ("ref_c", C.c_void_p), ("rec", C.c_void_p),
                 ("atom_align", C.c_void_p), ("atom_slot", C.c_void_p), ("rec_slot", C.c_void_p), ("slot_atom", C.c_void_p), ("n_slot", C.c_int32),
-                ("n_rec_slot", C.c_int32)]
+                ("n_rec_slot", C.c_int32), ("align_w", C.c_void_p)]
 
 
 class MLPDesc(C.Structure):

@@ -29,6 +29,9 @@ class ScriptableAlignFeature(torch.nn.Module):
         self.use_angle_value: bool = bool(layer.use_angle_value)
         self.register_buffer("align_idx", layer.align_idx.detach().cpu().to(torch.long))
         self.register_buffer("ref_c", layer.ref_c.detach().cpu().clone())
+        # per-atom alignment weights (mean 1; ref_c is already multiplied by them, pp.AlignFeatureLayer); ones = uniform
+        aw = getattr(layer, "align_w", None)
+        self.register_buffer("align_w", torch.ones(layer.ref_c.shape[0]) if aw is None else aw.detach().cpu().clone())
 
         def pick(type_id, n_atoms):
             rows = rec[rec[:, 0] == type_id]
@@ -52,7 +55,7 @@ class ScriptableAlignFeature(torch.nn.Module):
         out = torch.zeros(x.shape[0], self.d_r, dtype=x.dtype, device=x.device)
         if self.pos_atoms.numel() > 0:
             xa = x[:, self.align_idx, :]
-            c = xa.mean(dim=1, keepdim=True)
+            c = (self.align_w.to(x.dtype)[None, :, None] * xa).mean(dim=1, keepdim=True)
             h = torch.matmul((xa - c).transpose(1, 2), ref)
             u, s, vh = torch.linalg.svd(h)
             d = torch.sign(torch.linalg.det(torch.matmul(u, vh)))

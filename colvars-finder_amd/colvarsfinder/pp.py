@@ -78,9 +78,13 @@ class AlignFeatureLayer(torch.nn.Module):
         ref_pos: ``[n_align, 3]`` reference positions of those atoms (stored centred).
         features: list of ``(type_name, local_atom_indices)``.
         use_angle_value: emit angles in radians instead of cos / (cos, sin).
+        align_weights: optional ``[n_align]`` non-negative per-atom weights w_b of the alignment (masses, say): the
+            frame's weighted centroid goes to the reference's and the rotation minimises
+            ``sum_b w_b |(x_b - c) R - ref_b|^2``.  ``None`` = the uniform weights of molann's layer.  Weighted layers
+            run on the general kernels only (at most 64 atoms per frame).
     """
 
-    def __init__(self, n_atoms, align_idx, ref_pos, features, use_angle_value=False):
+    def __init__(self, n_atoms, align_idx, ref_pos, features, use_angle_value=False, align_weights=None):
         super().__init__()
         align_idx = np.asarray(align_idx, dtype=np.int64)
         ref = np.asarray(ref_pos, dtype=np.float64)
@@ -107,6 +111,18 @@ class AlignFeatureLayer(torch.nn.Module):
             flags |= _hip.PP_ALIGN_CONTIG
         if all(r[0] == _hip.FEAT_POSITION and r[1] == i and r[5] == 3 * i for i, r in enumerate(rec)):
             flags |= _hip.PP_PURE_POSITION
+        # per-atom weights: the kernels take them with mean 1, and the reference positions centred by their WEIGHTED
+        # centroid and pre-multiplied by them (include/cvf.h, cvf_pp_desc.align_w) - the covariance
+        # sum_b w_b (x_b - c) (x) ref_b is then the same loop as the unweighted one
+        w_hat = None
+        if align_weights is not None:
+            w = np.asarray(align_weights, dtype=np.float64).reshape(-1)
+            assert w.shape == (len(align_idx),), f"align_weights must be [{len(align_idx)}], got {w.shape}"
+            assert np.all(np.isfinite(w)) and np.all(w >= 0) and np.count_nonzero(w) >= 3, \
+                "align_weights must be finite, non-negative, with at least 3 non-zero entries"
+            assert 3 * n_atoms <= 192, "weighted alignment is built for frames of at most 64 atoms"
+            w_hat = w * (len(w) / w.sum())
+            flags = 0   # the fast layouts assume uniform weights
         self._flags = flags
         # per-atom tables for the streaming kernel of large molecules (include/cvf.h): which ref row an atom aligns
         # to, and the compact "slot" of every atom some feature reads
@@ -126,14 +142,21 @@ class AlignFeatureLayer(torch.nn.Module):
         # with the record, so the order is free; type -1 entries are padding)
         rec_slot = _batch_records(sorted(rec_slot, key=lambda r: r[0]))
         self._n_rec_slot = len(rec_slot)
-        self._flags |= _hip.PP_SLOT_BATCHED
+        if w_hat is None:
+            self._flags |= _hip.PP_SLOT_BATCHED
         self._n_slot = len(used)
         self.register_buffer("atom_align", torch.tensor(atom_align))
         self.register_buffer("atom_slot", torch.tensor(atom_slot))
         self.register_buffer("rec_slot", torch.tensor(rec_slot, dtype=torch.int32).reshape(-1, 6))
         self.register_buffer("slot_atom", torch.tensor(used, dtype=torch.int32))
         self.register_buffer("align_idx", torch.tensor(align_idx, dtype=torch.int32))
-        self.register_buffer("ref_c", torch.tensor(ref - ref.mean(axis=0, keepdims=True), dtype=torch.float32))
+        if w_hat is None:
+            ref_c = ref - ref.mean(axis=0, keepdims=True)
+            self.align_w = None
+        else:
+            ref_c = w_hat[:, None] * (ref - (w_hat[:, None] * ref).mean(axis=0, keepdims=True))
+            self.register_buffer("align_w", torch.tensor(w_hat, dtype=torch.float32))
+        self.register_buffer("ref_c", torch.tensor(ref_c, dtype=torch.float32))
         self.register_buffer("rec", torch.tensor(rec, dtype=torch.int32).reshape(-1, 6))
 
     def pp_desc(self):
@@ -146,6 +169,7 @@ class AlignFeatureLayer(torch.nn.Module):
         d.align_idx, d.ref_c, d.rec = self.align_idx.data_ptr(), self.ref_c.data_ptr(), self.rec.data_ptr()
         d.atom_align, d.atom_slot, d.rec_slot = self.atom_align.data_ptr(), self.atom_slot.data_ptr(), self.rec_slot.data_ptr()
         d.slot_atom, d.n_slot, d.n_rec_slot = self.slot_atom.data_ptr(), self._n_slot, self._n_rec_slot
+        d.align_w = self.align_w.data_ptr() if self.align_w is not None else None
         return d
 
     def forward(self, x):
@@ -203,7 +227,8 @@ class FeatureLayer:
 class AlignmentLayer:
     """``AlignmentLayer(align_atom_group, input_atom_group)`` (main.ipynb:345)."""
 
-    def __init__(self, align_atom_group, input_atom_group):
+    def __init__(self, align_atom_group, input_atom_group, weights=None):
+        self.weights = None if weights is None else np.asarray(weights, dtype=np.float64)
         self.align_ix = _ix(align_atom_group)
         self.input_ix = _ix(input_atom_group)
         lut = {int(g): i for i, g in enumerate(self.input_ix)}
@@ -212,7 +237,7 @@ class AlignmentLayer:
         except KeyError as e:
             raise ValueError(f"align atom {e} is not in the input atom group") from None
         pos = np.asarray(align_atom_group.positions, dtype=np.float64)
-        self.ref_c = pos - pos.mean(axis=0, keepdims=True)
+        self.ref_c = pos - pos.mean(axis=0, keepdims=True)   # (the fused layer re-centres by the weighted centroid)
 
     def show_info(self):
         print(f"\n{len(self.input_ix)} atoms used for input, (0-based) global indices: \n {list(self.input_ix)}")
@@ -227,7 +252,7 @@ class PreprocessingANN(AlignFeatureLayer):
     def __init__(self, align_layer, feature_layer):
         assert np.array_equal(align_layer.input_ix, feature_layer.input_ix), "align and feature layers use different input atoms"
         super().__init__(len(align_layer.input_ix), align_layer.local_idx, align_layer.ref_c, feature_layer.local,
-                         feature_layer.use_angle_value)
+                         feature_layer.use_angle_value, align_weights=getattr(align_layer, "weights", None))
 
 
 def identity_desc(n_coord):

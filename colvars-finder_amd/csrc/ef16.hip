@@ -852,7 +852,7 @@ extern "C" int cvf_ef16_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp
   if (!mlp || !pp || !ef16_shape(mlp, &H, &NH) || getenv("CVF_NO_EF16")) return 0;
   if (!ef16_dispatch(H, NH, [](auto, auto) {})) return 0;
   const int fast = CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION;
-  if (pp->mode != CVF_PP_ALIGN || (pp->flags & fast) != fast || pp->n_align > pp->n_rec || pp->n_align < 3) return 0;
+  if (pp->mode != CVF_PP_ALIGN || pp->align_w || (pp->flags & fast) != fast || pp->n_align > pp->n_rec || pp->n_align < 3) return 0;
   if (pp->d_r != 3 * pp->n_rec || pp->d_r != mlp->dims[0] || pp->d_r > 72 || pp->n_coord > 192 || pp->n_coord < pp->d_r) return 0;
   if (mlp->n_nets < 1 || mlp->n_nets > CVF_MAX_NETS) return 0;
   return (size_t)front16_lds(pp->n_coord, pp->n_align, mlp->n_nets).total * sizeof(float) <= 64 * 1024;

@@ -1356,7 +1356,7 @@ extern "C" int cvf_ef_fwd_metric_supported(const cvf_mlp_desc* mlp, const cvf_pp
   if (!mlp || !pp || !ef_shape(mlp, &H, &NH) || getenv("CVF_NO_FWD_METRIC")) return 0;
   if (!ef_dispatch(H, NH, [](auto, auto) {})) return 0;
   const int fast = CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION;
-  if (pp->mode != CVF_PP_ALIGN || (pp->flags & fast) != fast || pp->n_align > pp->n_rec) return 0;
+  if (pp->mode != CVF_PP_ALIGN || pp->align_w || (pp->flags & fast) != fast || pp->n_align > pp->n_rec) return 0;
   if (pp->d_r != 3 * pp->n_rec || pp->d_r != mlp->dims[0] || pp->d_r > 72 || pp->n_coord > 192) return 0;
   return fwd_metric_lds(pp, mlp->n_nets) <= 80 * 1024 && cvf_ef_saved_floats(mlp, 1) > 0;
 }

@@ -77,7 +77,12 @@ __device__ __forceinline__ void align_lane(const cvf_pp_desc& pp, const Tables& 
     const int a = CONTIG ? b : tb.align_idx[b];
     const double x0 = (double)my[3 * a], x1 = (double)my[3 * a + 1], x2 = (double)my[3 * a + 2];
     const double r0 = (double)tb.ref_c[3 * b], r1 = (double)tb.ref_c[3 * b + 1], r2 = (double)tb.ref_c[3 * b + 2];
-    cx += x0; cy += x1; cz += x2;
+    if (!CONTIG && pp.align_w) {   // weighted centroid (cvf_pp_desc.align_w has mean 1; ref_c carries the weights already)
+      const double wb = (double)pp.align_w[b];
+      cx = fma(wb, x0, cx); cy = fma(wb, x1, cy); cz = fma(wb, x2, cz);
+    } else {
+      cx += x0; cy += x1; cz += x2;
+    }
     rs0 += r0; rs1 += r1; rs2 += r2;
     H[0][0] = fma(x0, r0, H[0][0]); H[0][1] = fma(x0, r1, H[0][1]); H[0][2] = fma(x0, r2, H[0][2]);
     H[1][0] = fma(x1, r0, H[1][0]); H[1][1] = fma(x1, r1, H[1][1]); H[1][2] = fma(x1, r2, H[1][2]);
@@ -549,10 +554,12 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
       Z[3 * i + 1] = -R[3 * i + 0] * s.z + R[3 * i + 2] * s.x;
       Z[3 * i + 2] = R[3 * i + 0] * s.y - R[3 * i + 1] * s.x;
     }
+    // (weighted alignment: atom b's share of the centroid is align_w[b] / n_align, and ref_c holds align_w[b] * ref_b)
     const V3 shift = inv_nal * sump;
     for (int b = 0; b < pp.n_align; ++b) {
       const V3 rf = v3(tb.ref_c[3 * b], tb.ref_c[3 * b + 1], tb.ref_c[3 * b + 2]);
-      addG(tb.align_idx[b], mat_times(Z, rf) - shift);
+      const float wb = pp.align_w ? pp.align_w[b] : 1.0f;
+      addG(tb.align_idx[b], mat_times(Z, rf) - wb * shift);
     }
   }
   // ---- E = sum a G^2 ; u = a .* G (in place)
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(64) void metric_align_kernel(cvf_pp_desc pp, const 
   V3 ubar = v3(0, 0, 0);
   float dR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (pp.has_position) {
-    for (int b = 0; b < pp.n_align; ++b) ubar = ubar + getU(tb.align_idx[b]);
+    for (int b = 0; b < pp.n_align; ++b) ubar = ubar + (pp.align_w ? pp.align_w[b] : 1.0f) * getU(tb.align_idx[b]);
     ubar = inv_nal * ubar;
     float dH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < pp.n_align; ++b) {
@@ -748,6 +755,9 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
   CVF_REQUIRE(pp->mode == CVF_PP_ALIGN, "unknown pp mode %d", pp->mode);
   CVF_REQUIRE(pp->n_coord % 3 == 0 && pp->n_align >= 3 && pp->align_idx && pp->ref_c && pp->rec,
               "cvf_align_feature_fwd: malformed descriptor (n_coord=%d n_align=%d)", pp->n_coord, pp->n_align);
+  CVF_REQUIRE(!pp->align_w || (pp->flags == 0 && pp->n_coord <= kLanePerFrameMaxCoord),
+              "cvf_align_feature_fwd: per-atom alignment weights need flags == 0 and at most %d coordinates per frame",
+              kLanePerFrameMaxCoord);
   if (pp->n_coord > kLanePerFrameMaxCoord) {
     return cvf_k1_large_launch(pp, x, B, feat_tiled, feat_rows, aux_tiled, (float*)scratch, s);
   }
@@ -841,6 +851,9 @@ static int metric_apply_impl(const cvf_pp_desc* pp, const float* x, int64_t B, c
     return cvf_check_launch("metric_identity_kernel");
   }
   CVF_REQUIRE(aux_tiled, "cvf_metric_apply: align mode needs aux");
+  CVF_REQUIRE(!pp->align_w || (pp->flags == 0 && pp->n_coord <= kLanePerFrameMaxCoord),
+              "cvf_metric_apply: per-atom alignment weights need flags == 0 and at most %d coordinates per frame",
+              kLanePerFrameMaxCoord);
   if (pp->n_coord > kLanePerFrameMaxCoord) {
     CVF_REQUIRE(slot_xyz && dense && pp->rec_slot && pp->slot_atom && pp->atom_align && pp->n_slot > 0,
                 "cvf_metric_apply: large molecules need the slot tables, slot_xyz (cvf_align_feature_fwd scratch) and "

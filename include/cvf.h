@@ -69,6 +69,11 @@ typedef struct cvf_pp_desc {
   const int32_t* slot_atom;  /* [n_slot]: atom of each slot */
   int32_t n_slot;
   int32_t n_rec_slot;        /* entries of rec_slot (0: n_rec, unbatched) */
+  /* optional per-atom alignment weights ("weighted Kabsch": the rotation and translation minimise
+   * sum_b w_b |(x_b - c) R - ref_b|^2, c = sum_b w_b x_b / sum_b w_b).  NULL = uniform weights.  When set:
+   *   align_w[b] = n_align * w_b / sum w   (mean 1), and ref_c[b] = align_w[b] * (ref_b - weighted centroid of ref),
+   * flags must be 0 and 3 N must fit the lane-per-frame kernels (the layouts built for speed assume uniform weights). */
+  const float* align_w;      /* [n_align] or NULL */
 } cvf_pp_desc;
 
 /* k identical feed-forward nets (colvarsfinder.nn.EigenFunctions, nn.py:242-293) or one

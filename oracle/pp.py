@@ -52,11 +52,17 @@ def feature_dim(features, use_angle_value=False):
     return d
 
 
-def kabsch_rotation(x, align_idx, ref_c):
-    """x [B,N,3], align_idx [n_al] long, ref_c [n_al,3] (centred).  Returns (R [B,3,3], c [B,1,3])."""
+def kabsch_rotation(x, align_idx, ref_c, w=None):
+    """x [B,N,3], align_idx [n_al] long, ref_c [n_al,3] (centred).  Returns (R [B,3,3], c [B,1,3]).
+    ``w`` [n_al] (sum 1): per-atom weights - c is the weighted centroid, H the weighted covariance, ``ref_c`` centred by
+    the weighted centroid; ``None`` is molann's uniform alignment."""
     xa = x[:, align_idx, :]
-    c = xa.mean(dim=1, keepdim=True)
-    H = torch.matmul((xa - c).transpose(1, 2), ref_c)  # [B,3,3]
+    if w is None:
+        c = xa.mean(dim=1, keepdim=True)
+        H = torch.matmul((xa - c).transpose(1, 2), ref_c)  # [B,3,3]
+    else:
+        c = (w[None, :, None] * xa).sum(dim=1, keepdim=True)
+        H = torch.matmul((xa - c).transpose(1, 2), w[:, None] * ref_c)
     U, S, Vh = torch.linalg.svd(H)
     d = torch.sign(torch.linalg.det(torch.matmul(U, Vh))).detach()
     D = torch.diag_embed(torch.stack([torch.ones_like(d), torch.ones_like(d), d], dim=1))
@@ -107,18 +113,26 @@ class AlignFeature(torch.nn.Module):
     ``ref_pos``: [n_al,3] positions of those atoms in the reference frame; stored minus
     their unweighted centroid (what ``align.show_info()`` prints, main.ipynb:316-327).
     ``features``: list of ``(type_name, atom_index_tuple)``.
+    ``align_weights``: optional [n_al] per-atom weights (the north star's "weighted Kabsch"; molann itself aligns with
+    uniform weights): weighted centroids, weighted covariance.
     """
 
-    def __init__(self, align_idx, ref_pos, features, use_angle_value=False):
+    def __init__(self, align_idx, ref_pos, features, use_angle_value=False, align_weights=None):
         super().__init__()
         ref = torch.as_tensor(np.asarray(ref_pos), dtype=torch.get_default_dtype())
         self.register_buffer("align_idx", torch.as_tensor(np.asarray(align_idx), dtype=torch.long))
-        self.register_buffer("ref_c", ref - ref.mean(dim=0, keepdim=True))
+        if align_weights is None:
+            self.w = None
+            self.register_buffer("ref_c", ref - ref.mean(dim=0, keepdim=True))
+        else:
+            w = torch.as_tensor(np.asarray(align_weights, dtype=np.float64), dtype=torch.get_default_dtype())
+            self.register_buffer("w", w / w.sum())
+            self.register_buffer("ref_c", ref - (self.w[:, None] * ref).sum(dim=0, keepdim=True))
         self.features = [(t, tuple(int(i) for i in a)) for t, a in features]
         self.use_angle_value = bool(use_angle_value)
 
     def align(self, x):
-        R, c = kabsch_rotation(x, self.align_idx, self.ref_c.to(x.dtype))
+        R, c = kabsch_rotation(x, self.align_idx, self.ref_c.to(x.dtype), None if self.w is None else self.w.to(x.dtype))
         return torch.matmul(x - c, R)
 
     def forward(self, x):

@@ -733,3 +733,76 @@ def test_regae_three_regularisers_three_latents_vs_oracle(dev):
     assert got.shape == want.shape == (2, 3, 4 + K + 3)
     np.testing.assert_allclose(got[0, 0], want[0, 0], rtol=1e-4, atol=1e-6)          # first step: same weights on both sides
     np.testing.assert_allclose(got, want, rtol=2e-3, atol=1e-5)                      # six Adam steps on, fp32 vs fp64
+
+
+# ------------------------------------------------------------------------------------------------
+# per-atom alignment weights (north_star's "weighted Kabsch"; cvf_pp_desc.align_w)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_atoms,B,feats", [(10, 131, MIXED), (22, 300, None), (12, 64, None)])
+def test_weighted_alignment_features_vs_oracle(dev, n_atoms, B, feats):
+    from colvarsfinder import pp
+    from oracle.pp import AlignFeature
+    traj, _, ref = make_molecule_traj(n_atoms, B, seed=91 + n_atoms)
+    align = list(range(n_atoms)) if feats is None else [0, 1, 2, 4, 5, 8]
+    feats = feats or [("position", tuple(range(n_atoms)))]
+    aw = np.random.RandomState(n_atoms).uniform(0.2, 3.0, size=len(align))
+    layer = pp.AlignFeatureLayer(n_atoms, align, ref[align], feats, False, align_weights=aw).to(dev)
+    got = layer(torch.tensor(traj)).numpy()
+    torch.set_default_dtype(torch.float64)
+    want = AlignFeature(align, ref[align], feats, False, align_weights=aw)(torch.tensor(traj, dtype=torch.float64)).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6 * np.abs(want).max())
+    # and the weights are not ignored
+    plain = AlignFeature(align, ref[align], feats, False)(torch.tensor(traj, dtype=torch.float64)).numpy()
+    assert np.abs(plain - want).max() > 1e-3
+    # uniform weights give the unweighted layer's features (general kernel vs fast kernels)
+    uni = pp.AlignFeatureLayer(n_atoms, align, ref[align], feats, False, align_weights=np.full(len(align), 0.7)).to(dev)
+    np.testing.assert_allclose(uni(torch.tensor(traj)).numpy(), plain, rtol=1e-5, atol=2e-6 * np.abs(plain).max())
+
+
+@pytest.mark.parametrize("n_atoms,B,k,mixed", [(9, 130, 2, False), (10, 97, 3, True)])
+def test_weighted_alignment_generator_step_vs_oracle(dev, n_atoms, B, k, mixed):
+    """Generator-mode step through a weighted alignment layer: the derivative of the weighted Kabsch rotation and of the
+    weighted centroid (metric_align_kernel) against autograd through the fp64 oracle."""
+    from colvarsfinder import core, nn, pp
+    from oracle import losses, nnref
+    from oracle.pp import AlignFeature
+    traj, w, ref = make_molecule_traj(n_atoms, B, seed=1500 + B, scale=2.0, sigma=0.3)
+    align = [0, 1, 2, 4, 5, 8] if mixed else list(range(n_atoms))
+    feats = MIXED if mixed else [("position", tuple(range(n_atoms)))]
+    aw = np.random.RandomState(B).uniform(0.2, 3.0, size=len(align))
+    layer = pp.AlignFeatureLayer(n_atoms, align, ref[align], feats, False, align_weights=aw).to(dev)
+    dims = [layer.d_r, 12, 12, 1]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(5))
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    a = torch.tensor(diag_coeff_for(n_atoms, 3), dtype=torch.float32)
+    eig_w = [1.0 - 0.1 * i for i in range(k)]
+    task = core.EigenFunctionTask(Traj(traj, w, 1.0), layer, model, "/tmp/cvf_test", 12.0, eig_w, diag_coeff=a, beta=1.2, lag_tau=0,
+                                  k=k, device=dev, verbose=False, save_model_every_step=0)
+    loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+    X = torch.tensor(traj, dtype=torch.float64, requires_grad=True)
+    olayer = AlignFeature(align, ref[align], feats, False, align_weights=aw)
+    lo, eo, no, po, co = losses.ef_loss(sd, k, olayer, X, torch.tensor(w), alpha=12.0, eig_w=eig_w, diag_coeff=a.double(), beta=1.2)
+    lo.backward()
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=RTOL64)
+    want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+    # the unweighted oracle gives a different loss: the weights reach the derivative kernel
+    lu = losses.ef_loss({n: p.double() for n, p in sd0.items()}, k, AlignFeature(align, ref[align], feats, False),
+                        torch.tensor(traj, dtype=torch.float64, requires_grad=True), torch.tensor(w), alpha=12.0, eig_w=eig_w,
+                        diag_coeff=a.double(), beta=1.2)[0]
+    assert abs(float(lu.detach()) - float(lo.detach())) > 1e-4 * abs(float(lo.detach()))
+
+
+def test_weighted_alignment_rejects_layouts_it_was_not_built_for(dev):
+    from colvarsfinder import pp
+    _, _, ref = make_molecule_traj(80, 4, seed=3)
+    with pytest.raises(AssertionError, match="at most 64 atoms"):
+        pp.AlignFeatureLayer(80, list(range(80)), ref, [("position", tuple(range(80)))], False, align_weights=np.ones(80))
+    with pytest.raises(AssertionError, match="non-negative"):
+        pp.AlignFeatureLayer(5, list(range(5)), ref[:5], [("position", (0, 1))], False, align_weights=[1, -1, 1, 1, 1])

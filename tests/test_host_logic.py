@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 def test_struct_layouts_match_the_header(built_lib):
     # sizes computed from include/cvf.h by hand: any drift between the C structs and ctypes breaks every call
-    assert ctypes.sizeof(built_lib.PPDesc) == 8 * 4 + 7 * 8 + 2 * 4
+    assert ctypes.sizeof(built_lib.PPDesc) == 8 * 4 + 7 * 8 + 2 * 4 + 8
     assert ctypes.sizeof(built_lib.MLPDesc) == 4 * (2 + 13 + 12 + 2 * 8 * 12 + 1)
     assert ctypes.sizeof(built_lib.EFCfg) == 4 * 4 + 8 * 3 + 8 * 8
 
@@ -277,8 +277,8 @@ def test_slot_record_batches_are_conflict_free():
             assert len(slots) == len(set(slots))
 
 
-@pytest.mark.parametrize("angle_value", [False, True])
-def test_export_twin_matches_oracle_and_scripts(tmp_path, angle_value):
+@pytest.mark.parametrize("angle_value,weighted", [(False, False), (True, False), (False, True)])
+def test_export_twin_matches_oracle_and_scripts(tmp_path, angle_value, weighted):
     """export.ScriptableAlignFeature (the TorchScript export twin of the kernel-backed layer, reference save_model
     core.py:205-226): same features as the oracle layer, scriptable, and the saved file reloads and reproduces them."""
     from colvarsfinder import export, pp
@@ -289,10 +289,11 @@ def test_export_twin_matches_oracle_and_scripts(tmp_path, angle_value):
     feats = [("position", (0, 3, 4, 9)), ("bond", (0, 1)), ("dihedral", (1, 2, 3, 4)), ("angle", (5, 6, 7)), ("bond", (8, 13)),
              ("dihedral", (9, 10, 11, 12))]
     align = [0, 1, 2, 3, 4, 5, 6, 7, 9, 11]
-    layer = pp.AlignFeatureLayer(n_atoms, align, ref[align], feats, angle_value)
+    aw = np.random.RandomState(5).uniform(0.3, 2.0, size=len(align)) if weighted else None
+    layer = pp.AlignFeatureLayer(n_atoms, align, ref[align], feats, angle_value, align_weights=aw)
     twin = export.ScriptableAlignFeature(layer)
     x = torch.tensor(traj, dtype=torch.float64)
-    want = AlignFeature(align, ref[align], feats, angle_value).double()(x).numpy()
+    want = AlignFeature(align, ref[align], feats, angle_value, align_weights=aw).double()(x).numpy()
     got = twin(x).numpy()
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)   # the layer keeps its reference in fp32
     cv = export.scriptable_cv(torch.nn.Sequential(layer, torch.nn.Linear(layer.d_r, 2)))

@@ -138,3 +138,55 @@ def test_closed_form_vjp_reflection_branch():
         (L(x) * torch.tensor(g.reshape(1, -1))).sum().backward()
         G = opp.kabsch_vjp_np(mirrored[b], L.align_idx.numpy(), L.ref_c.numpy(), g, list(range(8)))
         np.testing.assert_allclose(G, x.grad[0].numpy(), rtol=1e-8, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------
+# per-atom alignment weights ("weighted Kabsch", north_star; molann's own layer is the uniform case)
+# ------------------------------------------------------------------------------------------------
+def _weights(n, seed=0):
+    return np.random.RandomState(seed).uniform(0.2, 3.0, size=n)
+
+
+def test_weighted_alignment_uniform_weights_is_the_unweighted_layer():
+    traj, _, ref = make_molecule_traj(10, 12, 21, dtype=np.float64)
+    x = torch.tensor(traj)
+    a = opp.AlignFeature(list(range(10)), ref, MIXED)(x)
+    b = opp.AlignFeature(list(range(10)), ref, MIXED, align_weights=np.full(10, 2.5))(x)
+    np.testing.assert_allclose(b.numpy(), a.numpy(), atol=1e-12)
+
+
+def test_weighted_alignment_minimises_the_weighted_residual():
+    """(R, c) must be the minimiser of sum_b w_b |(x_b - c) R - ref_b|^2: checked against brute-force perturbations of
+    the rotation and against NumPy's SVD of the weighted covariance."""
+    n = 9
+    traj, _, ref = make_molecule_traj(n, 6, 22, dtype=np.float64)
+    w = _weights(n, 3)
+    L = opp.AlignFeature(list(range(n)), ref, [("position", tuple(range(n)))], align_weights=w)
+    x = torch.tensor(traj)
+    wn = torch.tensor(w / w.sum())
+    res = lambda al: (wn[None, :, None] * (al - L.ref_c) ** 2).sum(dim=(1, 2))
+    base = res(L.align(x))
+    rs = np.random.RandomState(2)
+    for _ in range(20):
+        Rp = torch.linalg.matrix_exp(torch.tensor(opp._skew(rs.normal(size=3) * 0.05)))
+        assert (res(torch.matmul(L.align(x), Rp)) >= base - 1e-10).all()
+    # independent restatement in NumPy
+    for b in range(traj.shape[0]):
+        c = (wn.numpy()[:, None] * traj[b]).sum(0)
+        rc = ref - (wn.numpy()[:, None] * ref).sum(0)
+        U, S, Vt = np.linalg.svd((traj[b] - c).T @ (wn.numpy()[:, None] * rc))
+        D = np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))])
+        np.testing.assert_allclose(L.align(x)[b].numpy(), (traj[b] - c) @ (U @ D @ Vt), atol=1e-10)
+    # the weights matter: the unweighted layer gives different positions
+    U0 = opp.AlignFeature(list(range(n)), ref, [("position", tuple(range(n)))])
+    assert (L.align(x) - L.ref_c - (U0.align(x) - U0.ref_c)).abs().max() > 1e-3
+
+
+def test_weighted_alignment_rigid_motion_invariance():
+    n = 10
+    traj, _, ref = make_molecule_traj(n, 8, 23, dtype=np.float64)
+    align = [0, 1, 2, 4, 5, 8]
+    L = opp.AlignFeature(align, ref[align], MIXED, align_weights=_weights(len(align), 5))
+    Rm = random_rotations(np.random.RandomState(4), 8)
+    moved = np.einsum("bij,baj->bai", Rm, traj) + np.random.RandomState(6).normal(size=(8, 1, 3)) * 5
+    np.testing.assert_allclose(L(torch.tensor(moved)).numpy(), L(torch.tensor(traj)).numpy(), atol=1e-9)
