@@ -134,12 +134,15 @@ def note(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def run_steps(task, X, Wt, B, steps, warmup, tag, world, dev, max_batches=8):
+def run_steps(task, X, Wt, B, steps, warmup, tag, world, dev, max_batches=8, preheat_ms=0.0):
     """W untimed + EXACTLY K timed train steps of the product's own step path on this rank's resident rows, B frames per rank
     per step.  As EigenFunctionTask.train() replays one hipGraph per EPOCH (all its static batches), the steps run in chunks of
     C = the number of distinct resident batches (<= max_batches) through task._graph_call - one graph replay per chunk - and the
     remainder K mod C as single-step replays.  The timed region is bracketed by a barrier + device synchronisation on both
-    sides.  Returns (max-over-ranks seconds, last loss vector, single-step function)."""
+    sides.  `preheat_ms` > 0: after the W warm-up steps, further UNTIMED chunks of the same steps run for about that many
+    milliseconds, so that the clock starts with the GPU at the frequency a training run of thousands of steps sees (the
+    driver's default K = 20 steps last 1.5 ms in all - shorter than the power manager's ramp; the count is reported as
+    `preheat_steps`).  Returns (max-over-ranks seconds, last loss vector, single-step function)."""
     n_batches = max(1, min(X.shape[0] // B, max_batches))
     log = torch.zeros(n_batches, 3 + 2 * task.k, device=dev, dtype=torch.float64)
 
@@ -166,6 +169,25 @@ def run_steps(task, X, Wt, B, steps, warmup, tag, world, dev, max_batches=8):
     for i in range(rest if task._use_graphs else 0):                       # (and the single-step graphs the remainder uses)
         step(i)
         step(i)
+    run_steps.preheat_steps = 0
+    if preheat_ms > 0:
+        barrier()
+        t0 = time.perf_counter()
+        chunk()
+        barrier()
+        per_chunk = max(time.perf_counter() - t0, 1e-5)
+        n_pre = int(min(2000, max(0.0, preheat_ms * 1e-3 / per_chunk)))
+        if world > 1:   # the same count on every rank (the chunks hold collectives)
+            t = torch.tensor([n_pre], device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            n_pre = int(t)
+        for _ in range(n_pre):
+            chunk()
+        # (the first graph launch after a long queue has drained costs the host 0.1-0.4 ms of clean-up - tools/timing_probe.py -
+        # which must not land inside a 1.5 ms timed region: drain, replay once more, drain)
+        barrier()
+        chunk()
+        run_steps.preheat_steps = (n_pre + 2) * n_batches
     barrier()
     t0 = time.perf_counter()
     for _ in range(n_chunks):
@@ -197,6 +219,8 @@ def main():
     ap.add_argument("--frames-total", type=int, default=1_000_000, help="config 4: frames of the whole job")
     ap.add_argument("--global-batch", type=int, default=160_000, help="strong scaling: frames per step of the whole job")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 disables it)")
+    ap.add_argument("--preheat-ms", type=float, default=75.0,
+                    help="untimed steps run for about this long after the W warm-up steps, before the clock starts (GPU frequency ramp; 0 = off)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other global batches, K1 rooflines)")
     ap.add_argument("--workload", choices=["c3", "c5", "c2", "regae"], default="c3",
                     help="c3 = the benchmark line; c5 = config-5 shape, c2 = config-2 AutoEncoderTask (extra measurements)")
@@ -250,7 +274,8 @@ def main():
                     "batch sums + flat gradient per step")
     X, Wt = device_frames(frames_rank, ref, 0.3, SEED + 1 + rank, dev)
     note(f"headline: {frames_rank} frames resident per GPU, {B} per GPU per step, {world} GPU(s), {scaling} scaling")
-    elapsed, loss_vec, step = run_steps(task, X, Wt, B, args.steps, args.warmup, "bench", world, dev)
+    elapsed, loss_vec, step = run_steps(task, X, Wt, B, args.steps, args.warmup, "bench", world, dev, preheat_ms=args.preheat_ms)
+    preheat_steps = run_steps.preheat_steps
     graphs = task._use_graphs
     final_loss = float(loss_vec[0])
 
@@ -355,6 +380,9 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "preheat_steps": preheat_steps,
+        "preheat_note": "untimed steps of the same kind run after the W warm-up steps (--preheat-ms) so that the timed K steps see the "
+                        "GPU clock of a long training run; --preheat-ms 0 turns it off",
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": scaling,
