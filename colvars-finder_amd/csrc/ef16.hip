@@ -116,6 +116,26 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     const int64_t frame = unit * kU + tid;
     wL[tid] = frame < B ? w[frame] : 0.0f;      // frames past the batch replicate the last one with weight 0
   }
+  // ---- the first layer's weights are requested here, behind the coordinates and the tables (vector memory returns in issue
+  //      order: in front of them they delayed the staging by 7 k cycles): their round trip runs beside the barrier and the
+  //      alignment (requested after the alignment, layer 0 began with a wait of ~2 k cycles per wave)
+  const PackLayout L = pack_layout(H, NH, D);
+  const URows pk = urows(packed + (int64_t)net * L.per_net, L.per_net, lane);   // this net's fragments (see URows)
+  const int S = (D + 3) >> 2, CT = (D + 15) >> 4;
+  float a0[SMAX][RT];
+  float bias[NH][RT][4];
+  auto request_layer0 = [&]() {
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+      const int se = s < S ? s : S - 1;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) a0[s][rt] = pk.ld(L.f0() + (se * RT + rt) * 64);   // (k-steps past S are skipped below)
+    }
+    load_hid_const_u<H>(urows(theta + mlp.b_off[net][0], H, q), bias[0]);
+  };
+  // (wave 0 asks after its alignment: the solve's fp64 state and these 36 + 8 registers do not fit 128 together, and
+  //  a spilled fragment is stored behind a wait for ALL outstanding loads)
+  if (wave != 0) request_layer0();
   __syncthreads();
   const float* my = xt + f * stride;
   CVF_STAMP(21);
@@ -153,23 +173,10 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     for (int i = 0; i < kAuxP; ++i)
       if ((i & 3) == p) auxL[f * kAuxP + i] = av[i];   // the four lanes of a frame hold the same record: each writes a quarter
     if (lane < 3) rsL[lane] = (float)(lane == 0 ? acc[12] : lane == 1 ? acc[13] : acc[14]);
+    request_layer0();
   }
   lds_barrier();
   CVF_STAMP(22);
-
-  // ---- every weight the forward chain needs is requested now: the feature phase below covers the round trip
-  const PackLayout L = pack_layout(H, NH, D);
-  const URows pk = urows(packed + (int64_t)net * L.per_net, L.per_net, lane);   // this net's fragments (see URows)
-  const int S = (D + 3) >> 2, CT = (D + 15) >> 4;
-  float a0[SMAX][RT];
-#pragma unroll
-  for (int s = 0; s < SMAX; ++s) {
-    const int se = s < S ? s : S - 1;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a0[s][rt] = pk.ld(L.f0() + (se * RT + rt) * 64);   // (k-steps past S are skipped below)
-  }
-  float bias[NH][RT][4];
-  load_hid_const_u<H>(urows(theta + mlp.b_off[net][0], H, q), bias[0]);
 
   // ---- aligned positions = features: the block's waves split the atoms (lane p of wave v: atoms p + 4 v + 4 nw i)
   {
@@ -585,12 +592,17 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
   // a finished 16x16 tile of layer `l` (rows = outputs, columns = inputs + bias).  Every tile of the gradient is produced
   // by exactly one wave, so a block that handles ONE tile of frames stores it straight into its slab row; a block that
   // walks several accumulates in the LDS image and flushes at the end.
+  // (the row offset is made opaque, or the four offsets of every call site are hoisted out of the layer loops, spilled, and
+  //  reloaded behind a wait for ALL outstanding memory operations - i.e. for the previous store's completion, eight times
+  //  per tile)
   auto emit_tile = [&](int l, int n_out, int n_in, int rt, int ct, const f32x4& acc) {
     const int wo = mlp.w_off[net][l] - gbase, bo = mlp.b_off[net][l] - gbase;
     const int i = 16 * ct + row16;
+    int ob = 16 * rt + r0;
+    asm volatile("" : "+v"(ob));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int o = 16 * rt + r0 + r;
+      const int o = ob + r;
       const bool isw = o < n_out && i < n_in, isb = o < n_out && i == n_in;
       const int idx = isw ? wo + o * n_in + i : bo + (o < n_out ? o : 0);
       if (isw || isb) {
