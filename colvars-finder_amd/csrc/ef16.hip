@@ -592,9 +592,12 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
   // a finished 16x16 tile of layer `l` (rows = outputs, columns = inputs + bias).  Every tile of the gradient is produced
   // by exactly one wave, so a block that handles ONE tile of frames stores it straight into its slab row; a block that
   // walks several accumulates in the LDS image and flushes at the end.
-  // (the row offset is made opaque, or the four offsets of every call site are hoisted out of the layer loops, spilled, and
-  //  reloaded behind a wait for ALL outstanding memory operations - i.e. for the previous store's completion, eight times
-  //  per tile)
+  // (direct stores go through a buffer descriptor of the row's span: entries outside the layer get an offset past its end and
+  //  are dropped by the hardware - no lane-divergent branch around the stores, so the compiler can count them when it waits
+  //  for the weight fragments requested before them instead of waiting for everything; and the row offset is made opaque, or
+  //  the four offsets of every call site are hoisted out of the layer loops, spilled, and reloaded behind a wait for ALL
+  //  outstanding memory operations - i.e. for the previous store's completion, eight times per tile)
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, gspan * 4, 0x00020000);
   auto emit_tile = [&](int l, int n_out, int n_in, int rt, int ct, const f32x4& acc) {
     const int wo = mlp.w_off[net][l] - gbase, bo = mlp.b_off[net][l] - gbase;
     const int i = 16 * ct + row16;
@@ -605,9 +608,11 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
       const int o = ob + r;
       const bool isw = o < n_out && i < n_in, isb = o < n_out && i == n_in;
       const int idx = isw ? wo + o * n_in + i : bo + (o < n_out ? o : 0);
-      if (isw || isb) {
-        if (MULTI) GI[idx] += acc[r];
-        else out[idx] = acc[r];
+      const float av = acc[r];   // (by value: __builtin_bit_cast applied to the vector-element lvalue acc[r] read element 0 four times)
+      if (MULTI) {
+        if (isw || isb) GI[idx] += av;
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, av), out_rs, (isw || isb) ? idx * 4 : 0x7ffffff0, 0, 0);
       }
     }
   };
@@ -712,25 +717,32 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) hbar.v[rt][0][r] = alpha * wl[rt][r];
+    // Every step's operands from memory (the transposed weights of a hidden layer; the feature / q rows of the first) are
+    // requested one step ahead, BEFORE the step's slab stores: vector memory returns in issue order, and requests issued
+    // behind the stores (at the top of the next step) waited for the stores' acknowledgements first.
+    HFrag<H> tfl;
+    float4 bA[4], bB[4];
+    auto request = [&](float4 (&dst)[4], const float* src_tile, int ct) {
+      const int i = 16 * ct + row16;
+      const float4* p = reinterpret_cast<const float4*>(src_tile + (int64_t)(i < D ? i : D - 1) * CVF_TILE + 4 * q);
 #pragma unroll
-    for (int l = NH - 1; l >= 0; --l) {
-      CVF_STAMP(13 + (NH - 1 - l));
-      HFrag<H> tfl;
-      if (l > 0) load_hfrag_u<H>(tfl, pk, L.th(l));
-      // the first layer's B operands come straight from memory (the feature tile + ones row, then q): wave w owns column
-      // tile w; k-slot kq of k-step (j, c) is frame 16 j + 4 kq + c, so a lane's sixteen values of one operand row are four
-      // 16-byte loads.  The [f ; 1] rows are requested here, q's after the barrier, behind the matrix instructions of the first half.
-      float4 bA[4], bB[4];
-      auto request = [&](float4 (&dst)[4], const float* src_tile, int ct) {
-        const int i = 16 * ct + row16;
-        const float4* p = reinterpret_cast<const float4*>(src_tile + (int64_t)(i < D ? i : D - 1) * CVF_TILE + 4 * q);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j] = p[4 * j];
-      };
-      if (l == 0) {
+      for (int j = 0; j < 4; ++j) dst[j] = p[4 * j];
+    };
+    auto request_step = [&](int l) {   // l: compile-time after unrolling
+      if (l > 0) {
+        load_hfrag_u<H>(tfl, pk, L.th(l));
+      } else {
         request(bA, f_tile, wave);
         request(bB, q_tile, wave);
       }
+    };
+    request_step(NH - 1);
+#pragma unroll
+    for (int l = NH - 1; l >= 0; --l) {
+      CVF_STAMP(13 + (NH - 1 - l));
+      // the first layer's B operands come straight from memory (the feature tile + ones row, then q): wave w owns column
+      // tile w; k-slot kq of k-step (j, c) is frame 16 j + 4 kq + c, so a lane's sixteen values of one operand row are four
+      // 16-byte loads.  The [f ; 1] rows are requested here, q's after the barrier, behind the matrix instructions of the first half.
       Vec<H, 1> zbar, dl;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -754,13 +766,14 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
         tangent_of<H, 1>(td, h[l - 1], t[l - 1]);
         store_image<H, 1, false>(SB2, td, one, lane, fo);
         __syncthreads();
+        // hbar_{l-1} = W_l^T zbar_l  (registers), then the next step's requests, then this step's tiles
+        init_bias<H, 1>(hbar, nullptr, q);
+        hidden_mul<H, 1>(hbar, tfl, zbar);
+        request_step(l - 1);
         for (int pr = wave; pr < RTO * CTH; pr += WPB) {
           const int rt = pr / CTH, ct = pr - rt * CTH;
           emit_tile(l, H, H, rt, ct, outer2(SA1, SB1, SA2, SB2, rt, ct));
         }
-        // hbar_{l-1} = W_l^T zbar_l  (registers; overlaps the other waves' outer products)
-        init_bias<H, 1>(hbar, nullptr, q);
-        hidden_mul<H, 1>(hbar, tfl, zbar);
         __syncthreads();
       } else {
         __syncthreads();
