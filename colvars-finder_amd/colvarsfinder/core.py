@@ -1193,15 +1193,125 @@ class _RegFlatParams:
         return [(p, gv) for p, _, gv in self.views]
 
 
+class _EncGradPenalty:
+    """``eta[0]``: ``reg_enc_grad_loss`` (core.py:896-910) = sum_i (1/W) sum_b w_b |d enc_i / d r (r_b)|^2, the derivative
+    taken with respect to the FEATURES r = pp(x) (``Y.requires_grad_()`` there), and its gradient with respect to the
+    encoder's parameters (second order through the encoder).
+
+    That is the energy term of the eigenfunction task's generator mode with an identity preprocessing layer and
+    ``diag_coeff = 1``, for k "virtual" scalar nets that share the encoder's hidden layers and end in row i of its last layer.
+    So it runs on the eigenfunction kernels: the encoder's parameters are gathered into the k-net layout, ``cvf_ef_mlp_fwd``
+    (y, g = dy/dr) + ``cvf_metric_apply_stats`` (E_i = |g_i|^2 and the batch sums) give the term, ``cvf_ef_backward`` with the
+    coefficient vector [0 .. eta_0 / W on the E entries .. 0] + ``cvf_slab_reduce`` give d(eta_0 term)/d(virtual parameters), and
+    the k copies of the shared layers are added back (fixed order) into the encoder's block of the flat gradient."""
+
+    def __init__(self, task):
+        from .nn import _chain_layers
+        enc = _chain_layers(task.model.encoder)
+        self.task, self.k, self.L = task, task.k, len(enc)
+        fl, dev, k, L = task._flat, task.device, task.k, len(enc)
+        dims = [enc[0][0].in_features] + [lin.out_features for lin, _ in enc]
+        assert dims[0] == task.tot_dim, \
+            (f"eta[0] > 0: the gradient-norm penalty reshapes the encoder's input gradient to [-1, {task.tot_dim}] (core.py:907), "
+             f"so the preprocessing layer must emit {task.tot_dim} features, not {dims[0]}")
+        if [a for _, a in enc] != [True] * (L - 1) + [False] or L < 2:
+            raise NotImplementedError("eta[0] on MI355X: the encoder must be Linear/Tanh layers ending in a Linear layer")
+        d = _hip.MLPDesc()
+        vd = dims[:-1] + [1]
+        d.n_nets, d.n_layers = k, L
+        for l in range(L):
+            d.dims[l], d.dims[l + 1], d.act[l] = vd[l], vd[l + 1], int(l < L - 1)
+        # virtual net i = [shared layers 0..L-2 | row i of the last weight | entry i of the last bias]
+        ed = fl.desc
+        n_shared = ed.w_off[0][L - 1] - ed.w_off[0][0]
+        assert ed.w_off[0][0] == 0 and ed.b_off[0][L - 2] + dims[L - 1] == n_shared   # the encoder opens the flat buffer
+        h = dims[L - 1]
+        per = n_shared + h + 1
+        src, pos = [], 0
+        for i in range(k):
+            for l in range(L - 1):
+                d.w_off[i][l], d.b_off[i][l] = pos + ed.w_off[0][l], pos + ed.b_off[0][l]
+            d.w_off[i][L - 1], d.b_off[i][L - 1] = pos + n_shared, pos + n_shared + h
+            src += list(range(n_shared)) + list(range(ed.w_off[0][L - 1] + i * h, ed.w_off[0][L - 1] + (i + 1) * h)) + [ed.b_off[0][L - 1] + i]
+            pos += per
+        d.n_params = pos
+        n_pack = _hip.lib().cvf_ef_pack_floats(d)
+        if k > _hip.MAX_NETS or n_pack <= 0:
+            raise NotImplementedError(
+                f"eta[0] on MI355X runs on the eigenfunction kernels: encoder widths {dims} need 1 to 3 equal hidden layers of one of "
+                f"{_hip.EF_HIDDEN_WIDTHS} units and at most {_hip.MAX_NETS} latent components")
+        self.desc, self.n, self.per, self.n_shared, self.h = d, pos, per, n_shared, h
+        self.last_w, self.last_b = int(ed.w_off[0][L - 1]), int(ed.b_off[0][L - 1])
+        self.src = torch.tensor(src, device=dev, dtype=torch.long)
+        self.theta = torch.zeros(pos, device=dev, dtype=torch.float32)
+        self.packed = torch.zeros(n_pack, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(pos, device=dev, dtype=torch.float32)
+        self.ones = torch.ones(dims[0], device=dev, dtype=torch.float32)
+        self.pp = identity_desc(dims[0])
+        cfg = _hip.EFCfg()
+        cfg.k, cfg.lag_idx, cfg.sort_eigvals, cfg.alpha, cfg.beta, cfg.dt = k, 0, 0, 0.0, 1.0, 1.0
+        for i in range(k):
+            cfg.eig_w[i] = 1.0
+        self.cfg, self.d_r = cfg, dims[0]
+        self._ws = {}
+
+    def _workspace(self, B):
+        ws = self._ws.get(B)
+        if ws is None:
+            lib, k, d_r, dev = _hip.lib(), self.k, self.d_r, self.task.device
+            T = _hip.ntiles(B)
+            f32, f64 = dict(device=dev, dtype=torch.float32), dict(device=dev, dtype=torch.float64)
+            n_saved = lib.cvf_ef_saved_floats(self.desc, T)
+            rows = lib.cvf_ef_backward_slab_rows(T)
+            ws = dict(T=T, feat=torch.empty(T * d_r * _hip.TILE, **f32), y=torch.empty(T * k * _hip.TILE, **f32),
+                      g=torch.empty(T * k * d_r * _hip.TILE, **f32), q=torch.empty(T * k * d_r * _hip.TILE, **f32),
+                      e=torch.empty(T * k * _hip.TILE, **f32),
+                      scratch=torch.zeros(lib.cvf_metric_stats_scratch_doubles(B, k), **f64),
+                      stats=torch.zeros(lib.cvf_ef_nstats(k, 0), **f64), coef=torch.zeros(4 * k + k * k, **f64),
+                      saved=torch.empty(n_saved, **f32) if n_saved > 0 else None, rows=rows,
+                      slab=torch.empty(rows * self.n, **f32))
+            self._ws[B] = ws
+        return ws
+
+    def run(self, rows, w, eta0, with_grad):
+        """``rows``: [B, d_r] feature rows of the batch (contiguous), ``w``: [B].  Returns the term (0-dim fp64 device tensor);
+        with ``with_grad`` adds d(eta0 * term)/d(encoder parameters) to the encoder's block of the task's flat gradient."""
+        task, lib, P, s = self.task, _hip.lib(), _hip.ptr, _hip.stream()
+        fl, k = task._flat, self.k
+        B = int(rows.shape[0])
+        ws = self._workspace(B)
+        torch.index_select(fl.theta, 0, self.src, out=self.theta)
+        task._call("cvf_ef_pack", lib.cvf_ef_pack, self.desc, P(self.theta), P(self.packed), s)
+        task._call("cvf_align_feature_fwd", lib.cvf_align_feature_fwd, self.pp, P(rows), B, P(ws["feat"]), None, None, None, s)
+        task._call("cvf_ef_mlp_fwd", lib.cvf_ef_mlp_fwd, self.desc, P(self.theta), P(self.packed), P(ws["feat"]), ws["T"], P(ws["y"]),
+                   P(ws["g"]), P(ws["saved"]), s)
+        task._call("cvf_metric_apply", lib.cvf_metric_apply_stats, self.pp, P(rows), B, None, P(self.ones), k, P(ws["g"]), P(ws["q"]),
+                   P(ws["e"]), None, None, self.cfg, P(w), P(ws["y"]), P(ws["scratch"]), P(ws["stats"]), None, None, s)
+        st = ws["stats"]                                   # [W, S1(k), S2(i<=j), E(k)]
+        e0 = 1 + k + k * (k + 1) // 2
+        term = st[e0:e0 + k].sum() / st[0]
+        if with_grad:
+            ge = ws["coef"][k + k * k:2 * k + k * k]       # [gS1(k), gS2(k*k), gE(k), ...]: d(eta0 term)/dE_i = eta0 / W
+            ge.copy_((eta0 / st[0]).expand(k))
+            task._call("cvf_ef_backward", lib.cvf_ef_backward, self.cfg, self.desc, P(self.theta), P(self.packed), B, P(w), None,
+                       P(ws["feat"]), P(ws["y"]), P(ws["q"]), P(ws["coef"]), P(ws["slab"]), None, P(ws["saved"]), s)
+            task._call("cvf_slab_reduce", lib.cvf_slab_reduce, P(ws["slab"]), ws["rows"], self.n, P(self.grad), None, s)
+            gv = self.grad.view(k, self.per)
+            fl.grad[:self.n_shared] += gv[:, :self.n_shared].sum(0)
+            fl.grad[self.last_w:self.last_w + k * self.h].view(k, self.h).add_(gv[:, self.n_shared:self.n_shared + self.h])
+            fl.grad[self.last_b:self.last_b + k] += gv[:, self.n_shared + self.h]
+        return term
+
+
 class RegAutoEncoderTask(TrainingTask):
     """Regularised autoencoder (arguments, defaults and attributes as core.py:792-816).
 
     Built on the MI355X path: the time-lagged reconstruction loss (``alpha``, ``lag_tau_ae``, core.py:883-885) and the
     transfer-operator eigenfunction regulariser (``gamma``, ``lag_tau_reg > 0``, core.py:973-1036) - the configurations
-    of the reference's notebooks (2d.ipynb:743-760, main.ipynb:452-458) - with ``freeze_encoder`` and the variance /
-    covariance penalties on the latent vector (``eta[1]``, ``eta[2]``, core.py:912-971).  Not built (the constructor raises
-    ``NotImplementedError``): the generator-mode regulariser (``lag_tau_reg = 0`` with ``gamma``) and the gradient-norm
-    penalty ``eta[0]`` (core.py:887-910).
+    of the reference's notebooks (2d.ipynb:743-760, main.ipynb:452-458) - with ``freeze_encoder``, the variance /
+    covariance penalties on the latent vector (``eta[1]``, ``eta[2]``, core.py:912-971) and the gradient-norm penalty of the
+    encoder (``eta[0]``, core.py:887-910: :class:`_EncGradPenalty`, on the eigenfunction task's kernels).  Not built (the
+    constructor raises ``NotImplementedError``): the generator-mode regulariser (``lag_tau_reg = 0`` with ``gamma``).
 
     A step is three launches + the reduction: ``cvf_regae_forward`` (one chain: encoder, then decoder and regulariser
     nets side by side; y on the batch's frames and on their lagged partners, reconstruction error), ``cvf_ef_stats``
@@ -1238,9 +1348,6 @@ class RegAutoEncoderTask(TrainingTask):
             if self.gamma[0] <= self._eps:
                 raise NotImplementedError("RegAutoEncoderTask on MI355X: gamma[0] must be positive when gamma[1] is")
             self._beta = beta
-        if self.eta[0] > self._eps:
-            raise NotImplementedError("RegAutoEncoderTask on MI355X: the encoder gradient-norm regulariser eta[0] (core.py:887-910) "
-                                      "is not built (eta[1], eta[2] are)")
         self._use_enc = max(self.eta[1], self.eta[2]) > self._eps
         assert _dist.world() == 1, "RegAutoEncoderTask runs in one process per model in this round"
         self.init_model_and_optimizer()
@@ -1268,6 +1375,7 @@ class RegAutoEncoderTask(TrainingTask):
         self._ecfg = ecfg
         self._n_enc_layers = len([m for m in self.model.encoder if isinstance(m, torch.nn.Linear)])
         self._ws = {}
+        self._enc_grad = _EncGradPenalty(self) if self.eta[0] > self._eps else None   # (raises here when the encoder does not fit)
 
     # -- the base class builds the flat buffer from mlp_layout(); this model needs the side-by-side chain
     def init_model_and_optimizer(self):
@@ -1355,18 +1463,26 @@ class RegAutoEncoderTask(TrainingTask):
         self._call("cvf_regae_loss_row", lib.cvf_regae_loss_row, P(ws["out2"]), P(ws["loss_vec"]) if use_reg else None, alpha,
                    float(self.gamma[0]) if use_reg else 0.0, float(self.gamma[1]) if use_reg else 0.0, K,
                    P(ws["eterms"]) if use_enc else None, eta1, eta2, P(out), _hip.stream())
+        eg = self._enc_grad if self.eta[0] > self._eps else None
+        rows = None
+        if eg is not None:   # core.py:1092-1095: the gradient-norm penalty of the encoder, on the eigenfunction kernels
+            rows = feat[:B] if idx is None else feat.index_select(0, idx)
         if with_grad:
             if wsum is None:
                 wsum = float(w.sum(dtype=torch.float64))
-            adam = self.optimizer.fused_args() if advance else None
+            adam = self.optimizer.fused_args() if advance and eg is None else None   # (its gradient is added before the update)
             self._call("cvf_regae_backward", lib.cvf_regae_backward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
                        lag_reg if use_reg else 0, K, P(w), P(w_lag) if use_reg else None, alpha / wsum,
                        float(self.gamma[0]) if use_reg else 0.0, P(ws["y"]) if use_reg else None,
                        P(ws["coef"]) if use_reg else None, self._n_enc_layers, P(ws["ecoef"]) if use_enc else None,
                        P(ws["scratch"]), P(fl.grad), P(fl.mask),
                        P(self.optimizer.step_count) if advance else None, adam, _hip.stream())
-            if advance and adam is None:
-                self.optimizer.step(advance=False)
+        if eg is not None:
+            term = eg.run(rows, w, float(self.eta[0]), with_grad and not self.freeze_encoder)
+            out[4 + K] = term
+            out[0] += float(self.eta[0]) * term
+        if with_grad and advance and adam is None:
+            self.optimizer.step(advance=False)
         return out
 
     # -- the reference's public loss functions, evaluated on raw coordinate batches (forward values; the training
@@ -1409,7 +1525,10 @@ class RegAutoEncoderTask(TrainingTask):
             p.grad = gv.clone()
 
     def reg_enc_grad_loss(self, X, weight):
-        raise NotImplementedError("the encoder gradient-norm regulariser (core.py:887-910) is not built on the MI355X path")
+        """core.py:887-910 (forward value)."""
+        if self._enc_grad is None:
+            self._enc_grad = _EncGradPenalty(self)
+        return self._enc_grad.run(self._features(X), self._dev(weight), 1.0, False).to(torch.get_default_dtype())
 
     def _enc_terms(self, X, weight):
         out = self._terms(self._features(X), self._dev(weight), None, 0, 0, 0.0, False, True)

@@ -353,7 +353,10 @@ def test_regae_train_trace(dev, name, tag, rtol):
     np.testing.assert_allclose(out[:4 + K], g["kat"], rtol=rtol_kat)
     if "kat_enc" in g.files:     # variance / covariance penalties on the latent vector (core.py:912-971)
         np.testing.assert_allclose(out[5 + K:], g["kat_enc"], rtol=rtol_kat, atol=1e-9)
-        assert out[4 + K] == 0.0
+        if eta[0] > 0:          # gradient-norm penalty of the encoder (core.py:896-910)
+            np.testing.assert_allclose(out[4 + K], float(g["kat_enc_grad"]), rtol=rtol_kat)
+        else:
+            assert out[4 + K] == 0.0
     np.testing.assert_array_equal(task._cvec_dev.cpu().numpy().astype(np.int64), g["kat_cvec"])
     # absolute tolerance on the scale of the whole gradient (as for the loss_func fixtures above)
     gmax = max(float(np.abs(g["grad/" + n]).max()) for n, _ in model.named_parameters())
@@ -375,7 +378,9 @@ def test_regae_train_trace(dev, name, tag, rtol):
     eig, npl, pen, cvec = task.reg_eigen_loss(X[:nb], task._weights[:nb], X[lag_reg:lag_reg + nb], task._weights[lag_reg:lag_reg + nb])
     np.testing.assert_allclose([float(ae), float(npl), float(pen)] + [float(e) for e in eig], g["kat"][1:], rtol=rtol_kat)
     np.testing.assert_array_equal(np.asarray(cvec), g["kat_cvec"])
-    if "kat_enc" in g.files:
+    if eta[0] > 0:
+        np.testing.assert_allclose(float(task.reg_enc_grad_loss(X[:nb], task._weights[:nb])), float(g["kat_enc_grad"]), rtol=rtol_kat)
+    if "kat_enc" in g.files and eta[1] > 0 and eta[2] > 0:   # (the fixture stores 0 for a penalty that is switched off)
         np.testing.assert_allclose([float(task.reg_enc_norm_loss(X[:nb], task._weights[:nb])),
                                     float(task.reg_enc_orthognal_loss(X[:nb], task._weights[:nb]))], g["kat_enc"], rtol=rtol_kat, atol=1e-9)
     np.random.seed(int(g["seed"]))
@@ -410,8 +415,9 @@ def test_regae_unbuilt_options_fail_loudly(dev):
     kw = dict(eig_weights=[1.0], device=dev, verbose=False)
     with pytest.raises(NotImplementedError):   # generator-mode regulariser
         core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), model, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0, **kw)
-    with pytest.raises(NotImplementedError):   # gradient-norm penalty on the encoder
-        core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), model, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0.5,
+    wide = nn.RegAutoEncoder([2, 40, 1], [1, 8, 2], [1, 8, 1], 1)
+    with pytest.raises(NotImplementedError):   # gradient-norm penalty on an encoder the eigenfunction kernels do not cover
+        core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), wide, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0.5,
                                 eta=[1.0, 0.0, 0.0], **kw)
 
 

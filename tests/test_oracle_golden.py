@@ -153,13 +153,16 @@ def test_regae_train_trace(name, tag):
     eta = [float(v) for v in g["eta"]] if "eta" in g.files else [0.0, 0.0, 0.0]
     en = losses.regae_enc_norm(sd, F[:nb], W[:nb]) if eta[1] > 0 else torch.zeros(())
     eo = losses.regae_enc_orth(sd, F[:nb], W[:nb]) if eta[2] > 0 else torch.zeros(())
-    l0 = alpha * ae + gamma[0] * npl + gamma[1] * pen + eta[1] * en + eta[2] * eo
+    eg = losses.regae_enc_grad(sd, F[:nb], W[:nb]) if eta[0] > 0 else torch.zeros(())
+    l0 = alpha * ae + gamma[0] * npl + gamma[1] * pen + eta[0] * eg + eta[1] * en + eta[2] * eo
     l0.backward()
     tol = TOL[tag]
     got = np.asarray([float(l0), float(ae), float(npl), float(pen)] + [float(e) for e in eig])
     np.testing.assert_allclose(got, g["kat"], **tol)
     if "kat_enc" in g.files:
         np.testing.assert_allclose([float(en), float(eo)], g["kat_enc"], **tol)
+    if "kat_enc_grad" in g.files:
+        np.testing.assert_allclose(float(eg), float(g["kat_enc_grad"]), **tol)
     np.testing.assert_array_equal(np.asarray(cvec), g["kat_cvec"])
     for n, p in sd.items():
         np.testing.assert_allclose(p.grad.numpy(), g["grad/" + n], rtol=tol["rtol"] * 10, atol=tol["atol"] * 10, err_msg=n)

@@ -266,7 +266,8 @@ def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alp
         eig0, npl0, pen0, cvec0 = task.reg_eigen_loss(X, wb, task._traj[lag_reg:lag_reg + nb], task._weights[lag_reg:lag_reg + nb])
         en0 = task.reg_enc_norm_loss(X, wb) if eta[1] > 0 else torch.zeros(())
         eo0 = task.reg_enc_orthognal_loss(X, wb) if eta[2] > 0 else torch.zeros(())
-        l0 = alpha * ae0 + gamma[0] * npl0 + gamma[1] * pen0 + eta[1] * en0 + eta[2] * eo0
+        eg0 = task.reg_enc_grad_loss(X.clone(), wb) if eta[0] > 0 else torch.zeros(())   # (the call sets requires_grad on its input)
+        l0 = alpha * ae0 + gamma[0] * npl0 + gamma[1] * pen0 + eta[0] * eg0 + eta[1] * en0 + eta[2] * eo0
         l0.backward()
         grads0 = {f"grad/{n}": p.grad.detach().numpy().copy() for n, p in model.named_parameters()}
         model.zero_grad(set_to_none=True)
@@ -280,7 +281,7 @@ def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alp
     out = dict(kind="regae_train", e_dims=np.asarray(e_dims), d_dims=np.asarray(d_dims), r_dims=np.asarray(r_dims), K=K, lr=lr,
                batch_size=bs, num_epochs=epochs, seed=seed, alpha=alpha, gamma=np.asarray(gamma, dtype=np.float64),
                eig_w=np.asarray(eig_w, dtype=np.float64), lag_ae=lag_ae, lag_reg=lag_reg, dt=dt, freeze=freeze, traj=traj, w=w,
-               eta=np.asarray(eta, dtype=np.float64), kat_enc=np.asarray([float(en0), float(eo0)]),
+               eta=np.asarray(eta, dtype=np.float64), kat_enc=np.asarray([float(en0), float(eo0)]), kat_enc_grad=float(eg0),
                train_idx=perm[n_test:], test_idx=perm[:n_test], kat_n=nb,
                kat=np.asarray([float(l0), float(ae0), float(npl0), float(pen0)] + [float(e) for e in eig0]),
                kat_cvec=np.asarray(cvec0),
@@ -306,6 +307,17 @@ def run_regae_eta_cases(core, rnn, id2, mol10):
         # ... and alone (no eigenfunction regulariser), three latent components, identity preprocessing
         run_regae_train(core, rnn, "train_regae_id2_k1_eta", id2, [2, 16, 3], [3, 16, 2], [3, 8, 1], 1, dtype, 1.0,
                         [1.0, 5.0], [1.0], 1, 2, 0.5, 5e-3, 100, 2, 705, eta=(0.0, 1.5, 0.7))
+    torch.set_default_dtype(torch.float32)
+
+
+def run_regae_grad_cases(core, rnn, id2, mol10):
+    for dtype in (torch.float32, torch.float64):
+        # the gradient-norm penalty on the encoder (eta_0, core.py:896-910) with the transfer-operator regulariser, main.ipynb shape
+        run_regae_train(core, rnn, "train_regae_mol10_k2_eg", mol10, [30, 20, 20, 20, 2], [2, 10, 10, 30], [2, 10, 10, 1], 2, dtype, 1.0,
+                        [1.0, 10.0], [1.0, 0.5], 0, 1, 0.5, 2e-3, 64, 3, 706, eta=(0.4, 0.0, 0.0))
+        # ... with the two other penalties, three latent components, one hidden layer, identity layer
+        run_regae_train(core, rnn, "train_regae_id2_k1_eg", id2, [2, 16, 3], [3, 16, 2], [3, 8, 1], 1, dtype, 1.0,
+                        [1.0, 5.0], [1.0], 1, 2, 0.5, 5e-3, 100, 2, 707, eta=(0.8, 1.5, 0.7))
     torch.set_default_dtype(torch.float32)
 
 
@@ -387,6 +399,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     core, rnn = import_reference()
     print("reference imported from", core.__file__)
+    if "--regae-grad-only" in sys.argv:
+        t2, w2 = make_2d_traj(600, seed=11)
+        run_regae_grad_cases(core, rnn, dict(pp="identity", traj=t2, w=w2), molecule_case(10, 300, seed=21))
+        return
     if "--regae-eta-only" in sys.argv:
         t2, w2 = make_2d_traj(600, seed=11)
         run_regae_eta_cases(core, rnn, dict(pp="identity", traj=t2, w=w2), molecule_case(10, 300, seed=21))
@@ -426,6 +442,7 @@ def main():
     torch.set_default_dtype(torch.float32)
     run_regae_cases(core, rnn, id2, mol10)
     run_regae_eta_cases(core, rnn, id2, mol10)
+    run_regae_grad_cases(core, rnn, id2, mol10)
 
 
 if __name__ == "__main__":
