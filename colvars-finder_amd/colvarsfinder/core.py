@@ -187,12 +187,12 @@ class _FlatParams:
         L = len(chains[0])
         dims = [chains[0][0][0].in_features] + [lin.out_features for lin, _ in chains[0]]
         hidden = dims[1:-1]
-        if not (2 <= L <= 4) or dims[-1] != 1 or not hidden or max(hidden) > max(_hip.EF_HIDDEN_WIDTHS):
+        if not (2 <= L <= 6) or dims[-1] != 1 or not hidden or max(hidden) > max(_hip.EF_HIDDEN_WIDTHS):
             return False
         for c in chains:
             if [c[0][0].in_features] + [lin.out_features for lin, _ in c] != dims or [a for _, a in c] != [True] * (L - 1) + [False]:
                 return False
-        H = min(w for w in _hip.EF_HIDDEN_WIDTHS if w >= max(hidden) and (w < 24 or L - 1 >= 2))
+        H = min(w for w in _hip.ef_widths(L - 1) if w >= max(hidden))
         if all(h == H for h in hidden):
             return False                      # already a kernel shape: plain layout
         pdims = [dims[0]] + [H] * (L - 1) + [1]
@@ -515,9 +515,10 @@ class EigenFunctionTask(TrainingTask):
             d = self._flat.desc
             raise NotImplementedError(
                 "EigenFunctionTask on MI355X: no kernel instance for nets with layer widths "
-                f"{[d.dims[i] for i in range(d.n_layers + 1)]}. Supported: 1 to 3 hidden layers of at most "
-                f"{max(_hip.EF_HIDDEN_WIDTHS)} units each (kernel widths {_hip.EF_HIDDEN_WIDTHS}; other widths are zero-padded to "
-                f"the next one), scalar output, Tanh between layers, k <= {_hip.MAX_NETS} (csrc/ef_mfma.hip: ef_shape / ef_dispatch).")
+                f"{[d.dims[i] for i in range(d.n_layers + 1)]}. Supported: 1 to 5 hidden layers of at most "
+                f"{max(_hip.EF_HIDDEN_WIDTHS)} units each (kernel widths {_hip.EF_HIDDEN_WIDTHS}, for 4 or 5 hidden layers 20 and 32; "
+                f"other widths are zero-padded to the next one), scalar output, Tanh between layers, k <= {_hip.MAX_NETS} "
+                "(csrc/ef_mfma.hip: ef_shape / ef_dispatch).")
 
         # The frames stay resident in HBM (core.py:343-344 keeps CPU copies and moves every batch, core.py:500).  One process:
         # the whole trajectory.  Data-parallel job (one process per GPU): NOT here - train() uploads only the rows of this

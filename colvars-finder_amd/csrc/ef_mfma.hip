@@ -1261,6 +1261,10 @@ bool ef_dispatch(int H, int NH, F&& f) {
   EF_CASE(20, 1) EF_CASE(20, 2) EF_CASE(20, 3)
   EF_CASE(24, 2) EF_CASE(24, 3)
   EF_CASE(32, 2) EF_CASE(32, 3)
+  // four and five hidden layers (e.g. regulariser o encoder chains of RegAutoEncoderTask's generator mode): two widths,
+  // narrower nets are zero-padded to them by the host
+  EF_CASE(20, 4) EF_CASE(20, 5)
+  EF_CASE(32, 4) EF_CASE(32, 5)
 #undef EF_CASE
   return false;
 }

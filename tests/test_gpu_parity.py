@@ -812,3 +812,43 @@ def test_weighted_alignment_rejects_layouts_it_was_not_built_for(dev):
         pp.AlignFeatureLayer(80, list(range(80)), ref, [("position", tuple(range(80)))], False, align_weights=np.ones(80))
     with pytest.raises(AssertionError, match="non-negative"):
         pp.AlignFeatureLayer(5, list(range(5)), ref[:5], [("position", (0, 1))], False, align_weights=[1, -1, 1, 1, 1])
+
+
+@pytest.mark.parametrize("dims,mixed", [([27, 20, 20, 20, 20, 1], False), ([27, 12, 12, 10, 8, 8, 1], False), ([20, 16, 16, 16, 16, 16, 1], True),
+                                         ([27, 32, 24, 24, 32, 1], False)])
+def test_four_and_five_hidden_layers_generator_step_vs_oracle(dev, dims, mixed):
+    """Nets of four and five hidden layers (kernel widths 20 and 32 at that depth, narrower / mixed widths zero-padded): loss,
+    eigenvalues and every parameter gradient of a generator-mode step against the fp64 oracle (autograd through linalg.svd)."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    n_atoms, B, k = (10, 150, 2) if mixed else (9, 130, 2)
+    traj, w, ref = make_molecule_traj(n_atoms, B, seed=1700 + len(dims), scale=2.0, sigma=0.3)
+    align = [0, 1, 2, 4, 5, 8] if mixed else list(range(n_atoms))
+    spec = dict(align_idx=align, ref_pos=ref[align], features=MIXED if mixed else [("position", tuple(range(n_atoms)))], use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    assert layer.d_r == dims[0]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(11))
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    a = torch.tensor(diag_coeff_for(n_atoms, 3), dtype=torch.float32)
+    task = core.EigenFunctionTask(Traj(traj, w, 1.0), layer, model, "/tmp/cvf_test", 12.0, [1.0, 0.6], diag_coeff=a, beta=1.2, lag_tau=0,
+                                  k=k, device=dev, verbose=False, save_model_every_step=0)
+    loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+    X = torch.tensor(traj, dtype=torch.float64, requires_grad=True)
+    lo, eo, no, po, co = losses.ef_loss(sd, k, oracle_layer(spec), X, torch.tensor(w), alpha=12.0, eig_w=[1.0, 0.6], diag_coeff=a.double(), beta=1.2)
+    lo.backward()
+    torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=RTOL64)
+    assert list(cvec) == list(co)
+    want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+    # and a few optimiser steps run (the fused Adam path of the deeper instances)
+    np.random.seed(1)
+    task.num_epochs, task.batch_size = 2, 50
+    task.train()
+    assert np.isfinite(task.train_loss_df.to_numpy()).all()
