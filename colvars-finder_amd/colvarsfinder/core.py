@@ -1304,6 +1304,101 @@ class _EncGradPenalty:
         return term
 
 
+class _RegGenerator:
+    """The eigenfunction regulariser in GENERATOR mode (``gamma`` with ``lag_tau_reg = 0``, the constructor's default;
+    core.py:990,1008-1022): y_i = reg_i(encoder(r(x))) differentiated with respect to the coordinates x, the same loss as
+    :class:`EigenFunctionTask`'s generator mode with ``diag_coeff = 1`` (core.py:851).
+
+    The K chains reg_i o encoder ARE scalar nets d_r -> .. -> 1: the encoder's hidden layers (shared), one merged layer
+    (the encoder's last Linear has no activation, so it folds into the regulariser's first: W = W_r1 W_e, b = W_r1 b_e + b_r1),
+    the regulariser's remaining layers.  They are laid out as an :class:`EigenFunctions` model of K nets, every hidden layer
+    zero-padded to one kernel width, and handed to an inner ``EigenFunctionTask`` - so the step runs on that task's kernels
+    (alignment derivative, forward, q = J J^T g, batch sums, loss tail, backward), whichever it picks for the shape.  The
+    gradient with respect to the virtual parameters goes back to the module's parameters through the (tiny) map that built
+    them, by autograd on the host-side torch graph: shared layers summed over i, the merged layer by the product rule."""
+
+    def __init__(self, task, beta):
+        from .nn import _chain_layers
+        m = task.model
+        self.task, self.K = task, m.num_reg
+        self.enc = _chain_layers(m.encoder)
+        self.regs = [_chain_layers(r) for r in m.reg]
+        Le, Lr = len(self.enc), len(self.regs[0])
+        ok = [a for _, a in self.enc] == [True] * (Le - 1) + [False] and all(
+            len(r) == Lr and [a for _, a in r] == [True] * (Lr - 1) + [False] and r[-1][0].out_features == 1 for r in self.regs)
+        if not ok or Lr < 2:
+            raise NotImplementedError("generator-mode regulariser on MI355X: encoder and regulariser nets must be Linear/Tanh chains "
+                                      "ending in a Linear layer, the regulariser nets with at least one hidden layer")
+        d_r = self.enc[0][0].in_features
+        hidden = [lin.out_features for lin, _ in self.enc[:-1]] + [lin.out_features for lin, _ in self.regs[0][:-1]]
+        for r in self.regs:
+            assert [lin.out_features for lin, _ in r] == [lin.out_features for lin, _ in self.regs[0]], "regulariser nets differ in shape"
+        widths = [w for w in _hip.ef_widths(len(hidden)) if w >= max(hidden)] if 1 <= len(hidden) <= 5 else []
+        if not widths or self.K > _hip.MAX_NETS:
+            raise NotImplementedError(
+                f"generator-mode regulariser on MI355X: the chain regulariser o encoder has hidden widths {hidden}; the eigenfunction "
+                f"kernels take 1 to 5 hidden layers of at most {max(_hip.EF_HIDDEN_WIDTHS)} units and at most {_hip.MAX_NETS} nets "
+                "(use lag_tau_reg > 0 - the transfer operator - for other shapes)")
+        self.H = H = widths[0]
+        self.pdims = [d_r] + [H] * len(hidden) + [1]
+        model = EigenFunctions(self.pdims, self.K)
+        tok = np.zeros((4,) + tuple(np.asarray(task._traj_host).shape[1:]), dtype=np.float32)
+
+        class _Tok:
+            trajectory, weights, dt, n_frames = tok, np.ones(4), task.traj_dt, 4
+
+        if isinstance(task.preprocessing_layer, AlignFeatureLayer):   # (a frame the alignment accepts: the reference itself)
+            _Tok.trajectory = np.zeros_like(tok) + np.random.RandomState(0).normal(size=tok.shape[1:]).astype(np.float32)
+        g0, g1 = float(task.gamma[0]), float(task.gamma[1])
+        self.inner = EigenFunctionTask(_Tok, task.preprocessing_layer, model, task.model_path, g1 / g0, [float(v) for v in task._eig_w],
+                                       diag_coeff=None, beta=beta, lag_tau=0, learning_rate=task.learning_rate, k=self.K,
+                                       batch_size=task.batch_size, device=task.device, verbose=False, save_model_every_step=0)
+        self.n = self.inner._flat.n
+
+    def _params(self):
+        ps = [p for lin, _ in self.enc for p in (lin.weight, lin.bias)]
+        for r in self.regs:
+            ps += [p for lin, _ in r for p in (lin.weight, lin.bias)]
+        return ps
+
+    def _theta(self):
+        """The virtual parameters as a (differentiable) function of the module's: flat, in the inner model's order."""
+        pd, out = self.pdims, []
+        We, be = self.enc[-1][0].weight, self.enc[-1][0].bias
+        for i in range(self.K):
+            r = self.regs[i]
+            layers = [(lin.weight, lin.bias) for lin, _ in self.enc[:-1]]
+            layers.append((r[0][0].weight @ We, r[0][0].weight @ be + r[0][0].bias))
+            layers += [(lin.weight, lin.bias) for lin, _ in r[1:]]
+            for l, (W, b) in enumerate(layers):
+                fo, fi = pd[l + 1], pd[l]
+                out.append(torch.nn.functional.pad(W, (0, fi - W.shape[1], 0, fo - W.shape[0])).reshape(-1))
+                out.append(torch.nn.functional.pad(b, (0, fo - b.shape[0])))
+        return torch.cat(out)
+
+    def forward(self, X, w, with_grad):
+        """Loss terms of the batch ``X`` (raw coordinates on the device): returns the inner task's device loss vector
+        ``[npl + (gamma_1/gamma_0) pen, npl, pen, eig_1..K sorted, cvec]`` (fp64)."""
+        inner = self.inner
+        with torch.enable_grad() if with_grad else torch.no_grad():
+            self._tv = self._theta()
+        inner._flat.theta.copy_(self._tv.detach())
+        inner._flat.repack()
+        self._ws = inner._forward(X, w)
+        return self._ws.loss_out
+
+    def backward(self, w, scale):
+        """Adds ``scale`` * d(npl + (gamma_1/gamma_0) pen)/d(parameter) to the module parameters' slices of the flat gradient."""
+        inner, task = self.inner, self.task
+        inner._backward(self._ws, w, advance=False, fuse_adam=False)
+        views = {id(p): gv for p, _, gv in task._flat.views}
+        ps = [p for p in self._params() if not (task.freeze_encoder and any(p is q for lin, _ in self.enc for q in (lin.weight, lin.bias)))]
+        grads = torch.autograd.grad(self._tv, ps, grad_outputs=inner._flat.grad * scale, allow_unused=True)
+        for p, g in zip(ps, grads):
+            if g is not None:
+                views[id(p)].add_(g)
+
+
 class RegAutoEncoderTask(TrainingTask):
     """Regularised autoencoder (arguments, defaults and attributes as core.py:792-816).
 
@@ -1311,8 +1406,9 @@ class RegAutoEncoderTask(TrainingTask):
     transfer-operator eigenfunction regulariser (``gamma``, ``lag_tau_reg > 0``, core.py:973-1036) - the configurations
     of the reference's notebooks (2d.ipynb:743-760, main.ipynb:452-458) - with ``freeze_encoder``, the variance /
     covariance penalties on the latent vector (``eta[1]``, ``eta[2]``, core.py:912-971) and the gradient-norm penalty of the
-    encoder (``eta[0]``, core.py:887-910: :class:`_EncGradPenalty`, on the eigenfunction task's kernels).  Not built (the
-    constructor raises ``NotImplementedError``): the generator-mode regulariser (``lag_tau_reg = 0`` with ``gamma``).
+    encoder (``eta[0]``, core.py:887-910: :class:`_EncGradPenalty`, on the eigenfunction task's kernels) and the
+    regulariser in generator mode (``lag_tau_reg = 0``, core.py:990,1008-1022: :class:`_RegGenerator`, an inner
+    :class:`EigenFunctionTask` over the chains regulariser o encoder).
 
     A step is three launches + the reduction: ``cvf_regae_forward`` (one chain: encoder, then decoder and regulariser
     nets side by side; y on the batch's frames and on their lagged partners, reconstruction error), ``cvf_ef_stats``
@@ -1343,9 +1439,6 @@ class RegAutoEncoderTask(TrainingTask):
         self._use_reg = self.gamma[0] + self.gamma[1] > self._eps
         if self._use_reg:
             assert self.num_reg > 0, 'number of eigenfunctions must be positive!'
-            if self.lag_idx == 0:
-                raise NotImplementedError("RegAutoEncoderTask on MI355X: the generator-mode regulariser (lag_tau_reg = 0) is not "
-                                          "built; use lag_tau_reg > 0 (transfer operator) or EigenFunctionTask")
             if self.gamma[0] <= self._eps:
                 raise NotImplementedError("RegAutoEncoderTask on MI355X: gamma[0] must be positive when gamma[1] is")
             self._beta = beta
@@ -1377,6 +1470,10 @@ class RegAutoEncoderTask(TrainingTask):
         self._n_enc_layers = len([m for m in self.model.encoder if isinstance(m, torch.nn.Linear)])
         self._ws = {}
         self._enc_grad = _EncGradPenalty(self) if self.eta[0] > self._eps else None   # (raises here when the encoder does not fit)
+        # generator-mode regulariser (lag_tau_reg = 0): needs the coordinates themselves (its derivative runs through r(x))
+        self._traj_host = traj
+        self._gen = _RegGenerator(self, beta) if self._use_reg and self.lag_idx == 0 else None
+        self._traj = _hip.upload_f32(traj, self.device) if self._gen is not None else None
 
     # -- the base class builds the flat buffer from mlp_layout(); this model needs the side-by-side chain
     def init_model_and_optimizer(self):
@@ -1433,15 +1530,19 @@ class RegAutoEncoderTask(TrainingTask):
             self._ws[B] = ws
         return ws
 
-    def _step(self, feat, idx, w, w_lag, lag_ae, lag_reg, with_grad, advance=False, wsum=None, out=None):
+    def _step(self, feat, idx, w, w_lag, lag_ae, lag_reg, with_grad, advance=False, wsum=None, out=None, X=None):
         """Loss terms (and, with ``with_grad``, gradient + optimizer step) of one batch: rows ``idx`` of ``feat``
         (``None``: rows 0..B-1), targets at ``+lag_ae``, lagged partners at ``+lag_reg``.  ``wsum``: the batch's weight
         sum when the caller knows it (static batches), else one host read.  Returns (or fills ``out`` with) the device
-        vector [loss, ae, npl, pen, eig_1..K, 0, enc_norm, enc_orth] (fp64)."""
+        vector [loss, ae, npl, pen, eig_1..K, enc_grad, enc_norm, enc_orth] (fp64).  ``X``: the batch's raw coordinates for the
+        generator-mode regulariser (``None``: rows ``idx`` of the resident trajectory)."""
         lib, fl, P = _hip.lib(), self._flat, _hip.ptr
         B, K = int(w.shape[0]), self.num_reg
         ws = self._workspace(B)
         use_reg = self._use_reg and K > 0
+        gen = self._gen if use_reg and lag_reg == 0 else None    # generator mode: the regulariser runs on the eigenfunction task's kernels
+        assert not (use_reg and lag_reg == 0 and gen is None), 'generator-mode regulariser needs gamma and lag_tau_reg = 0 at construction'
+        use_reg = use_reg and gen is None     # (from here on: the transfer-operator regulariser inside the chain kernels)
         alpha = float(self.alpha) if self.alpha > self._eps else 0.0
         use_enc = self._use_enc
         eta1 = float(self.eta[1]) if self.eta[1] > self._eps else 0.0
@@ -1471,13 +1572,21 @@ class RegAutoEncoderTask(TrainingTask):
         if with_grad:
             if wsum is None:
                 wsum = float(w.sum(dtype=torch.float64))
-            adam = self.optimizer.fused_args() if advance and eg is None else None   # (its gradient is added before the update)
+            adam = self.optimizer.fused_args() if advance and eg is None and gen is None else None   # (their gradients are added before the update)
             self._call("cvf_regae_backward", lib.cvf_regae_backward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
                        lag_reg if use_reg else 0, K, P(w), P(w_lag) if use_reg else None, alpha / wsum,
                        float(self.gamma[0]) if use_reg else 0.0, P(ws["y"]) if use_reg else None,
                        P(ws["coef"]) if use_reg else None, self._n_enc_layers, P(ws["ecoef"]) if use_enc else None,
                        P(ws["scratch"]), P(fl.grad), P(fl.mask),
                        P(self.optimizer.step_count) if advance else None, adam, _hip.stream())
+        if gen is not None:
+            lv = gen.forward(X if X is not None else (self._traj[:B] if idx is None else self._traj.index_select(0, idx)), w, with_grad)
+            out[2:4] = lv[1:3]
+            out[4:4 + K] = lv[3:3 + K]
+            out[0] += float(self.gamma[0]) * lv[1] + float(self.gamma[1]) * lv[2]
+            self._cvec_dev = lv[3 + K:3 + 2 * K]
+            if with_grad:
+                gen.backward(w, float(self.gamma[0]))
         if eg is not None:
             term = eg.run(rows, w, float(self.eta[0]), with_grad and not self.freeze_encoder)
             out[4 + K] = term
@@ -1508,7 +1617,13 @@ class RegAutoEncoderTask(TrainingTask):
 
     def reg_eigen_loss(self, X, weight, X_lagged, weight_lagged):
         """core.py:973-1036 (transfer operator): ``(eig_vals, non_penalty_loss, penalty, cvec)``."""
-        assert self.num_reg > 0 and self.lag_idx > 0, 'needs regularisers and lag_tau_reg > 0'
+        assert self.num_reg > 0, 'needs regularisers'
+        if self.lag_idx == 0:   # generator mode (core.py:990,1008-1022): X_lagged / weight_lagged are not used
+            assert self._gen is not None, 'generator-mode regulariser needs gamma at construction'
+            Xd = _hip.upload_f32(torch.as_tensor(X).detach(), self.device)
+            lv = self._gen.forward(Xd, self._dev(weight), False)
+            dt, K = torch.get_default_dtype(), self.num_reg
+            return lv[3:3 + K].to(dt).cpu(), lv[1].to(dt), lv[2].to(dt), lv[3 + K:3 + 2 * K].cpu().to(torch.long).numpy()
         B = int(torch.as_tensor(X).shape[0])
         feat = torch.cat([self._features(X), self._features(X_lagged)])
         gam, self.gamma = self.gamma, (self.gamma if self._use_reg else [1.0, 1.0])

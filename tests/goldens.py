@@ -12,7 +12,8 @@ KAT_CASES = ["kat_gen_id2_k1", "kat_gen_id2_k3", "kat_tr_id2_k2", "kat_gen_mol10
 EF_TRAIN_CASES = ["train_gen_id2_k1", "train_tr_id2_k2", "train_gen_mol22_k3", "train_tr_mol10_k2"]
 AE_TRAIN_CASES = ["train_ae_id2", "train_ae_mol22"]
 REGAE_TRAIN_CASES = ["train_regae_id2_k1", "train_regae_mol10_k2", "train_regae_id2_k2_frozen", "train_regae_mol10_k2_eta",
-                     "train_regae_id2_k1_eta", "train_regae_mol10_k2_eg", "train_regae_id2_k1_eg"]
+                     "train_regae_id2_k1_eta", "train_regae_mol10_k2_eg", "train_regae_id2_k1_eg", "train_regae_id2_k1_gen",
+                     "train_regae_mol10_k2_gen", "train_regae_id2_k2_gen_frozen"]
 
 
 def load(name, tag):

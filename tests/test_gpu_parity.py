@@ -338,7 +338,8 @@ def test_regae_train_trace(dev, name, tag, rtol):
     task = core.RegAutoEncoderTask(Traj(traj, np.array(g["w"]), dt), layer, model, "/tmp/cvf_test", eig_weights=[float(v) for v in g["eig_w"]],
                                    learning_rate=float(g["lr"]), batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]),
                                    alpha=float(g["alpha"]), gamma=[float(v) for v in g["gamma"]], eta=eta, lag_tau_ae=lag_ae * dt,
-                                   lag_tau_reg=lag_reg * dt, freeze_encoder=frozen, device=dev, verbose=False, save_model_every_step=0)
+                                   lag_tau_reg=lag_reg * dt, beta=float(g["beta"]) if "beta" in g.files else 1.0, freeze_encoder=frozen,
+                                   device=dev, verbose=False, save_model_every_step=0)
     # the module's parameters alias the flat chain buffer (strided blocks for the side-by-side layers): values unchanged
     for n, p in model.state_dict().items():
         np.testing.assert_array_equal(p.cpu().numpy(), np.array(g["sd/" + n], dtype=np.float32), err_msg=n)
@@ -350,7 +351,10 @@ def test_regae_train_trace(dev, name, tag, rtol):
     task.backward()
     # (the fp32 fixtures carry the reference's own cancellation noise in sum w (y' - y)^2: 1e-3 against its fp64 run here)
     rtol_kat = rtol if tag == "f64" else 10 * rtol
-    np.testing.assert_allclose(out[:4 + K], g["kat"], rtol=rtol_kat)
+    # (generator mode: the reference's fp32 run differentiates through linalg.svd in fp32 - 0.4 % off its own fp64 run in the
+    #  Dirichlet term of the molecule fixture; that distance is allowed on top, the fp64 fixture pins the exact value)
+    kat_noise = 2.0 * np.abs(g["kat"] - goldens.load(name, "f64")["kat"]) if (tag == "f32" and lag_reg == 0) else 0.0
+    assert np.all(np.abs(out[:4 + K] - g["kat"]) <= rtol_kat * np.abs(g["kat"]) + kat_noise)
     if "kat_enc" in g.files:     # variance / covariance penalties on the latent vector (core.py:912-971)
         np.testing.assert_allclose(out[5 + K:], g["kat_enc"], rtol=rtol_kat, atol=1e-9)
         if eta[0] > 0:          # gradient-norm penalty of the encoder (core.py:896-910)
@@ -376,7 +380,8 @@ def test_regae_train_trace(dev, name, tag, rtol):
     X = torch.tensor(traj)
     ae = task.weighted_MSE_loss(X[:nb], X[lag_ae:lag_ae + nb], task._weights[:nb])
     eig, npl, pen, cvec = task.reg_eigen_loss(X[:nb], task._weights[:nb], X[lag_reg:lag_reg + nb], task._weights[lag_reg:lag_reg + nb])
-    np.testing.assert_allclose([float(ae), float(npl), float(pen)] + [float(e) for e in eig], g["kat"][1:], rtol=rtol_kat)
+    pub = np.asarray([float(ae), float(npl), float(pen)] + [float(e) for e in eig])
+    assert np.all(np.abs(pub - g["kat"][1:]) <= rtol_kat * np.abs(g["kat"][1:]) + (kat_noise[1:] if np.ndim(kat_noise) else 0.0))
     np.testing.assert_array_equal(np.asarray(cvec), g["kat_cvec"])
     if eta[0] > 0:
         np.testing.assert_allclose(float(task.reg_enc_grad_loss(X[:nb], task._weights[:nb])), float(g["kat_enc_grad"]), rtol=rtol_kat)
@@ -393,6 +398,14 @@ def test_regae_train_trace(dev, name, tag, rtol):
         first32, first64 = g["train_loss"][0, 0], g64["train_loss"][0, 0]
         np.testing.assert_allclose(tr[0, 0], first32, rtol=rtol_kat, atol=rtol + 2.0 * np.abs(first32 - first64).max())
         np.testing.assert_allclose(tr[0, 0], first64, rtol=rtol_kat, atol=rtol)     # ... and the exact first step
+        return
+    if tag == "f32" and lag_reg == 0:
+        # generator mode: the reference's fp32 run carries its own rounding of the Dirichlet term (autograd through the nets
+        # in fp32: 2e-4 from its fp64 run in single steps) - allow that distance on top, entry by entry; the fp64 fixture
+        # (the exact answer) pins the trace at the plain tolerance
+        n32tr, n32te = 2.0 * np.abs(g["train_loss"] - g64["train_loss"]), 2.0 * np.abs(g["test_loss"] - g64["test_loss"])
+        assert np.all(np.abs(tr - g["train_loss"]) <= rtol + rtol * np.abs(g["train_loss"]) + n32tr)
+        assert np.all(np.abs(te - g["test_loss"]) <= rtol + rtol * np.abs(g["test_loss"]) + n32te)
         return
     np.testing.assert_allclose(tr, g["train_loss"], rtol=rtol, atol=rtol)
     np.testing.assert_allclose(te, g["test_loss"], rtol=rtol, atol=rtol)
@@ -413,8 +426,10 @@ def test_regae_unbuilt_options_fail_loudly(dev):
     traj, w = make_2d_traj(200, seed=3)
     model = nn.RegAutoEncoder([2, 8, 1], [1, 8, 2], [1, 8, 1], 1)
     kw = dict(eig_weights=[1.0], device=dev, verbose=False)
-    with pytest.raises(NotImplementedError):   # generator-mode regulariser
-        core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), model, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0, **kw)
+    wide_reg = nn.RegAutoEncoder([2, 8, 1], [1, 8, 2], [1, 40, 1], 1)
+    with pytest.raises(NotImplementedError):   # generator-mode regulariser on a chain the eigenfunction kernels do not cover
+        core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), wide_reg, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0, **kw)
+    core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), model, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0, **kw)   # built
     wide = nn.RegAutoEncoder([2, 40, 1], [1, 8, 2], [1, 8, 1], 1)
     with pytest.raises(NotImplementedError):   # gradient-norm penalty on an encoder the eigenfunction kernels do not cover
         core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), wide, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0.5,

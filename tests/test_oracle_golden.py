@@ -148,8 +148,13 @@ def test_regae_train_trace(name, tag):
     nb = int(g["kat_n"])
     sd = {n: p.clone().requires_grad_(True) for n, p in sd0.items()}
     ae = losses.regae_mse(sd, F[:nb], F[lag_ae:lag_ae + nb], W[:nb])
-    eig, npl, pen, cvec = losses.regae_eigen_loss(sd, K, F[:nb], W[:nb], F[lag_reg:lag_reg + nb], W[lag_reg:lag_reg + nb],
-                                                  eig_w=eig_w, lag_idx=lag_reg, dt=dt)
+    beta = float(g["beta"]) if "beta" in g.files else 1.0
+    if lag_reg == 0:   # generator-mode regulariser: differentiated with respect to the raw coordinates
+        Xg = torch.tensor(np.array(g["traj"])[:nb]).to(dtype).requires_grad_(True)
+        eig, npl, pen, cvec = losses.regae_eigen_loss_generator(sd, K, pp, Xg, W[:nb], eig_w=eig_w, beta=beta)
+    else:
+        eig, npl, pen, cvec = losses.regae_eigen_loss(sd, K, F[:nb], W[:nb], F[lag_reg:lag_reg + nb], W[lag_reg:lag_reg + nb],
+                                                      eig_w=eig_w, lag_idx=lag_reg, dt=dt)
     eta = [float(v) for v in g["eta"]] if "eta" in g.files else [0.0, 0.0, 0.0]
     en = losses.regae_enc_norm(sd, F[:nb], W[:nb]) if eta[1] > 0 else torch.zeros(())
     eo = losses.regae_enc_orth(sd, F[:nb], W[:nb]) if eta[2] > 0 else torch.zeros(())
@@ -169,7 +174,7 @@ def test_regae_train_trace(name, tag):
     np.random.seed(int(g["seed"]))
     res = train.train_regae(sd0, K, pp, np.array(g["traj"]), np.array(g["w"]), eig_w=eig_w, alpha=alpha, gamma=gamma, eta=eta,
                             lag_ae_idx=lag_ae, lag_idx=lag_reg, dt=dt, learning_rate=float(g["lr"]),
-                            batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]), freeze_encoder=bool(g["freeze"]))
+                            batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]), freeze_encoder=bool(g["freeze"]), beta=beta)
     np.testing.assert_array_equal(res["train_idx"], g["train_idx"])
     np.testing.assert_array_equal(res["test_idx"], g["test_idx"])
     # fp64: the restatement is exact (1e-9).  fp32: sum w (y' - y)^2 with y' ~ y amplifies every reordering of fp32

@@ -246,7 +246,7 @@ def run_ae_train(core, rnn, name, case, e_dims, d_dims, dtype, lr, bs, epochs, s
 
 
 def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alpha, gamma, eig_w, lag_ae, lag_reg, dt, lr, bs,
-                    epochs, seed, freeze=False, eta=(0.0, 0.0, 0.0)):
+                    epochs, seed, freeze=False, eta=(0.0, 0.0, 0.0), beta=1.0):
     torch.set_default_dtype(dtype)
     g = torch.Generator().manual_seed(seed)
     sd0 = nnref.init_regautoencoder(e_dims, d_dims, r_dims, K, g, dtype)
@@ -257,13 +257,14 @@ def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alp
     with tempfile.TemporaryDirectory() as tmp:
         task = core.RegAutoEncoderTask(Traj(traj, w, dt), pp, model, tmp, eig_weights=eig_w, learning_rate=lr, batch_size=bs,
                                        num_epochs=epochs, test_ratio=0.2, alpha=alpha, gamma=gamma, eta=list(eta),
-                                       lag_tau_ae=lag_ae * dt, lag_tau_reg=lag_reg * dt, freeze_encoder=freeze, verbose=False,
+                                       lag_tau_ae=lag_ae * dt, lag_tau_reg=lag_reg * dt, beta=beta, freeze_encoder=freeze, verbose=False,
                                        save_model_every_step=0)
         # known answer at the initial weights: the loss terms of the first 200 frames + all parameter gradients
         nb = min(200, traj.shape[0] - max(lag_ae, lag_reg))
         X, wb = task._traj[:nb], task._weights[:nb]
         ae0 = task.weighted_MSE_loss(X, task._traj[lag_ae:lag_ae + nb], wb)
-        eig0, npl0, pen0, cvec0 = task.reg_eigen_loss(X, wb, task._traj[lag_reg:lag_reg + nb], task._weights[lag_reg:lag_reg + nb])
+        Xg = X.clone() if lag_reg == 0 else X     # (generator mode sets requires_grad on its input, core.py:990)
+        eig0, npl0, pen0, cvec0 = task.reg_eigen_loss(Xg, wb, task._traj[lag_reg:lag_reg + nb], task._weights[lag_reg:lag_reg + nb])
         en0 = task.reg_enc_norm_loss(X, wb) if eta[1] > 0 else torch.zeros(())
         eo0 = task.reg_enc_orthognal_loss(X, wb) if eta[2] > 0 else torch.zeros(())
         eg0 = task.reg_enc_grad_loss(X.clone(), wb) if eta[0] > 0 else torch.zeros(())   # (the call sets requires_grad on its input)
@@ -281,7 +282,7 @@ def run_regae_train(core, rnn, name, case, e_dims, d_dims, r_dims, K, dtype, alp
     out = dict(kind="regae_train", e_dims=np.asarray(e_dims), d_dims=np.asarray(d_dims), r_dims=np.asarray(r_dims), K=K, lr=lr,
                batch_size=bs, num_epochs=epochs, seed=seed, alpha=alpha, gamma=np.asarray(gamma, dtype=np.float64),
                eig_w=np.asarray(eig_w, dtype=np.float64), lag_ae=lag_ae, lag_reg=lag_reg, dt=dt, freeze=freeze, traj=traj, w=w,
-               eta=np.asarray(eta, dtype=np.float64), kat_enc=np.asarray([float(en0), float(eo0)]), kat_enc_grad=float(eg0),
+               eta=np.asarray(eta, dtype=np.float64), kat_enc=np.asarray([float(en0), float(eo0)]), kat_enc_grad=float(eg0), beta=beta,
                train_idx=perm[n_test:], test_idx=perm[:n_test], kat_n=nb,
                kat=np.asarray([float(l0), float(ae0), float(npl0), float(pen0)] + [float(e) for e in eig0]),
                kat_cvec=np.asarray(cvec0),
@@ -318,6 +319,21 @@ def run_regae_grad_cases(core, rnn, id2, mol10):
         # ... with the two other penalties, three latent components, one hidden layer, identity layer
         run_regae_train(core, rnn, "train_regae_id2_k1_eg", id2, [2, 16, 3], [3, 16, 2], [3, 8, 1], 1, dtype, 1.0,
                         [1.0, 5.0], [1.0], 1, 2, 0.5, 5e-3, 100, 2, 707, eta=(0.8, 1.5, 0.7))
+    torch.set_default_dtype(torch.float32)
+
+
+def run_regae_generator_cases(core, rnn, id2, mol10):
+    for dtype in (torch.float32, torch.float64):
+        # the eigenfunction regulariser in GENERATOR mode (lag_tau_reg = 0, the constructor's default; core.py:1008-1022):
+        # regulariser o encoder o r(x) differentiated with respect to the coordinates.  2d.ipynb shape, K = 1
+        run_regae_train(core, rnn, "train_regae_id2_k1_gen", id2, [2, 20, 20, 20, 1], [1, 20, 20, 2], [1, 20, 20, 1], 1, dtype, 1.0,
+                        [1.0, 20.0], [1.0], 2, 0, 0.5, 5e-3, 100, 3, 711, beta=1.5)
+        # main.ipynb shape through the alignment layer, K = 2, with the encoder's gradient-norm penalty on top
+        run_regae_train(core, rnn, "train_regae_mol10_k2_gen", mol10, [30, 20, 20, 20, 2], [2, 10, 10, 30], [2, 10, 10, 1], 2, dtype, 1.0,
+                        [1.0, 10.0], [1.0, 0.5], 0, 0, 0.5, 2e-3, 64, 3, 712, eta=(0.2, 0.0, 0.0), beta=1.0)
+        # a shallow encoder (three hidden layers in the chain regulariser o encoder), frozen
+        run_regae_train(core, rnn, "train_regae_id2_k2_gen_frozen", id2, [2, 12, 2], [2, 12, 12, 2], [2, 12, 12, 1], 2, dtype, 0.5,
+                        [2.0, 8.0], [1.0, 0.3], 1, 0, 0.5, 5e-3, 100, 2, 713, freeze=True)
     torch.set_default_dtype(torch.float32)
 
 
@@ -399,6 +415,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     core, rnn = import_reference()
     print("reference imported from", core.__file__)
+    if "--regae-generator-only" in sys.argv:
+        t2, w2 = make_2d_traj(600, seed=11)
+        run_regae_generator_cases(core, rnn, dict(pp="identity", traj=t2, w=w2), molecule_case(10, 300, seed=21))
+        return
     if "--regae-grad-only" in sys.argv:
         t2, w2 = make_2d_traj(600, seed=11)
         run_regae_grad_cases(core, rnn, dict(pp="identity", traj=t2, w=w2), molecule_case(10, 300, seed=21))
@@ -443,6 +463,7 @@ def main():
     run_regae_cases(core, rnn, id2, mol10)
     run_regae_eta_cases(core, rnn, id2, mol10)
     run_regae_grad_cases(core, rnn, id2, mol10)
+    run_regae_generator_cases(core, rnn, id2, mol10)
 
 
 if __name__ == "__main__":
