@@ -9,8 +9,8 @@ input gradients (K4a), q = J A J^T g (K2/K3), batch sums (K5), loss tail, parame
 Adam (K6).  With N > 1 (one process per GPU, launched by torch.distributed.run) every rank owns its own
 block of the frames and the two all-reduces of SURVEY.md section 8e (batch sums before the backward pass, flat gradient
 after it) run over RCCL.  N > 1 defaults to STRONG scaling on BASELINE config 4: 1 M frames in all (1/N resident per GPU), a
-fixed global batch (--global-batch, default 160 000 frames per step of the whole job); --scaling weak keeps --batch frames
-per GPU.  Every line also carries `scaling_table`: the same job at global batches 20 000 / 160 000 / 800 000 and the weak line.
+fixed global batch (--global-batch, default 800 000 frames per step of the whole job = the whole training split of the
+1 M-frame set at the reference's test_ratio 0.2, one step per epoch); --scaling weak keeps --batch frames per GPU.  Every line also carries `scaling_table`: the same job at global batches 20 000 / 160 000 / 800 000 and the weak line.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = frames of all ranks / second.
 """
@@ -217,7 +217,8 @@ def main():
                     help="N>1: strong (default) = BASELINE config 4, --frames-total frames and --global-batch frames per step split "
                          "over the ranks; weak = --batch frames per GPU per step")
     ap.add_argument("--frames-total", type=int, default=1_000_000, help="config 4: frames of the whole job")
-    ap.add_argument("--global-batch", type=int, default=160_000, help="strong scaling: frames per step of the whole job")
+    ap.add_argument("--global-batch", type=int, default=800_000,
+                    help="strong scaling: frames per step of the whole job (default: the training split of the 1 M-frame set)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 disables it)")
     ap.add_argument("--preheat-ms", type=float, default=75.0,
                     help="untimed steps run for about this long after the W warm-up steps, before the clock starts (GPU frequency ramp; 0 = off)")
