@@ -132,18 +132,39 @@ class EigenFunctions(torch.nn.Module):
 # Flat-buffer description of a model for the HIP kernels (not part of the reference API)
 # ----------------------------------------------------------------------------------------------
 
+# activation codes of include/cvf.h (cvf_mlp_desc.act); 1 == True, so "followed by Tanh" still reads as a flag
+ACT_NONE, ACT_TANH, ACT_SIGMOID, ACT_RELU, ACT_ELU, ACT_LEAKY_RELU, ACT_SOFTPLUS = range(7)
+
+
+def _act_code(module):
+    """cvf_mlp_desc.act code of a torch activation module (the reference takes any, nn.py:29-59); the chain kernels of the
+    autoencoder tasks implement these, with the modules' default parameters."""
+    if isinstance(module, torch.nn.Tanh):
+        return ACT_TANH
+    if isinstance(module, torch.nn.Sigmoid):
+        return ACT_SIGMOID
+    if isinstance(module, torch.nn.ReLU):
+        return ACT_RELU
+    if isinstance(module, torch.nn.ELU) and module.alpha == 1.0:
+        return ACT_ELU
+    if isinstance(module, torch.nn.LeakyReLU) and module.negative_slope == 0.01:
+        return ACT_LEAKY_RELU
+    if isinstance(module, torch.nn.Softplus) and module.beta == 1.0 and module.threshold == 20.0:
+        return ACT_SOFTPLUS
+    raise NotImplementedError(
+        f"the MI355X kernels implement Tanh, Sigmoid, ReLU, ELU(alpha=1), LeakyReLU(0.01) and Softplus(beta=1, threshold=20) "
+        f"in the autoencoder tasks and Tanh in EigenFunctionTask (got {module})")
+
+
 def _chain_layers(seq):
-    """[(Linear, followed_by_activation)] of a create_sequential_nn module; rejects anything else."""
+    """[(Linear, activation code that follows it - 0: none)] of a create_sequential_nn module; rejects anything else."""
     out = []
     children = list(seq._modules.values())  # children() would drop the repeats of the shared activation
     for i, child in enumerate(children):
         if isinstance(child, torch.nn.Linear):
             nxt = children[i + 1] if i + 1 < len(children) else None
             has_act = nxt is not None and not isinstance(nxt, torch.nn.Linear)
-            if has_act and not isinstance(nxt, torch.nn.Tanh):
-                raise NotImplementedError(
-                    f"the MI355X kernels implement Tanh activations only (got {type(nxt).__name__})")
-            out.append((child, has_act))
+            out.append((child, _act_code(nxt) if has_act else ACT_NONE))
     return out
 
 
@@ -156,6 +177,10 @@ def mlp_layout(model):
         pos += p.numel()
     if isinstance(model, EigenFunctions):
         chains = [_chain_layers(net) for net in model.eigen_funcs]
+        for chain in chains:   # the eigenfunction kernels carry tanh and its first two derivatives
+            if any(act not in (ACT_NONE, ACT_TANH) for _, act in chain):
+                raise NotImplementedError("EigenFunctionTask on MI355X: the eigenfunction kernels implement Tanh activations only "
+                                          "(they need the activation's first two derivatives); the autoencoder tasks take others")
     elif isinstance(model, AutoEncoder):
         chains = [_chain_layers(model.encoder) + _chain_layers(model.decoder)]
     else:

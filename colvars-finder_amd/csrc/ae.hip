@@ -41,7 +41,7 @@ __host__ __device__ inline AeLayout ae_layout(const cvf_mlp_desc& m, bool with_g
 
 // out[o] = act(b[o] + sum_i W[o][i] in[i]) for one lane, 8 outputs at a time
 __device__ __forceinline__ void dense_fwd(const float* __restrict__ W, const float* __restrict__ b, int din, int dout,
-                                          const float* in, float* out, bool act, int lane) {
+                                          const float* in, float* out, int act, int lane) {
   for (int o0 = 0; o0 < dout; o0 += 8) {
     float acc[8];
     int ro[8];
@@ -58,7 +58,7 @@ __device__ __forceinline__ void dense_fwd(const float* __restrict__ W, const flo
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (o0 + j < dout) out[(o0 + j) * P + lane] = act ? cvf_tanh(acc[j]) : acc[j];
+      if (o0 + j < dout) out[(o0 + j) * P + lane] = cvf_act(act, acc[j]);
   }
 }
 
@@ -208,14 +208,14 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
       const float* bl = WL + s_boff[l];
       const float* in = l > 0 ? lds + s_img[l] : nullptr;
       float* dst = l + 1 < L ? lds + s_img[l + 1] : ZB;
-      const bool act = s_act[l] != 0;
+      const int act = s_act[l];
       auto finish = [&](int rt, const f32x4& acc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = 16 * rt + 4 * kq + r;
           if (o < dout) {
             const float v = acc[r] + bl[o];
-            dst[o * AP + fcol] = act ? cvf_tanh(v) : v;
+            dst[o * AP + fcol] = cvf_act(act, v);
           }
         }
       };
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
     // ---- weighted squared error and zbar_L = 2 w (out - f) / sum(w)     (core.py:666); rows o = 16 rt + 4 kq + r
     {
       const float scale = (float)(2.0 * (double)wb * inv_wsum);
-      const bool act_last = s_act[L - 1] != 0;
+      const int act_last = s_act[L - 1];
       float err2 = 0.0f;
       for (int rt0 = 0; 16 * rt0 < dL; rt0 += 4) {
         float fv[16];
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
             const float df = out - fv[u];
             err2 = fmaf(df, df, err2);
             float zb = scale * df;
-            if (act_last) zb *= 1.0f - out * out;
+            zb *= cvf_act_d1(act_last, out);
             ZB[o * AP + fcol] = zb;
           } else if (o < dL) {
             // regulariser head i: output gradient of the transfer-operator loss (as ef_bwd_mfma_kernel, lag_idx > 0)
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
                 g = (double)wl * (gS1l[i] + 2.0 * gS2l[i] * (double)yl[i * CVF_TILE]) + tterm;
               }
               zb = (float)(reg.head_scale * g);
-              if (act_last) zb *= 1.0f - out * out;
+              zb *= cvf_act_d1(act_last, out);
             }
             ZB[o * AP + fcol] = zb;
           }
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
       if (l > 0) {
         const float* Wl = WL + wo;
         const float* al = lds + s_img[l];
-        const bool act = s_act[l - 1] != 0;
+        const int act = s_act[l - 1];
         const bool add_enc = reg.enc_coef != nullptr && l == reg.enc_layer && !lagged;
         constexpr int kBT = 4, kBC = 8;   // row tiles per pass, k-steps per batch (as in the forward layers)
         for (int rt0 = 0; 16 * rt0 < din; rt0 += kBT) {
@@ -433,10 +433,7 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
                 const int i = 16 * rt + 4 * kq + r;
                 if (i < din) {
                   float v = acc[t][r];
-                  if (act) {
-                    const float a = al[i * AP + fcol];
-                    v *= 1.0f - a * a;
-                  }
+                  if (act) v *= cvf_act_d1(act, al[i * AP + fcol]);
                   Zn[i * AP + fcol] = v;
                 }
               }
@@ -510,7 +507,7 @@ __global__ __launch_bounds__(64) void mlp_eval_rows_kernel(cvf_mlp_desc mlp, con
   for (int net = 0; net < mlp.n_nets; ++net) {
     for (int l = 0; l < upto; ++l)
       dense_fwd(theta + mlp.w_off[net][l], theta + mlp.b_off[net][l], mlp.dims[l], mlp.dims[l + 1], lds + lay.act_off[l],
-                l + 1 < upto ? lds + lay.act_off[l + 1] : ZB, mlp.act[l] != 0, lane);
+                l + 1 < upto ? lds + lay.act_off[l + 1] : ZB, mlp.act[l], lane);
     if (valid)
       for (int j = 0; j < dU; ++j) out[bb * (int64_t)(mlp.n_nets * dU) + net * dU + j] = ZB[j * P + lane];
   }

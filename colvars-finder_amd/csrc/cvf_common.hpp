@@ -78,6 +78,31 @@ __device__ __forceinline__ float cvf_tanh(float x) {
   return copysignf(r, x);
 }
 
+// Activations of the chain kernels (cvf_mlp_desc.act codes, include/cvf.h) and their derivative expressed through the
+// OUTPUT h = act(z) - the backward pass keeps activations, not pre-activations.  `kind` is uniform over a launch.
+__device__ __forceinline__ float cvf_act(int kind, float z) {
+  switch (kind) {
+    case CVF_ACT_TANH: return cvf_tanh(z);
+    case CVF_ACT_SIGMOID: return 1.0f / (1.0f + expf(-z));
+    case CVF_ACT_RELU: return fmaxf(z, 0.0f);
+    case CVF_ACT_ELU: return z > 0.0f ? z : expm1f(z);
+    case CVF_ACT_LEAKY_RELU: return z > 0.0f ? z : 0.01f * z;
+    case CVF_ACT_SOFTPLUS: return z > 20.0f ? z : log1pf(expf(z));
+    default: return z;
+  }
+}
+__device__ __forceinline__ float cvf_act_d1(int kind, float h) {
+  switch (kind) {
+    case CVF_ACT_TANH: return 1.0f - h * h;
+    case CVF_ACT_SIGMOID: return h * (1.0f - h);
+    case CVF_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
+    case CVF_ACT_ELU: return h > 0.0f ? 1.0f : h + 1.0f;
+    case CVF_ACT_LEAKY_RELU: return h > 0.0f ? 1.0f : 0.01f;
+    case CVF_ACT_SOFTPLUS: return h > 20.0f ? 1.0f : 1.0f - expf(-h);   // 1 - e^{-softplus(z)} = sigmoid(z)
+    default: return 1.0f;
+  }
+}
+
 // Developer aid: the tools/*.hip probes compile a kernel file with -DCVF_STAMPS to read s_memtime at phase
 // boundaries of one wave per block; in the shipped library the macro is empty.
 #ifdef CVF_STAMPS

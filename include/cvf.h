@@ -36,6 +36,18 @@ extern "C" {
  * "position ... type_id 3") */
 enum { CVF_FEAT_ANGLE = 0, CVF_FEAT_BOND = 1, CVF_FEAT_DIHEDRAL = 2, CVF_FEAT_POSITION = 3 };
 enum { CVF_PP_IDENTITY = 0, CVF_PP_ALIGN = 1 };
+/* cvf_mlp_desc.act[l]: what follows Linear layer l (nn.py:29-59 takes any torch activation module).  The chain kernels
+ * (cvf_ae_*, cvf_regae_*, cvf_mlp_eval_rows) take all of these; the eigenfunction kernels (cvf_ef_*, cvf_ef16_*), which
+ * need the activation's first TWO derivatives, take CVF_ACT_TANH between layers only. */
+enum {
+  CVF_ACT_NONE = 0,
+  CVF_ACT_TANH = 1,
+  CVF_ACT_SIGMOID = 2,
+  CVF_ACT_RELU = 3,
+  CVF_ACT_ELU = 4,        /* alpha = 1 */
+  CVF_ACT_LEAKY_RELU = 5, /* negative_slope = 0.01 */
+  CVF_ACT_SOFTPLUS = 6    /* beta = 1, threshold = 20 */
+};
 /* cvf_pp_desc.flags: structure of the tables, enabling kernels whose LDS addresses are affine in the atom index */
 enum {
   CVF_PP_ALIGN_CONTIG = 1,   /* align_idx[b] == b for all b (the align atoms are the first n_align frame atoms) */

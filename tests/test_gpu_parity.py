@@ -867,3 +867,90 @@ def test_four_and_five_hidden_layers_generator_step_vs_oracle(dev, dims, mixed):
     task.num_epochs, task.batch_size = 2, 50
     task.train()
     assert np.isfinite(task.train_loss_df.to_numpy()).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# activations other than Tanh in the autoencoder tasks (the reference takes any torch module, nn.py:29-59)
+# ------------------------------------------------------------------------------------------------
+ACTIVATIONS = [("sigmoid", torch.nn.Sigmoid, torch.sigmoid), ("relu", torch.nn.ReLU, torch.relu), ("elu", torch.nn.ELU, torch.nn.functional.elu),
+               ("leaky_relu", torch.nn.LeakyReLU, torch.nn.functional.leaky_relu), ("softplus", torch.nn.Softplus, torch.nn.functional.softplus),
+               ("tanh", torch.nn.Tanh, torch.tanh)]
+
+
+@pytest.mark.parametrize("name,module,fn", ACTIVATIONS, ids=[a[0] for a in ACTIVATIONS])
+def test_autoencoder_activations_vs_oracle(dev, name, module, fn):
+    """AutoEncoderTask with each supported activation: weighted-MSE loss, every parameter gradient, the learned CVs and a
+    short training run against the fp64 oracle (autograd through the same torch function)."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref, train as otrain
+    n_atoms, n = 10, 600
+    traj, w, ref = make_molecule_traj(n_atoms, n, seed=2100, scale=1.0, sigma=0.3)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_atoms)))], use_angle_value=False)
+    e_dims, d_dims = [30, 20, 12, 2], [2, 10, 30]
+    sd0 = nnref.init_autoencoder(e_dims, d_dims, torch.Generator().manual_seed(4))
+    model = nn.AutoEncoder(e_dims, d_dims, module())
+    model.load_state_dict(sd0)
+    task = core.AutoEncoderTask(Traj(traj, w, 1.0), make_layer(spec, n_atoms, dev), model, "/tmp/cvf_test", learning_rate=2e-3,
+                                batch_size=200, num_epochs=2, device=dev, verbose=False, save_model_every_step=0)
+    nb = 333
+    l0 = task.weighted_MSE_loss(task._feature_traj[:nb], task._weights[:nb])
+    task.backward()
+    cv = task.colvar_model()(torch.tensor(traj[:64])).detach().numpy()
+    torch.set_default_dtype(torch.float64)
+    F = oracle_layer(spec)(torch.tensor(traj, dtype=torch.float64))
+    sd = {k_: p.double().requires_grad_(True) for k_, p in sd0.items()}
+    lo = losses.ae_loss(sd, F[:nb], torch.tensor(w[:nb]), activation=fn)
+    lo.backward()
+    torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(float(l0), float(lo.detach()), rtol=RTOL64)
+    gmax = max(float(p.grad.abs().max()) for p in sd.values())
+    for k_, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), sd[k_].grad.numpy(), rtol=20 * RTOL64, atol=20 * RTOL64 * gmax, err_msg=k_)
+    np.testing.assert_allclose(cv, nnref.encoder_forward({k_: p.detach() for k_, p in sd.items()}, F[:64], fn).numpy(), rtol=1e-4, atol=2e-5)
+    np.random.seed(5)
+    task.train()
+    got = np.stack([e[0].numpy() for e in task.loss_list])
+    assert np.isfinite(got).all() and got[-1].mean() < got[0, 0]          # it trains
+
+
+@pytest.mark.parametrize("name,module,fn", ACTIVATIONS[:3], ids=[a[0] for a in ACTIVATIONS[:3]])
+def test_regautoencoder_activations_first_step_vs_oracle(dev, name, module, fn):
+    """RegAutoEncoderTask (transfer-operator regulariser + latent penalties) with other activations: the first step's loss terms
+    and parameter gradients against the fp64 oracle."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    rs = np.random.RandomState(21)
+    n, d, K = 500, 6, 2
+    traj = np.cumsum(rs.normal(scale=0.15, size=(n, d)), axis=0).astype(np.float32)
+    traj -= traj.mean(0)
+    w = rs.uniform(0.5, 1.5, size=n)
+    e_dims, d_dims, r_dims = [d, 8, 2], [2, 8, d], [2, 6, 1]
+    sd0 = nnref.init_regautoencoder(e_dims, d_dims, r_dims, K, torch.Generator().manual_seed(6), torch.float32)
+    model = nn.RegAutoEncoder(e_dims, d_dims, r_dims, K, module())
+    model.load_state_dict(sd0)
+    alpha, gamma, eta, eig_w, dt = 0.8, [1.0, 4.0], [0.0, 0.3, 0.5], [1.0, 0.5], 0.5
+    task = core.RegAutoEncoderTask(Traj(traj, w, dt), torch.nn.Identity(), model, "/tmp/cvf_test", eig_weights=eig_w, learning_rate=1e-3,
+                                   batch_size=150, num_epochs=1, alpha=alpha, gamma=gamma, eta=eta, lag_tau_ae=1 * dt, lag_tau_reg=2 * dt,
+                                   device=dev, verbose=False, save_model_every_step=0)
+    nb = 200
+    idx = torch.arange(nb, device=dev)
+    out = task._step(task._feature_traj, idx, task._weights[:nb].contiguous(), task._weights[2:2 + nb].contiguous(), 1, 2,
+                     with_grad=True).cpu().numpy()
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    F, W = torch.tensor(traj, dtype=torch.float64), torch.tensor(w)
+    sd = {k_: p.double().requires_grad_(True) for k_, p in sd0.items()}
+    ae = losses.regae_mse(sd, F[:nb], F[1:1 + nb], W[:nb], activation=fn)
+    eig, npl, pen, cvec = losses.regae_eigen_loss(sd, K, F[:nb], W[:nb], F[2:2 + nb], W[2:2 + nb], eig_w=eig_w, lag_idx=2, dt=dt, activation=fn)
+    en, eo = losses.regae_enc_norm(sd, F[:nb], W[:nb], activation=fn), losses.regae_enc_orth(sd, F[:nb], W[:nb], activation=fn)
+    lo = alpha * ae + gamma[0] * npl + gamma[1] * pen + eta[1] * en + eta[2] * eo
+    lo.backward()
+    torch.set_default_dtype(torch.float32)
+    want = np.asarray([float(lo.detach()), float(ae.detach()), float(npl.detach()), float(pen.detach())] + [float(e) for e in eig] +
+                      [0.0, float(en.detach()), float(eo.detach())])
+    np.testing.assert_allclose(out, want, rtol=5 * RTOL64, atol=1e-7)
+    gmax = max(float(p.grad.abs().max()) for p in sd.values())
+    for k_, p in model.named_parameters():
+        if k_.startswith("reg.") and k_.endswith(f".{len(r_dims) - 1}.bias"):
+            continue
+        np.testing.assert_allclose(p.grad.cpu().numpy(), sd[k_].grad.numpy(), rtol=20 * RTOL64, atol=20 * RTOL64 * gmax, err_msg=k_)
