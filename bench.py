@@ -223,9 +223,11 @@ def main():
     ap.add_argument("--preheat-ms", type=float, default=75.0,
                     help="untimed steps run for about this long after the W warm-up steps, before the clock starts (GPU frequency ramp; 0 = off)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other global batches, K1 rooflines)")
-    ap.add_argument("--workload", choices=["c3", "c5", "c2", "regae"], default="c3",
+    ap.add_argument("--workload", choices=["c3", "c5", "c2", "regae", "transfer"], default="c3",
                     help="c3 = the benchmark line; c5 = config-5 shape, c2 = config-2 AutoEncoderTask (extra measurements)")
     args = ap.parse_args()
+    if args.workload == "transfer":
+        return main_transfer(args)
     if args.workload == "c5":
         return main_c5(args)
     if args.workload == "regae":
@@ -526,6 +528,59 @@ def main_c5(args):
                           "ms_per_step": elapsed / args.steps * 1e3, "final_loss": float(lv[0]),
                           "kernel_avg_us": dict(sorted(kern.items(), key=lambda kv: -kv[1])),
                           "align_feature_GBps": bpf * B / (k1 * 1e-6) / 1e9, "align_feature_frac_of_8TBps": bpf * B / (k1 * 1e-6) / 8e12}))
+
+
+def main_transfer(args):
+    """Config-3 shape in TRANSFER-OPERATOR mode (lag_tau > 0: the mode the shipped dipeptide notebook runs, main.ipynb:275,420):
+    22 atoms, k = 3, nets [66,20,20,20,1], B = 20 000 frames + their lagged partners per step.  Extra measurement."""
+    from colvarsfinder import _dist, core, nn, pp
+    from tests.synth import Traj
+    _dist.init_from_env("nccl")
+    world, rank = _dist.world(), _dist.rank()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    ref = np.random.RandomState(SEED).normal(scale=2.0, size=(N_ATOMS, 3))
+    torch.manual_seed(SEED)
+    model = nn.EigenFunctions(LAYERS, K_NETS)
+    layer = pp.AlignFeatureLayer(N_ATOMS, list(range(N_ATOMS)), ref, [("position", tuple(range(N_ATOMS)))])
+    tok = np.zeros((64, N_ATOMS, 3), dtype=np.float32) + ref[None].astype(np.float32)
+    task = core.EigenFunctionTask(Traj(tok, np.ones(64), 1.0), layer, model, "/tmp/cvf_bench", ALPHA, EIG_W, beta=BETA, lag_tau=3.0,
+                                  learning_rate=LR, k=K_NETS, batch_size=args.batch, device=dev, verbose=False, save_model_every_step=0)
+    B, lag = min(args.batch, args.frames), 3
+    X, Wt = device_frames(args.frames + lag, ref, 0.3, SEED + 1 + rank, dev)
+    n_batches = args.frames // B
+    log = torch.zeros(n_batches, 3 + 2 * K_NETS, device=dev, dtype=torch.float64)
+
+    def one(b):
+        s_ = b * B
+        return task.train_step(X[s_:s_ + B], Wt[s_:s_ + B], X[s_ + lag:s_ + lag + B], Wt[s_ + lag:s_ + lag + B], out=log[b])
+
+    def chunk():
+        task._graph_call(("transfer", "chunk"), lambda: [one(b) for b in range(n_batches)])
+
+    n_chunks = max(1, args.steps // n_batches)
+    for _ in range(max(2, args.warmup // n_batches + 1) + 100):      # (+ the preheat of the headline run)
+        chunk()
+    torch.cuda.synchronize()
+    chunk()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_chunks):
+        chunk()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    steps = n_chunks * n_batches
+    task._use_graphs, task._events = False, {}
+    for i in range(20):
+        one(i % n_batches)
+    torch.cuda.synchronize()
+    kern = {n: float(np.mean([s_.elapsed_time(e_) for s_, e_ in ev])) * 1e3 for n, ev in task._events.items()}
+    if rank == 0:
+        print(json.dumps({"workload": "config-3 shape, transfer-operator mode (lag 3 frames): 22 atoms, k=3, nets [66,20,20,20,1], B=20000 + lagged partners",
+                          "n_gpus": world, "value": world * B * steps / elapsed, "unit": "frames/s", "steps": steps,
+                          "ms_per_step": elapsed / steps * 1e3, "final_loss": float(log[n_batches - 1, 0]),
+                          "call_avg_us": dict(sorted(kern.items(), key=lambda kv: -kv[1])),
+                          "call_timing": "HIP events around each C-ABI call, eager pass (includes launch overhead)"}))
 
 
 def main_c2(args):

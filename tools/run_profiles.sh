@@ -19,6 +19,6 @@ for c in FETCH_SIZE WRITE_SIZE; do echo "== pmc_k1_$c"; timeout -k 10 300 rocpro
 cd "$R"
 echo "== full bench"; timeout -k 10 500 python3 bench.py > "$O/bench_full.log" 2> "$O/bench_full.err" || { echo "bench failed"; tail -5 "$O/bench_full.err"; exit 1; }
 tail -1 "$O/bench_full.log" | cut -c1-600
-for wl in c2 c5 regae; do timeout -k 10 300 python3 bench.py --workload $wl > "$O/bench_$wl.log" 2>&1 && tail -1 "$O/bench_$wl.log" | cut -c1-400; done
+for wl in c2 c5 regae transfer; do timeout -k 10 300 python3 bench.py --workload $wl > "$O/bench_$wl.log" 2>&1 && tail -1 "$O/bench_$wl.log" | cut -c1-400; done
 grep '^{"case"' "$O/bench_k1.log"
 hipcc -O3 --offload-arch=gfx950 tools/stream_probe.hip -o /tmp/stream_probe && COPY_ONLY=1 timeout -k 10 120 /tmp/stream_probe > "$O/copy_probe.log" 2>&1; cat "$O/copy_probe.log"
