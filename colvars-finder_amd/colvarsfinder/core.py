@@ -462,7 +462,7 @@ class _EFWorkspace:
             self.e = torch.empty(T * k * _hip.TILE, **f32)
         else:
             self.g = self.q = self.e = None
-        self.scratch = torch.zeros(lib.cvf_ef16_scratch_doubles(B, k) if ef16 else
+        self.scratch = torch.zeros(lib.cvf_ef16_scratch_doubles(B, k) if ef16 and lag == 0 else
                                    lib.cvf_metric_stats_scratch_doubles(B, k) if lag == 0 else
                                    lib.cvf_ef_stats_scratch_doubles(k, lag), **f64)
         self.stats = torch.empty(lib.cvf_ef_nstats(k, lag), **f64)
@@ -592,10 +592,10 @@ class EigenFunctionTask(TrainingTask):
         return ws
 
     def _use_ef16(self):
-        """Generator mode on the fast layout: the 16-frames-per-wave step (csrc/ef16.hip), decided once."""
+        """The fast layout: the 16-frames-per-wave step (csrc/ef16.hip; generator and transfer-operator mode), decided once."""
         if self._ef16 is None:
-            self._ef16 = (self.lag_idx == 0 and not self._pipeline and
-                          bool(_hip.lib().cvf_ef16_supported(self._flat.desc, self._pp)))
+            self._ef16 = (not self._pipeline and os.environ.get("CVF_NO_EF16_TRANSFER" if self.lag_idx > 0 else "CVF_NO_EF16") is None
+                          and bool(_hip.lib().cvf_ef16_supported(self._flat.desc, self._pp)))
         return self._ef16
 
     def _align(self, ws, slot, X, X_lag):
@@ -624,6 +624,18 @@ class EigenFunctionTask(TrainingTask):
         ws.loss_out = ws.loss_vec if out is None else out
         assert ws.loss_out.is_contiguous() and ws.loss_out.dtype == torch.float64 and ws.loss_out.numel() == 3 + 2 * k
         lv, cf = (P(ws.loss_out), P(ws.coef)) if single else (None, None)
+        if self._use_ef16() and not aligned and lag > 0:
+            # transfer-operator mode: coordinates of the frames and of their lagged partners -> features, y, hidden activations
+            # in one launch (16 frames per wave), then the time-lagged batch sums and the loss tail
+            self._call("cvf_ef16_front_transfer", lib.cvf_ef16_front_transfer, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat),
+                       self._pp, P(X), P(X_lag), B, P(ws.y), P(ws.saved), s)
+            y_lag = ws.y[ws.T * k * _hip.TILE:]
+            self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), None, P(w_lag), P(y_lag),
+                       P(ws.scratch), P(ws.stats), lv, cf, s)
+            if not single:
+                _dist.allreduce_sum_(ws.stats)                                           # collective #1
+                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
+            return ws
         if self._use_ef16() and not aligned:
             # coordinates -> features, y, hidden activations, q = J A J^T g, E and the batch sums in one launch, 16 frames per
             # wave (+ the short launch that adds the units' rows and evaluates the loss tail)
@@ -688,7 +700,11 @@ class EigenFunctionTask(TrainingTask):
         (the kernel advances the device step counter).  ``fuse_adam``: single-process training - the kernel
         that sums the per-block partial gradients applies the Adam update in the same launch."""
         lib, fl, P = _hip.lib(), self._flat, _hip.ptr
-        if self._use_ef16():
+        if self._use_ef16() and self.lag_idx > 0:
+            self._call("cvf_ef16_backward_transfer", lib.cvf_ef16_backward_transfer, self._cfg, fl.desc, P(fl.theta), P(fl.packed), ws.B,
+                       P(w), P(w_lag), P(ws.feat), P(ws.y), P(ws.coef), P(ws.slab),
+                       P(self.optimizer.step_count) if advance else None, P(ws.saved), _hip.stream())
+        elif self._use_ef16():
             self._call("cvf_ef16_backward", lib.cvf_ef16_backward, self._cfg, fl.desc, P(fl.theta), P(fl.packed), ws.B, P(w),
                        P(ws.feat), P(ws.y), P(ws.q), P(ws.coef), P(ws.slab),
                        P(self.optimizer.step_count) if advance else None, P(ws.saved), _hip.stream())

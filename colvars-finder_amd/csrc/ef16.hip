@@ -72,7 +72,8 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
                                                              const float* __restrict__ a, const float* __restrict__ w,
                                                              float* __restrict__ feat_tiled, float* __restrict__ y_tiled,
                                                              float* __restrict__ saved, float* __restrict__ q_tiled,
-                                                             float* __restrict__ e_tiled, double* __restrict__ partial, int ns) {
+                                                             float* __restrict__ e_tiled, double* __restrict__ partial, int ns,
+                                                             const float* __restrict__ x_lag, int64_t units_x) {
   constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG, SMAX = 18, CTMAX = 5;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nw = nthreads >> 6;
@@ -80,8 +81,13 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
   //  with it, i.e. all of this net's weights and images - as lane-varying, in VGPR pairs)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = wave, k = mlp.n_nets, D = mlp.dims[0];
-  const int64_t unit = blockIdx.x, tile = unit >> 2;
+  // transfer-operator mode (x_lag != NULL): the grid holds the units of x, then the units of the lagged frames, whose tiles
+  // follow the tiles of x in every tiled output; the block stops after y and the hand-off of the hidden activations
+  const bool lagged = x_lag != nullptr && (int64_t)blockIdx.x >= units_x;   // (uniform)
+  const int64_t unit = lagged ? (int64_t)blockIdx.x - units_x : (int64_t)blockIdx.x;   // unit within its frame set
+  const int64_t tile = (unit >> 2) + (lagged ? (units_x >> 2) : 0);
   const int sub = (int)(unit & 3);
+  if (lagged) x = x_lag;
   const int nc = pp.n_coord, nal = pp.n_align, N = pp.n_rec;
   const int stride = x_tile_stride(nc);
   const Front16Lds Lo = front16_lds(nc, nal, k);
@@ -111,10 +117,10 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
   } else {
     load_x_tile<6>(x, B, nc, unit, xt, tid, nthreads, kU);
   }
-  for (int j = tid; j < 3 * nal + nc; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : a[j - 3 * nal];   // refL | aL
+  for (int j = tid; j < 3 * nal + nc; j += nthreads) refL[j] = j < 3 * nal ? pp.ref_c[j] : (a != nullptr ? a[j - 3 * nal] : 0.0f);   // refL | aL
   if (tid < kU) {
     const int64_t frame = unit * kU + tid;
-    wL[tid] = frame < B ? w[frame] : 0.0f;      // frames past the batch replicate the last one with weight 0
+    wL[tid] = (w != nullptr && frame < B) ? w[frame] : 0.0f;      // frames past the batch replicate the last one with weight 0
   }
   // ---- the first layer's weights are requested here, behind the coordinates and the tables (vector memory returns in issue
   //      order: in front of them they delayed the staging by 7 k cycles): their round trip runs beside the barrier and the
@@ -268,6 +274,16 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     y_tiled[(tile * k + net) * CVF_TILE + kU * sub + col] = yv;
   }
   CVF_STAMP(25);
+  if (x_lag != nullptr) {   // transfer-operator mode: y, h_1..h_NH and the feature tile are all the backward pass needs
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) sv.st((l * NG + g) * 256, h[l].v[g >> 2][0][g & 3]);
+    float* ft = feat_tiled + tile * (int64_t)D * CVF_TILE + kU * sub + f;
+    const float* fi = featI + f * kImgP;
+    for (int j = p + 4 * wave; j < D; j += 4 * nw) ft[j * CVF_TILE] = fi[j];
+    return;
+  }
   // ---- d chain and g = W_1^T d_1 -> this wave's image [frame][feature]
   {
     // (requested behind the hand-off stores of h - vector-memory operations return in issue order - but the d chain below
@@ -546,9 +562,13 @@ struct Back16Args {
   int k;
   int64_t B;
   int64_t n_tiles;
+  int64_t T;              // transfer-operator mode: tiles 0..T-1 hold the frames, T..2T-1 their lagged partners
+  const float* w_lag;     // ... and the partners' weights
 };
 
-template <int H, int NH, bool MULTI>
+// GEN: generator mode (tangent chain, second operands).  !GEN: transfer-operator mode - the plain backward pass of y and y'
+// with the coefficients of the time-lagged loss (as ef_bwd_mfma_kernel's lag_idx > 0 branch), no tangent chain.
+template <int H, int NH, bool MULTI, bool GEN>
 __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                             const float* __restrict__ packed, const float* __restrict__ w,
                                                             const float* __restrict__ feat, const float* __restrict__ y_tiled,
@@ -587,6 +607,7 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
   float wl[RT][4];
   load_hid_const_u<H>(urows(theta + mlp.w_off[net][NH], H, q), wl);
   const double gS1n = coef[net], gEtn = coef[k + k * k + net];
+  const double gS1ln = GEN ? 0.0 : coef[2 * k + k * k + net], gS2ln = GEN ? 0.0 : coef[3 * k + k * k + net];
   const float one[1] = {1.0f};
 
   // a finished 16x16 tile of layer `l` (rows = outputs, columns = inputs + bias).  Every tile of the gradient is produced
@@ -620,19 +641,26 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
   auto outer2 = [&](const float* A1, const float* B1, const float* A2, const float* B2, int rt, int ct) {
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     acc = outer_half(A1, B1, rt, ct, lane, acc);
-    acc = outer_half(A2, B2, rt, ct, lane, acc);
+    if constexpr (GEN) acc = outer_half(A2, B2, rt, ct, lane, acc);
     return acc;
   };
 
   for (int64_t tile = blockIdx.x; tile < args.n_tiles; tile += gridDim.x) {
     CVF_STAMP(8);
     // ---- everything the chains need from memory is requested here
-    const int64_t frame = tile * CVF_TILE + fo;
+    const bool lagged = !GEN && tile >= args.T;              // (uniform) a tile of lagged partners
+    const int64_t t0 = lagged ? tile - args.T : tile;        // the tile of the frames themselves
+    const int64_t frame = t0 * CVF_TILE + fo;
     const bool valid = frame < args.B;
     const float wraw = w[valid ? frame : args.B - 1];
     float yb[CVF_MAX_NETS];
 #pragma unroll
-    for (int j = 0; j < CVF_MAX_NETS; ++j) yb[j] = y_tiled[(tile * k + (j < k ? j : k - 1)) * CVF_TILE + fo];
+    for (int j = 0; j < CVF_MAX_NETS; ++j) yb[j] = y_tiled[(t0 * k + (j < k ? j : k - 1)) * CVF_TILE + fo];
+    float ylag = 0.0f, wlraw = 0.0f;
+    if constexpr (!GEN) {
+      ylag = y_tiled[((args.T + t0) * k + net) * CVF_TILE + fo];
+      wlraw = args.w_lag[valid ? frame : args.B - 1];
+    }
     const URows sv = urows(saved + (tile * k + net) * (int64_t)(kHand<NH>() * NG * 256) + wave * 64, kHand<NH>() * NG * 256 - wave * 64, lane);
     Vec<H, 1> h[NH], e[NH > 1 ? NH - 1 : 1], t[NH];
 #pragma unroll
@@ -642,59 +670,75 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
 #pragma unroll
       for (int g = 0; g < NG; ++g) h[l].v[g >> 2][0][g & 3] = sv.ld((l * NG + g) * 256);
     }
+    if constexpr (GEN) {
 #pragma unroll
-    for (int l = 0; l + 1 < NH; ++l) {
+      for (int l = 0; l + 1 < NH; ++l) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) e[l].v[rt][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int rt = 0; rt < RT; ++rt) e[l].v[rt][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int g = 0; g < NG; ++g) e[l].v[g >> 2][0][g & 3] = sv.ld(((NH + l) * NG + g) * 256);
+        for (int g = 0; g < NG; ++g) e[l].v[g >> 2][0][g & 3] = sv.ld(((NH + l) * NG + g) * 256);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) t[0].v[rt][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int g = 0; g < NG; ++g) t[0].v[g >> 2][0][g & 3] = sv.ld(((2 * NH - 1) * NG + g) * 256);
     }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) t[0].v[rt][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int g = 0; g < NG; ++g) t[0].v[g >> 2][0][g & 3] = sv.ld(((2 * NH - 1) * NG + g) * 256);
     // the tangent chain's weight fragments W_l, l = 2..NH, with the same round trip (the hbar chain's W_l^T are requested at
     // the top of each reverse step, a phase of outer products ahead of their use)
     HFrag<H> ffr[NH > 1 ? NH - 1 : 1];
+    if constexpr (GEN) {
 #pragma unroll
-    for (int l = 1; l < NH; ++l) load_hfrag_u<H>(ffr[l - 1], pk, L.fh(l));
+      for (int l = 1; l < NH; ++l) load_hfrag_u<H>(ffr[l - 1], pk, L.fh(l));
+    }
     const float* f_tile = feat + tile * (int64_t)D * CVF_TILE;
-    const float* q_tile = q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE;
+    const float* q_tile = GEN ? q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE : nullptr;
     // ---- per-frame coefficients
     const float wb = valid ? wraw : 0.0f;
-    float alpha, gamma;
-    {
+    float alpha, gamma = 0.0f;
+    float ynet = 0.0f;   // this net's y of the frame (selected, not indexed: yb[] lives in registers)
+#pragma unroll
+    for (int j = 0; j < CVF_MAX_NETS; ++j)
+      if (j == net) ynet = yb[j];
+    if (GEN || !lagged) {
       double a = gS1n;
 #pragma unroll
       for (int j = 0; j < CVF_MAX_NETS; ++j)
         if (j < k) a += (j == net ? 2.0 : 1.0) * coef[k + net * k + j] * (double)yb[j];
       alpha = (float)((double)wb * a);
-      gamma = (float)(2.0 * (double)wb * gEtn);
+      if constexpr (GEN) gamma = (float)(2.0 * (double)wb * gEtn);
+      else alpha = (float)((double)wb * a - 2.0 * (double)wb * gEtn * ((double)ylag - (double)ynet));   // ... and d/dy of gT sum w (y' - y)^2
+    } else {   // a lagged partner: d/dy' of the primed sums and of gT sum w (y' - y)^2
+      const double wlg = valid ? (double)wlraw : 0.0;
+      alpha = (float)(wlg * (gS1ln + 2.0 * gS2ln * (double)ylag) + 2.0 * (double)wb * gEtn * ((double)ylag - (double)ynet));
     }
     CVF_STAMP(9);
-    // ---- tangent chain: t_1 = gamma s, t_l = W_l tdot_{l-1}
+    if constexpr (GEN) {
+      // ---- tangent chain: t_1 = gamma s, t_l = W_l tdot_{l-1}
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) t[0].v[rt][0][r] *= gamma;
+        for (int r = 0; r < 4; ++r) t[0].v[rt][0][r] *= gamma;
 #pragma unroll
-    for (int l = 1; l < NH; ++l) {
-      Vec<H, 1> td;
-      tangent_of<H, 1>(td, h[l - 1], t[l - 1]);
-      init_bias<H, 1>(t[l], nullptr, q);
-      hidden_mul<H, 1>(t[l], ffr[l - 1], td);
+      for (int l = 1; l < NH; ++l) {
+        Vec<H, 1> td;
+        tangent_of<H, 1>(td, h[l - 1], t[l - 1]);
+        init_bias<H, 1>(t[l], nullptr, q);
+        hidden_mul<H, 1>(t[l], ffr[l - 1], td);
+      }
     }
     CVF_STAMP(11);
     // ---- last layer (1 x H):  W_L += sum alpha h_{NH} + tdot_{NH} ; b_L += sum alpha
     {
       if (q == 0) {
         SA1[fo] = alpha;
-        SA2[fo] = 1.0f;
+        if constexpr (GEN) SA2[fo] = 1.0f;
       }
       store_image<H, 1, false>(SB1, h[NH - 1], one, lane, fo);
-      Vec<H, 1> td;
-      tangent_of<H, 1>(td, h[NH - 1], t[NH - 1]);
-      store_image<H, 1, false>(SB2, td, one, lane, fo);
+      if constexpr (GEN) {
+        Vec<H, 1> td;
+        tangent_of<H, 1>(td, h[NH - 1], t[NH - 1]);
+        store_image<H, 1, false>(SB2, td, one, lane, fo);
+      }
       __syncthreads();
       for (int ct = wave; ct < CTH; ct += WPB) {
         const f32x4 acc = outer2(SA1, SB1, SA2, SB2, 0, ct);
@@ -733,7 +777,7 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
         load_hfrag_u<H>(tfl, pk, L.th(l));
       } else {
         request(bA, f_tile, wave);
-        request(bB, q_tile, wave);
+        if constexpr (GEN) request(bB, q_tile, wave);
       }
     };
     request_step(NH - 1);
@@ -750,21 +794,27 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
         for (int r = 0; r < 4; ++r) {
           const float hv = h[l].v[rt][0][r];
           const float om = 1.0f - hv * hv;
-          const float ev = (l == NH - 1) ? wl[rt][r] : e[l < NH - 1 ? l : 0].v[rt][0][r];
-          const float hb = fmaf(-2.0f * hv * t[l].v[rt][0][r], ev, hbar.v[rt][0][r]);
-          dl.v[rt][0][r] = ev * om;
-          zbar.v[rt][0][r] = om * hb;
+          if constexpr (GEN) {
+            const float ev = (l == NH - 1) ? wl[rt][r] : e[l < NH - 1 ? l : 0].v[rt][0][r];
+            const float hb = fmaf(-2.0f * hv * t[l].v[rt][0][r], ev, hbar.v[rt][0][r]);
+            dl.v[rt][0][r] = ev * om;
+            zbar.v[rt][0][r] = om * hb;
+          } else {
+            zbar.v[rt][0][r] = om * hbar.v[rt][0][r];
+          }
         }
       store_image<H, 1, false>(SA1, zbar, one, lane, fo);
-      {
+      if constexpr (GEN) {
         const float sc[1] = {l == 0 ? gamma : 1.0f};
         store_image<H, 1, true>(SA2, dl, sc, lane, fo);
       }
       if (l > 0) {
         store_image<H, 1, false>(SB1, h[l - 1], one, lane, fo);
-        Vec<H, 1> td;
-        tangent_of<H, 1>(td, h[l - 1], t[l - 1]);
-        store_image<H, 1, false>(SB2, td, one, lane, fo);
+        if constexpr (GEN) {
+          Vec<H, 1> td;
+          tangent_of<H, 1>(td, h[l - 1], t[l - 1]);
+          store_image<H, 1, false>(SB2, td, one, lane, fo);
+        }
         __syncthreads();
         // hbar_{l-1} = W_l^T zbar_l  (registers), then the next step's requests, then this step's tiles
         init_bias<H, 1>(hbar, nullptr, q);
@@ -809,18 +859,18 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
         if (wave < CT1) {   // wave-uniform
           half0(acc, SA1, bA, wave, 0, 1, true);
           if (wave < extra) request(bA, f_tile, WPB + wave / RTO);   // the extra pair's rows, behind the second half
-          half0(acc, SA2, bB, wave, 0, 1, false);
+          if constexpr (GEN) half0(acc, SA2, bB, wave, 0, 1, false);
 #pragma unroll
           for (int rt = 0; rt < RTO; ++rt) emit_tile(0, H, D, rt, wave, acc[rt]);
         }
         for (int pr = wave; pr < extra; pr += WPB) {
           const int ct = WPB + pr / RTO, rt = pr % RTO;
           if (pr != wave || wave >= CT1) request(bA, f_tile, ct);
-          request(bB, q_tile, ct);
+          if constexpr (GEN) request(bB, q_tile, ct);
 #pragma unroll
           for (int r_ = 0; r_ < RTO; ++r_) acc[r_] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           half0(acc, SA1, bA, ct, rt, RTO, true);
-          half0(acc, SA2, bB, ct, rt, RTO, false);
+          if constexpr (GEN) half0(acc, SA2, bB, ct, rt, RTO, false);
 #pragma unroll
           for (int r_ = 0; r_ < RTO; ++r_)
             if (r_ == rt) emit_tile(0, H, D, r_, ct, acc[r_]);
@@ -931,7 +981,7 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
     auto go = [&](auto kernel) {
       if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, *pp, x, B, a, w,
-                         feat_tiled, y_tiled, saved, q_tiled, e_tiled, rows ? scratch : nullptr, ns);
+                         feat_tiled, y_tiled, saved, q_tiled, e_tiled, rows ? scratch : nullptr, ns, (const float*)nullptr, units);
     };
     const int nit = (pp->n_rec + 3) / 4;   // atoms per lane in the four-lanes-per-frame passes (1..6: d_r <= 72)
     const bool allal = pp->n_align == pp->n_rec;
@@ -956,12 +1006,14 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
 
 extern "C" int64_t cvf_ef16_backward_slab_rows(int64_t n_tiles) { return n_tiles < 1024 ? n_tiles : 1024; }
 
-extern "C" int cvf_ef16_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
-                                 int64_t B, const float* w, const float* feat_tiled, const float* y_tiled, const float* q_tiled,
-                                 const double* coef, float* slab, int32_t* step_count, const float* saved, void* stream) {
-  CVF_REQUIRE(cfg && mlp && theta && packed && w && feat_tiled && y_tiled && q_tiled && coef && slab && saved && B > 0,
-              "cvf_ef16_backward: bad argument");
-  CVF_REQUIRE(cfg->lag_idx == 0 && cfg->k == mlp->n_nets, "cvf_ef16_backward: generator mode, cfg.k must equal the number of nets");
+static int ef16_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
+                              int64_t B, const float* w, const float* w_lag, const float* feat_tiled, const float* y_tiled,
+                              const float* q_tiled, const double* coef, float* slab, int32_t* step_count, const float* saved,
+                              void* stream) {
+  const bool transfer = cfg != nullptr && cfg->lag_idx > 0;
+  CVF_REQUIRE(cfg && mlp && theta && packed && w && feat_tiled && y_tiled && (transfer ? w_lag != nullptr : q_tiled != nullptr) && coef &&
+              slab && saved && B > 0, "cvf_ef16_backward: bad argument");
+  CVF_REQUIRE(cfg->k == mlp->n_nets, "cvf_ef16_backward: cfg.k must equal the number of nets");
   int H, NH;
   CVF_REQUIRE(ef16_shape(mlp, &H, &NH), "cvf_ef16_backward: unsupported net shape");
   CVF_REQUIRE(mlp->dims[0] <= 8 * 16 - 1, "cvf_ef16_backward: first layer wider than the column-tile schedule covers");
@@ -979,17 +1031,70 @@ extern "C" int cvf_ef16_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp,
   Back16Args a;
   a.k = cfg->k;
   a.B = B;
-  a.n_tiles = cvf_ntiles(B);
+  a.T = cvf_ntiles(B);
+  a.n_tiles = transfer ? 2 * a.T : a.T;
+  a.w_lag = w_lag;
   const int64_t G = cvf_ef16_backward_slab_rows(a.n_tiles);
   const bool launched = ef16_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    if (a.n_tiles > G)   // blocks walk several tiles: partial gradient in LDS, flushed once
-      hipLaunchKernelGGL((ef16_back_kernel<kH, kNH, true>), dim3((unsigned)G, cfg->k), dim3(256), (size_t)span * sizeof(float),
-                         (hipStream_t)stream, a, *mlp, theta, packed, w, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved);
-    else                 // one tile per block: every gradient tile goes straight to the block's slab row
-      hipLaunchKernelGGL((ef16_back_kernel<kH, kNH, false>), dim3((unsigned)G, cfg->k), dim3(256), 0,
-                         (hipStream_t)stream, a, *mlp, theta, packed, w, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved);
+    auto go = [&](auto kernel, size_t lds) {
+      hipLaunchKernelGGL(kernel, dim3((unsigned)G, cfg->k), dim3(256), lds, (hipStream_t)stream, a, *mlp, theta, packed, w, feat_tiled,
+                         y_tiled, q_tiled, coef, slab, step_count, saved);
+    };
+    const size_t gi = (size_t)span * sizeof(float);
+    // a.n_tiles > G: blocks walk several tiles (partial gradient in LDS, flushed once); else one tile per block, every
+    // gradient tile goes straight to the block's slab row
+    if (transfer) {
+      if (a.n_tiles > G) go(ef16_back_kernel<kH, kNH, true, false>, gi);
+      else go(ef16_back_kernel<kH, kNH, false, false>, 0);
+    } else {
+      if (a.n_tiles > G) go(ef16_back_kernel<kH, kNH, true, true>, gi);
+      else go(ef16_back_kernel<kH, kNH, false, true>, 0);
+    }
   });
   CVF_REQUIRE(launched, "cvf_ef16_backward: no kernel instance for hidden width %d x %d layers", H, NH);
   return cvf_check_launch("ef16_back_kernel");
+}
+
+extern "C" int cvf_ef16_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
+                                 int64_t B, const float* w, const float* feat_tiled, const float* y_tiled, const float* q_tiled,
+                                 const double* coef, float* slab, int32_t* step_count, const float* saved, void* stream) {
+  CVF_REQUIRE(cfg && cfg->lag_idx == 0, "cvf_ef16_backward: generator mode (transfer-operator mode: cvf_ef16_backward_transfer)");
+  return ef16_backward_impl(cfg, mlp, theta, packed, B, w, nullptr, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// transfer-operator mode (lag_tau > 0; core.py:403,414,420-431,440): y on the frames and on their lagged partners, then the
+// backward pass of both with the coefficients of the time-lagged loss.  Same kernels, same hand-off layout; the front
+// kernel stops after y (no derivative passes), the backward kernel is compiled without the tangent chain.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int cvf_ef16_front_transfer(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                                       const cvf_pp_desc* pp, const float* x, const float* x_lag, int64_t B, float* y_tiled,
+                                       float* saved, void* stream) {
+  CVF_REQUIRE(cvf_ef16_supported(mlp, pp), "cvf_ef16_front_transfer: shape not covered (cvf_ef16_supported() == 0)");
+  CVF_REQUIRE(theta && packed && feat_tiled && x && x_lag && y_tiled && saved && B > 0, "cvf_ef16_front_transfer: bad argument");
+  int H, NH;
+  ef16_shape(mlp, &H, &NH);
+  const int k = mlp->n_nets;
+  const int64_t T = cvf_ntiles(B), units = 4 * T;
+  CVF_REQUIRE(2 * units < (int64_t)1 << 31, "cvf_ef16_front_transfer: batch too large for one launch");
+  const size_t lds = (size_t)front16_lds(pp->n_coord, pp->n_align, k).total * sizeof(float);
+  ef16_dispatch(H, NH, [&](auto h_, auto nh_) {
+    constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
+    // (the passes' template parameters do not matter here - the block leaves before them: one instance serves)
+    auto kernel = ef16_front_kernel<kH, kNH, 6, true>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(2 * units)), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, *pp, x, B,
+                       (const float*)nullptr, (const float*)nullptr, feat_tiled, y_tiled, saved, (float*)nullptr, (float*)nullptr,
+                       (double*)nullptr, 0, x_lag, units);
+  });
+  return cvf_check_launch("ef16_front_kernel");
+}
+
+extern "C" int cvf_ef16_backward_transfer(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
+                                          int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
+                                          const float* y_tiled, const double* coef, float* slab, int32_t* step_count,
+                                          const float* saved, void* stream) {
+  CVF_REQUIRE(cfg && cfg->lag_idx > 0, "cvf_ef16_backward_transfer: transfer-operator mode (cfg.lag_idx > 0)");
+  return ef16_backward_impl(cfg, mlp, theta, packed, B, w, w_lag, feat_tiled, y_tiled, nullptr, coef, slab, step_count, saved, stream);
 }

@@ -243,6 +243,17 @@ int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const float* pac
 int cvf_ef16_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed, int64_t B,
                       const float* w, const float* feat_tiled, const float* y_tiled, const float* q_tiled, const double* coef,
                       float* slab, int32_t* step_count, const float* saved, void* stream);
+/* Transfer-operator mode (lag_tau > 0; core.py:403,414: y = model(pp_layer(X)) on the frames and on their lagged partners, then
+ * core.py:420-431,440 and loss.backward()) on the same kernels:
+ *  cvf_ef16_front_transfer   : x, x_lag [B][n_coord] -> feat_tiled [2T][d_r][64], y_tiled [2T][k][64] (the partners' tiles follow
+ *                              the frames'), saved (cvf_ef16_saved_floats(mlp, 2T)).  Follow with cvf_ef_stats (transfer mode).
+ *  cvf_ef16_backward_transfer: slab rows of the parameter gradient from both passes; follow with cvf_slab_reduce. */
+int cvf_ef16_front_transfer(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                            const cvf_pp_desc* pp, const float* x, const float* x_lag, int64_t B, float* y_tiled, float* saved,
+                            void* stream);
+int cvf_ef16_backward_transfer(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed, int64_t B,
+                               const float* w, const float* w_lag, const float* feat_tiled, const float* y_tiled,
+                               const double* coef, float* slab, int32_t* step_count, const float* saved, void* stream);
 
 /* --- K5: batch statistics (core.py:406-416,426,428,446-452), fp64, fixed-order two
  * stage reduction.  w [B]; y_tiled [T][k][64]; generator: e_tiled [T][k][64];
