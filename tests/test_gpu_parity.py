@@ -954,3 +954,41 @@ def test_regautoencoder_activations_first_step_vs_oracle(dev, name, module, fn):
         if k_.startswith("reg.") and k_.endswith(f".{len(r_dims) - 1}.bias"):
             continue
         np.testing.assert_allclose(p.grad.cpu().numpy(), sd[k_].grad.numpy(), rtol=20 * RTOL64, atol=20 * RTOL64 * gmax, err_msg=k_)
+
+
+@pytest.mark.parametrize("B,k,dims_h", [(5, 1, [12, 12]), (63, 2, [20, 20, 20]), (65, 4, [8]), (130, 3, [16, 16]), (257, 8, [12, 12]),
+                                        (1000, 3, [20, 20, 20])])
+def test_transfer_step_ragged_batches_vs_oracle(dev, B, k, dims_h):
+    """Transfer-operator mode on the fast layout (cvf_ef16_front_transfer / cvf_ef16_backward_transfer: frames and their lagged
+    partners in one launch, the backward kernel compiled without the tangent chain), on batches that do not fill their last
+    tile, 1..8 nets and 1..3 hidden layers: loss, eigenvalues, ordering and parameter gradient against the fp64 oracle."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    n_atoms, lag = 9, 2
+    traj, w, ref = make_molecule_traj(n_atoms, B + lag, seed=1900 + B, scale=2.0, sigma=0.3)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_atoms)))], use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    dims = [layer.d_r] + dims_h + [1]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(7))
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    eig_w = [1.0 - 0.1 * i for i in range(k)]
+    task = core.EigenFunctionTask(Traj(traj, w, 0.5), layer, model, "/tmp/cvf_test", 12.0, eig_w, beta=1.0, lag_tau=lag * 0.5,
+                                  k=k, device=dev, verbose=False, save_model_every_step=0)
+    assert task._use_ef16()
+    X, Xl, wt, wl = torch.tensor(traj[:B]), torch.tensor(traj[lag:lag + B]), torch.tensor(w[:B]), torch.tensor(w[lag:lag + B])
+    loss, eig, npl, pen, cvec = task.loss_func(X, wt, Xl, wl)
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+    lo, eo, no, po, co = losses.ef_loss(sd, k, oracle_layer(spec), X.double(), wt.double(), Xl.double(), wl.double(), alpha=12.0,
+                                        eig_w=eig_w, lag_idx=lag, dt=0.5)
+    lo.backward()
+    torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(float(npl), float(no.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=RTOL64)
+    assert list(cvec) == list(co)
+    want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
