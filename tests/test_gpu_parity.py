@@ -721,6 +721,34 @@ def test_large_batch_paths_by_duplication(dev):
     np.testing.assert_allclose(g8, g1, rtol=1e-4, atol=2e-6 * np.abs(g1).max())
 
 
+def test_large_batch_transfer_paths_by_duplication(dev):
+    """The same for the transfer-operator mode: 2 x 35 200 frames + partners = 2 200 tiles, past the 1024 slab rows - the backward
+    workgroups of cvf_ef16_backward_transfer walk several tiles and flush an LDS gradient image."""
+    from colvarsfinder import core, nn
+    n_atoms, B, k, lag = 22, 35_200, 3, 3
+    traj, w, ref = make_molecule_traj(n_atoms, B + lag, seed=4243)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_atoms)))], use_angle_value=False)
+    torch.manual_seed(12)
+    model = nn.EigenFunctions([66, 20, 20, 20, 1], k)
+    task = core.EigenFunctionTask(Traj(traj[:64], w[:64], 0.5), make_layer(spec, n_atoms, dev), model, "/tmp/cvf_test", 20.0,
+                                  [1.0, 0.7, 0.4], beta=1.0, lag_tau=lag * 0.5, learning_rate=1e-3, k=k, device=dev,
+                                  verbose=False, save_model_every_step=0)
+    X, Xl = torch.tensor(traj[:B]), torch.tensor(traj[lag:lag + B])
+    W, Wl = torch.tensor(w[:B], dtype=torch.float32), torch.tensor(w[lag:lag + B], dtype=torch.float32)
+
+    def run(n):
+        loss, eig, npl, pen, cvec = task.loss_func(torch.cat([X] * n), torch.cat([W] * n), torch.cat([Xl] * n), torch.cat([Wl] * n))
+        task.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+        return np.asarray([float(loss), float(npl), float(pen)] + [float(e) for e in eig]), g, list(cvec)
+
+    v1, g1, c1 = run(1)
+    v2, g2, c2 = run(2)
+    assert c1 == c2
+    np.testing.assert_allclose(v2, v1, rtol=2e-6)
+    np.testing.assert_allclose(g2, g1, rtol=1e-4, atol=2e-6 * np.abs(g1).max())
+
+
 def test_regae_three_regularisers_three_latents_vs_oracle(dev):
     """RegAutoEncoderTask beyond the fixtures' shapes: K = 3 regularisers, 3 latent components, latent penalties on, unequal
     lags, a batch that is not a multiple of 64 - first-step loss terms and a short training trace against the fp64 oracle."""
