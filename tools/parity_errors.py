@@ -106,6 +106,35 @@ def main():
         row["ref_f32_vs_f64_cv"] = rel_scale(g32["colvar_probe"], g64["colvar_probe"])
         out["ae_train"][name] = row
 
+    out["regae_train"] = {}
+    for name in goldens.REGAE_TRAIN_CASES:   # RegAutoEncoderTask: every option incl. eta[0] and the generator-mode regulariser
+        row = {}
+        g32, g64 = goldens.load(name, "f32"), goldens.load(name, "f64")
+        for tag, g in (("f32", g32), ("f64", g64)):
+            e_dims, d_dims, r_dims = ([int(d) for d in g[k_]] for k_ in ("e_dims", "d_dims", "r_dims"))
+            K, lag_ae, lag_reg, dt = int(g["K"]), int(g["lag_ae"]), int(g["lag_reg"]), float(g["dt"])
+            model = nn.RegAutoEncoder(e_dims, d_dims, r_dims, K)
+            model.load_state_dict(goldens.state_dict(g, dtype=torch.float32))
+            traj = np.array(g["traj"])
+            layer = make_layer(goldens.pp_spec(g), traj.shape[1] if traj.ndim == 3 else 0, dev)
+            task = core.RegAutoEncoderTask(Traj(traj, np.array(g["w"]), dt), layer, model, "/tmp/cvf_parity", eig_weights=[float(v) for v in g["eig_w"]],
+                                           learning_rate=float(g["lr"]), batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]),
+                                           alpha=float(g["alpha"]), gamma=[float(v) for v in g["gamma"]],
+                                           eta=[float(v) for v in g["eta"]] if "eta" in g.files else [0.0, 0.0, 0.0],
+                                           lag_tau_ae=lag_ae * dt, lag_tau_reg=lag_reg * dt, beta=float(g["beta"]) if "beta" in g.files else 1.0,
+                                           freeze_encoder=bool(g["freeze"]), device=dev, verbose=False, save_model_every_step=0)
+            np.random.seed(int(g["seed"]))
+            task.train()
+            tr = np.stack([e[0].numpy() for e in task.loss_list])
+            row[f"first_step_loss_vs_{tag}"] = rel(tr[0, 0, 0], np.array(g["train_loss"])[0, 0, 0])
+            row[f"step_loss_vs_{tag}"] = rel(tr[..., 0], np.array(g["train_loss"])[..., 0])
+            cv = task.colvar_model()(torch.tensor(traj[:64], dtype=torch.float32)).detach().numpy()
+            row[f"cv_vs_{tag}"] = rel_scale(cv, g["colvar_probe"])
+            row["steps"] = int(tr.shape[0] * tr.shape[1])
+        row["ref_f32_vs_f64_step_loss"] = rel(np.array(g32["train_loss"])[..., 0], np.array(g64["train_loss"])[..., 0])
+        row["ref_f32_vs_f64_cv"] = rel_scale(g32["colvar_probe"], g64["colvar_probe"])
+        out["regae_train"][name] = row
+
     def worst(key):
         return max(r[key] for sec in ("kat", "ef_train", "ae_train") for r in out[sec].values() if key in r)
 
@@ -113,7 +142,10 @@ def main():
                        "worst_step_loss_vs_f32_traces": worst("step_loss_vs_f32"), "worst_cv_vs_f64": worst("cv_vs_f64"),
                        "worst_cv_vs_f32": worst("cv_vs_f32"),
                        "reference_own_f32_vs_f64_worst_step_loss": worst("ref_f32_vs_f64_step_loss"),
-                       "reference_own_f32_vs_f64_worst_cv": worst("ref_f32_vs_f64_cv")}
+                       "reference_own_f32_vs_f64_worst_cv": worst("ref_f32_vs_f64_cv"),
+                       "regae_worst_first_step_loss_vs_f64": max(r["first_step_loss_vs_f64"] for r in out["regae_train"].values()),
+                       "regae_worst_step_loss_vs_f64_traces": max(r["step_loss_vs_f64"] for r in out["regae_train"].values()),
+                       "regae_reference_own_f32_vs_f64_worst_step_loss": max(r["ref_f32_vs_f64_step_loss"] for r in out["regae_train"].values())}
     path = os.path.join(ROOT, "gpurun_out", f"{tag_out}_parity_errors.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as fh:
