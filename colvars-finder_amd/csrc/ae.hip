@@ -9,6 +9,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// (csrc/ef_mfma.hip) fixed-order sum of slab rows [+ mask] [+ Adam] [+ one extra block adding n_pair [a, b] rows -> [a, b, a / b]]
+int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
+                         const cvf_adam_args* adam, void* stream, const double* pair_partial = nullptr, int n_pair = 0,
+                         double* pair_out = nullptr);
+
 namespace {
 
 constexpr int P = 66;  // LDS row pitch in dwords
@@ -572,17 +577,19 @@ extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const fl
                      partial, grad ? step_count : nullptr, none);
   int rc = cvf_check_launch("ae_mfma_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(ae_loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, G, out2);
-  rc = cvf_check_launch("ae_loss_sum_kernel");
-  if (rc || grad == nullptr) return rc;
-  // fixed-order sum of the slab rows (+ the Adam update when asked for): the kernel the eigenfunction path uses
+  if (grad == nullptr) {   // loss only: the blocks' [sum w e^2, sum w] pairs, fixed order
+    hipLaunchKernelGGL(ae_loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, G, out2);
+    return cvf_check_launch("ae_loss_sum_kernel");
+  }
+  // fixed-order sum of the slab rows (+ the Adam update when asked for): the kernel the eigenfunction path uses; the loss
+  // pairs ride along in one extra block of the same launch
   cvf_adam_args ad;
   if (adam != nullptr) {
     ad = *adam;
     ad.mlp = nullptr;      // an AutoEncoder has no MFMA fragment copy to refresh
     ad.packed = nullptr;
   }
-  return cvf_slab_reduce(slab, G, Pn, grad, adam != nullptr ? &ad : nullptr, stream);
+  return cvf_slab_reduce_impl(slab, G, Pn, grad, nullptr, adam != nullptr ? &ad : nullptr, stream, partial, G, out2);
 }
 
 // ---- RegAutoEncoderTask (time-lagged autoencoder + transfer-operator regulariser heads)
@@ -644,9 +651,6 @@ extern "C" int cvf_regae_forward(const cvf_mlp_desc* mlp, const float* theta, co
   hipLaunchKernelGGL(ae_loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, G, out2);
   return cvf_check_launch("ae_loss_sum_kernel");
 }
-
-int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
-                         const cvf_adam_args* adam, void* stream);
 
 extern "C" int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
                                   int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, const float* w_lag,

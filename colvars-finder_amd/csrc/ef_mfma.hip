@@ -1187,7 +1187,29 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
 constexpr int kSlabPX = 32, kSlabGY = 32, kSlabU = 10;   // parameters per block, row groups, loads in flight per thread
 __global__ __launch_bounds__(kSlabPX * kSlabGY) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nrows, int P,
                                                                         float* __restrict__ grad, const float* __restrict__ mask,
-                                                                        int use_adam, AdamDev adam, cvf_mlp_desc mlp) {
+                                                                        int use_adam, AdamDev adam, cvf_mlp_desc mlp,
+                                                                        const double* __restrict__ pair_partial, int n_pair,
+                                                                        double* __restrict__ pair_out) {
+  // (optional rider: one extra block adds n_pair rows of [a, b] partial sums in a fixed order -> pair_out = [a, b, a / b];
+  //  the autoencoder step's loss, which would otherwise be a launch of its own between the step kernel and this one)
+  if (pair_partial != nullptr && blockIdx.x == gridDim.x - 1) {
+    const int t = threadIdx.y * kSlabPX + threadIdx.x;
+    if (t < CVF_WAVE) {
+      double a0 = 0.0, a1 = 0.0;
+      for (int g = t; g < n_pair; g += CVF_WAVE) {
+        a0 += pair_partial[2 * g];
+        a1 += pair_partial[2 * g + 1];
+      }
+      a0 = wave_sum(a0);
+      a1 = wave_sum(a1);
+      if (t == 0) {
+        pair_out[0] = a0;
+        pair_out[1] = a1;
+        pair_out[2] = a0 / a1;
+      }
+    }
+    return;
+  }
   __shared__ float sub[kSlabGY][kSlabPX];
   __shared__ PackTab tab;
   const int px = threadIdx.x, gy = threadIdx.y;
@@ -1522,13 +1544,14 @@ extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, c
 }
 
 int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
-                         const cvf_adam_args* adam, void* stream);
+                         const cvf_adam_args* adam, void* stream, const double* pair_partial = nullptr, int n_pair = 0,
+                         double* pair_out = nullptr);
 extern "C" int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,
                                void* stream) {
   return cvf_slab_reduce_impl(slab, n_rows, n_params, grad, nullptr, adam, stream);
 }
 int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
-                         const cvf_adam_args* adam, void* stream) {
+                         const cvf_adam_args* adam, void* stream, const double* pair_partial, int n_pair, double* pair_out) {
   CVF_REQUIRE(slab && grad && n_rows > 0 && n_params > 0, "cvf_slab_reduce: bad argument");
   AdamDev ad{};
   cvf_mlp_desc md = {};
@@ -1540,7 +1563,8 @@ int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, fl
                  adam->step_count, adam->packed, adam->lr_dev};
     if (adam->packed) md = *adam->mlp;
   }
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n_params + kSlabPX - 1) / kSlabPX)), dim3(kSlabPX, kSlabGY), 0, (hipStream_t)stream, slab,
-                     n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md);
+  const unsigned nb = (unsigned)((n_params + kSlabPX - 1) / kSlabPX) + (pair_partial != nullptr ? 1u : 0u);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb), dim3(kSlabPX, kSlabGY), 0, (hipStream_t)stream, slab,
+                     n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md, pair_partial, n_pair, pair_out);
   return cvf_check_launch("slab_reduce_kernel");
 }
