@@ -77,10 +77,44 @@ def shard_batches(n, bs, r=None, w=None):
     return pos, b - a
 
 
+_abi_comm = None   # CVF_COMM=abi: the communicator of include/cvf.h's cvf_comm_* (RCCL behind the C ABI)
+
+
+def _abi():
+    """With ``CVF_COMM=abi`` the two sums go through ``cvf_comm_allreduce_*`` of the C ABI (the same RCCL all-reduce, issued on
+    the current stream by the library instead of by torch.distributed) - the path a host without PyTorch would take; the
+    unique id travels from rank 0 over the torch process group.  Default: torch.distributed."""
+    global _abi_comm
+    if os.environ.get("CVF_COMM", "") != "abi" or not torch.cuda.is_available():
+        return None
+    if _abi_comm is None:
+        import ctypes
+        from . import _hip
+        lib = _hip.lib()
+        nbytes = lib.cvf_comm_unique_id_bytes()
+        uid = torch.zeros(nbytes, dtype=torch.uint8)
+        if rank() == 0:
+            _hip.check(lib.cvf_comm_unique_id(uid.data_ptr()), "cvf_comm_unique_id")
+        if world() > 1:
+            dev_uid = uid.cuda() if backend() == "nccl" else uid
+            dist.broadcast(dev_uid, src=0)
+            uid = dev_uid.cpu()
+        handle = ctypes.c_void_p()
+        _hip.check(lib.cvf_comm_init(ctypes.byref(handle), rank(), world(), uid.data_ptr()), "cvf_comm_init")
+        _abi_comm = handle
+    return _abi_comm
+
+
 def allreduce_sum_(t):
     """In-place sum over ranks; a no-op in a single-process run."""
     if collectives():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        comm = _abi() if t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous() else None
+        if comm is not None:
+            from . import _hip
+            fn = _hip.lib().cvf_comm_allreduce_f64 if t.dtype == torch.float64 else _hip.lib().cvf_comm_allreduce_f32
+            _hip.check(fn(comm, _hip.ptr(t), t.numel(), _hip.stream()), "cvf_comm_allreduce")
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 

@@ -103,6 +103,12 @@ _SIGNATURES = {
     "cvf_ef16_backward_transfer": (C.c_int, [C.POINTER(EFCfg), C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),
+    "cvf_comm_unique_id_bytes": (C.c_int, []),
+    "cvf_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cvf_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
+    "cvf_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cvf_comm_allreduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cvf_comm_destroy": (C.c_int, [C.c_void_p]),
     "cvf_ef_stats_scratch_doubles": (C.c_int64, [C.c_int, C.c_int]),
     "cvf_ef_stats": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

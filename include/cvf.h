@@ -348,6 +348,19 @@ int cvf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n
 int cvf_sgd_step(float* theta, const float* grad, int64_t n, double lr, const float* lr_dev, const cvf_mlp_desc* mlp,
                  float* packed, void* stream); /* mlp/packed: NULL, or the nets' desc + fragment buffer to refresh */
 
+/* --- cross-rank sums of the data-parallel step (the reference has no multi-GPU path): RCCL all-reduces
+ * (in place, SUM) issued on `stream`, for hosts that bind this library without PyTorch - one process per GPU, the caller's
+ * current HIP device at cvf_comm_init is the rank's GPU.  Collective #1 = the fp64 batch sums between cvf_ef16_front /
+ * cvf_ef_stats (loss_vec == NULL) and cvf_ef_loss; collective #2 = the fp32 flat gradient between cvf_slab_reduce
+ * (adam == NULL) and cvf_adam_step.  Rank 0 calls cvf_comm_unique_id and hands the cvf_comm_unique_id_bytes() bytes to the
+ * other ranks by any means (the shipped Python host: torch.distributed broadcast); RCCL is located at run time. */
+int cvf_comm_unique_id_bytes(void);
+int cvf_comm_unique_id(void* id_host);
+int cvf_comm_init(void** comm, int rank, int world, const void* id_host);
+int cvf_comm_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
+int cvf_comm_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
+int cvf_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -331,3 +331,30 @@ def test_nonuniform_hidden_widths_are_padded_and_match_the_oracle(dev, tmp_path)
     for n, p in model.named_parameters():
         p.data.copy_(saved[n])
     assert np.isfinite(np.stack([e[0].numpy() for e in task.loss_list])).all()
+
+
+def test_comm_abi_single_rank_roundtrip(dev):
+    """cvf_comm_* (the data-parallel step's two sums behind the C ABI: RCCL located at run time): id, communicator of one rank,
+    in-place fp64 / fp32 all-reduce on the current stream (identity with one rank), destroy.  More ranks need more GPUs than
+    the test box has; the multi-rank arithmetic of the step itself is covered by tests/test_dist_gloo.py and tools/check_dp2.py."""
+    import ctypes
+    from colvarsfinder import _hip
+    lib = _hip.lib()
+    n = lib.cvf_comm_unique_id_bytes()
+    assert n == 128
+    uid = torch.zeros(n, dtype=torch.uint8)
+    _hip.check(lib.cvf_comm_unique_id(uid.data_ptr()), "cvf_comm_unique_id")
+    assert int(uid.to(torch.int64).abs().sum()) > 0
+    with torch.cuda.device(dev):
+        comm = ctypes.c_void_p()
+        _hip.check(lib.cvf_comm_init(ctypes.byref(comm), 0, 1, uid.data_ptr()), "cvf_comm_init")
+        a = torch.arange(13, device=dev, dtype=torch.float64) * 0.37
+        b = torch.randn(6603, device=dev, dtype=torch.float32)
+        a0, b0 = a.clone(), b.clone()
+        _hip.check(lib.cvf_comm_allreduce_f64(comm, _hip.ptr(a), a.numel(), _hip.stream()), "cvf_comm_allreduce_f64")
+        _hip.check(lib.cvf_comm_allreduce_f32(comm, _hip.ptr(b), b.numel(), _hip.stream()), "cvf_comm_allreduce_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(a, a0) and torch.equal(b, b0)
+        assert lib.cvf_comm_allreduce_f64(None, _hip.ptr(a), 13, _hip.stream()) != 0        # bad argument: error code, not a crash
+        assert b"bad argument" in lib.cvf_last_error()
+        _hip.check(lib.cvf_comm_destroy(comm), "cvf_comm_destroy")

@@ -686,6 +686,22 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(dev):
         assert rep[kind]["max_rel_loss_diff"] < 2e-4, rep
 
 
+def test_one_rank_rccl_collectives_inside_the_graphs(dev):
+    """The data-parallel step with REAL RCCL all-reduces captured inside its hipGraphs (one-rank nccl group,
+    CVF_FORCE_COLLECTIVES=1), through torch.distributed and through the C ABI's cvf_comm_* (CVF_COMM=abi): both reproduce the
+    plain single-process training, generator and transfer mode (tools/check_comm1.py)."""
+    import json
+    import subprocess
+    import sys
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_nccl_available():
+        pytest.skip("nccl (RCCL) backend not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "check_comm1.py")], capture_output=True, text=True, timeout=900)
+    rep = json.loads(res.stdout.strip().splitlines()[-1]) if res.stdout.strip() else {}
+    assert res.returncode == 0 and rep.get("ok"), (rep, res.stderr[-1500:])
+
+
 def test_large_batch_paths_by_duplication(dev):
     """Size-independent check of the large-launch paths (more than 1024 tiles: streaming alignment kernel, the batch sums'
     two-stage reduction, backward workgroups walking several tiles): a batch made of two copies of a 35 200-frame batch has
