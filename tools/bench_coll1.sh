@@ -1,0 +1,14 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: the headline step with and without the data-parallel code path forced on in a one-rank nccl group
+# (two real RCCL all-reduces per step inside the captured graphs, unfused Adam) - the fixed cost the multi-GPU step pays on
+# top of the single-GPU one before any inter-GPU latency.
+export RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29877
+for b in 20000 100000; do
+  for mode in plain coll abi; do
+    unset CVF_FORCE_COLLECTIVES CVF_COMM
+    [ $mode != plain ] && export CVF_FORCE_COLLECTIVES=1
+    [ $mode = abi ] && export CVF_COMM=abi
+    python bench.py --steps 40 --warmup 5 --no-extras --cpu-seconds 0 --batch $b --frames $((b*5)) 2>/dev/null | tail -1 > /tmp/line.json
+    python3 -c "import json; d=json.load(open('/tmp/line.json')); print('$mode', $b, 'us/step', round(d['ms_per_step']*1000,2), 'graphs', d['hip_graph'])"
+  done
+done
