@@ -592,7 +592,7 @@ class EigenFunctionTask(TrainingTask):
         return ws
 
     def _use_ef16(self):
-        """The fast layout: the 16-frames-per-wave step (csrc/ef16.hip; generator and transfer-operator mode), decided once."""
+        """The fast layout: the 16-frames-per-wave step (csrc/ef16_front.hip, ef16_back.hip; generator and transfer-operator mode), decided once."""
         if self._ef16 is None:
             self._ef16 = (not self._pipeline and os.environ.get("CVF_NO_EF16_TRANSFER" if self.lag_idx > 0 else "CVF_NO_EF16") is None
                           and bool(_hip.lib().cvf_ef16_supported(self._flat.desc, self._pp)))

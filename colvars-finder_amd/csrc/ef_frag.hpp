@@ -1,5 +1,5 @@
 // Register-level building blocks of the eigenfunction-net kernels on the matrix cores (shared by ef_mfma.hip and
-// ef16.hip): the "acc layout" of hidden vectors, weight-fragment loads, layer products, tanh, LDS operand images.
+// ef16_front.hip, ef16_back.hip): the "acc layout" of hidden vectors, weight-fragment loads, layer products, tanh, LDS operand images.
 #pragma once
 #include "cvf_common.hpp"
 #include "cvf_pack.hpp"

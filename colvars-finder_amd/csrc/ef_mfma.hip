@@ -803,7 +803,7 @@ struct EfBwdArgs {
 // each weight-gradient product.  Splitting the tile over waves shortens each wave's dependent chain and
 // puts two waves on every SIMD, which is what hides the LDS / L2 latencies at small batch sizes.
 // WPB = 4 (cvf_ef16_backward): wave w owns the 16 CONSECUTIVE frames 16 w .. 16 w + 15 of the tile - the unit whose activations
-// the 16-frames-per-wave front kernel (ef16.hip) left behind (SAVED = 2: its hand-off layout) - a quarter of the dependent
+// the 16-frames-per-wave front kernel (ef16_front.hip, ef16_back.hip) left behind (SAVED = 2: its hand-off layout) - a quarter of the dependent
 // chain per wave, four blocks of four waves per CU.
 template <int H, int NH, int WPB, int SAVED>
 __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kernel(EfBwdArgs args, cvf_mlp_desc mlp,

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(KT <= 5 ? 1024 : 512) void ef_stats_finish_kernel(c
                                                                double* __restrict__ coef) {
   __shared__ double fin[kMaxStats];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  // (24 row loads in flight per lane: the 1250 unit rows of a 20 000-frame batch (csrc/ef16.hip) are ONE round trip per
+  // (24 row loads in flight per lane: the 1250 unit rows of a 20 000-frame batch (csrc/ef16_front.hip, ef16_back.hip) are ONE round trip per
   //  statistic; with eight it was three dependent ones, 9 us for this launch)
   // stat_major: partial is [statistic][row] - a wave's 64 lanes read 512 consecutive bytes per load instead of one 8-byte
   // word in each of 64 rows (64 cache lines per instruction: with 1250 rows that access pattern alone was 8 us)

@@ -218,7 +218,7 @@ int cvf_ef_align_fwd_metric_stats(const cvf_mlp_desc* mlp, const float* theta, c
                                   const float* w, double* scratch, double* stats, double* loss_vec, double* coef,
                                   void* stream);
 
-/* --- The generator-mode step with SIXTEEN frames per wave (csrc/ef16.hip), for the shapes of cvf_ef16_supported(): pure position
+/* --- The generator-mode step with SIXTEEN frames per wave (csrc/ef16_front.hip, ef16_back.hip), for the shapes of cvf_ef16_supported(): pure position
  * features on a contiguous align set, d_r <= 72 (the dipeptide-sized configurations 3 and 4).  Same mathematics and the same
  * outputs as cvf_ef_align_fwd_metric_stats + cvf_ef_backward; what differs is the decomposition: a wave owns 16 frames (the
  * matrix instruction's N), so the launch has four times the waves of a quarter of the dependent chain each, 3-5 waves per SIMD.

@@ -1,10 +1,11 @@
-// Developer tool (not part of the library): the 16-frames-per-wave generator step (ef16.hip front kernel + the four-wave
+// Developer tool (not part of the library): the 16-frames-per-wave generator step (ef16_front.hip + ef16_back.hip: the front kernel and the four-wave
 // backward kernel of ef_mfma.hip) at the config-3 shape - kernel times with HIP events at several batch sizes and, with
 // -DCVF_STAMPS, s_memtime phase stamps per wave.
 // Build + run on the GPU box:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCVF_STAMPS -DCVF_STAMP_WPB=4 -Iinclude -Icolvars-finder_amd/csrc -Wno-pass-failed \
 //       tools/ef16_probe.hip colvars-finder_amd/csrc/stats.hip -o /tmp/ef16_probe && /tmp/ef16_probe
-#include "../colvars-finder_amd/csrc/ef16.hip"
+#include "../colvars-finder_amd/csrc/ef16_front.hip"
+#include "../colvars-finder_amd/csrc/ef16_back.hip"
 #include "../colvars-finder_amd/csrc/ef_mfma.hip"
 #include <cstdio>
 #include <random>
