@@ -265,7 +265,7 @@ def main():
         task.optimizer.exp_avg.zero_(); task.optimizer.exp_avg_sq.zero_(); task.optimizer.step_count.zero_()
 
     # ---- the headline workload of this N
-    if world == 1 or scaling == "weak":
+    if scaling == "weak":   # (N = 1 without --scaling: config 3; `--gpus 1 --scaling strong` runs the N = 1 point of the strong-scaling job)
         frames_rank, B = args.frames, min(args.batch, args.frames)
         workload = ("BASELINE config 3: alanine-dipeptide-shaped EigenFunctionTask, generator mode, k=3, 22 atoms, align+position "
                     "features d_r=66, nets [66,20,20,20,1], diag_coeff, Adam")
@@ -675,3 +675,9 @@ def main_regae(args):
 
 if __name__ == "__main__":
     main()
+    try:   # (leave the process group in order: every rank is past its last collective here)
+        import torch.distributed as _d
+        if _d.is_available() and _d.is_initialized():
+            _d.destroy_process_group()
+    except Exception:
+        pass
