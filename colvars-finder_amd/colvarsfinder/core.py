@@ -901,21 +901,28 @@ class EigenFunctionTask(TrainingTask):
 
         elog = _AsyncEpochLog(log_tr, log_te, len(tr_batches), len(te_batches), on_epoch)
 
-        def epoch_body():
-            for it, (a, b) in enumerate(tr_batches):
-                X, w, Xl, wl = sl(Xtr, a, b)
-                nxt = None
-                if self._pipeline and it + 1 < len(tr_batches):
-                    Xn, _, Xln, _ = sl(Xtr, *tr_batches[it + 1])
-                    nxt = (Xn, Xln)
-                self.train_step(X, w, Xl, wl, slot=it % 2, aligned=self._pipeline and it > 0, prefetch=nxt, out=log_tr[it])
-            for it, (a, b) in enumerate(te_batches):              # core.py:535-551 (same loss, no update)
-                X, w, Xl, wl = sl(Xte, a, b)
-                self._forward(X, w, Xl, wl, out=log_te[it])
+        def train_one(it):
+            X, w, Xl, wl = sl(Xtr, *tr_batches[it])
+            nxt = None
+            if self._pipeline and it + 1 < len(tr_batches):
+                Xn, _, Xln, _ = sl(Xtr, *tr_batches[it + 1])
+                nxt = (Xn, Xln)
+            self.train_step(X, w, Xl, wl, slot=it % 2, aligned=self._pipeline and it > 0, prefetch=nxt, out=log_tr[it])
+
+        def test_one(it):                                          # core.py:535-551 (same loss, no update)
+            X, w, Xl, wl = sl(Xte, *te_batches[it])
+            self._forward(X, w, Xl, wl, out=log_te[it])
+
+        # every step of the epoch (static batches) replays from hipGraphs: ONE graph per epoch, or - small batches on a long
+        # trajectory - one per kEpochChunk steps (a graph of many thousands of kernel nodes takes seconds to instantiate)
+        kEpochChunk = 256
+        steps = [(train_one, it) for it in range(len(tr_batches))] + [(test_one, it) for it in range(len(te_batches))]
+        chunks = [steps[c:c + kEpochChunk] for c in range(0, len(steps), kEpochChunk)]
 
         for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
             self.model.train()
-            self._graph_call(("epoch",), epoch_body)   # every step of the epoch (static batches): one hipGraph replay
+            for ci, chunk in enumerate(chunks):
+                self._graph_call(("epoch", ci), lambda chunk=chunk: [fn(it) for fn, it in chunk])
             elog.push(epoch)        # (the host reads the epoch's numbers later; epochs that save or plot flush first)
             saving = self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1
             plotting = self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1

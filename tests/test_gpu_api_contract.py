@@ -358,3 +358,28 @@ def test_comm_abi_single_rank_roundtrip(dev):
         assert lib.cvf_comm_allreduce_f64(None, _hip.ptr(a), 13, _hip.stream()) != 0        # bad argument: error code, not a crash
         assert b"bad argument" in lib.cvf_last_error()
         _hip.check(lib.cvf_comm_destroy(comm), "cvf_comm_destroy")
+
+
+def test_epoch_graphs_in_chunks_equal_eager_launches(dev, tmp_path):
+    """An epoch of more steps than one hipGraph takes (small batches: 300 steps > the 256-step chunk) replays from several graphs
+    and gives the numbers of the same training with eager launches, step by step."""
+    from colvarsfinder import core, nn
+    traj, w, ref = make_molecule_traj(10, 750, seed=77)
+
+    def run(graphs):
+        torch.manual_seed(3)
+        np.random.seed(3)
+        model = nn.EigenFunctions([30, 12, 12, 1], 2)
+        task = core.EigenFunctionTask(Traj(traj, w, 1.0), _position_layer(10, ref, dev), model, str(tmp_path), 10.0, [1.0, 0.5], k=2,
+                                      batch_size=2, num_epochs=3, learning_rate=1e-3, device=dev, verbose=False, save_model_every_step=0)
+        task._use_graphs = graphs
+        task.train()
+        if graphs:
+            assert len(task._graphs) >= 2          # the epoch was captured as more than one graph
+        return np.stack([e[0].numpy() for e in task.loss_list]), np.stack([e[1].numpy() for e in task.loss_list])
+
+    tr_g, te_g = run(True)
+    tr_e, te_e = run(False)
+    assert tr_g.shape[1] == 300 and te_g.shape[1] == 75
+    np.testing.assert_array_equal(tr_g, tr_e)
+    np.testing.assert_array_equal(te_g, te_e)
