@@ -189,8 +189,12 @@ class _FlatParams:
         hidden = dims[1:-1]
         if not (2 <= L <= 6) or dims[-1] != 1 or not hidden or max(hidden) > max(_hip.EF_HIDDEN_WIDTHS):
             return False
+        from .nn import ACT_TANH, ACT_RELU, ACT_ELU, ACT_LEAKY_RELU
+        act0 = chains[0][0][1]
+        if act0 not in (ACT_TANH, ACT_RELU, ACT_ELU, ACT_LEAKY_RELU):   # (a padded unit must emit act(0) = 0: not Sigmoid / Softplus)
+            return False
         for c in chains:
-            if [c[0][0].in_features] + [lin.out_features for lin, _ in c] != dims or [a for _, a in c] != [True] * (L - 1) + [False]:
+            if [c[0][0].in_features] + [lin.out_features for lin, _ in c] != dims or [a for _, a in c] != [act0] * (L - 1) + [0]:
                 return False
         H = min(w for w in _hip.ef_widths(L - 1) if w >= max(hidden))
         if all(h == H for h in hidden):
@@ -204,7 +208,7 @@ class _FlatParams:
         d = _hip.MLPDesc()
         d.n_nets, d.n_layers, d.n_params = len(chains), L, self.n
         for l in range(L):
-            d.dims[l], d.dims[l + 1], d.act[l] = pdims[l], pdims[l + 1], int(l < L - 1)
+            d.dims[l], d.dims[l + 1], d.act[l] = pdims[l], pdims[l + 1], (act0 if l < L - 1 else 0)
         self._views, pos = [], 0
         for i, chain in enumerate(chains):
             for l, (lin, _) in enumerate(chain):
@@ -517,7 +521,8 @@ class EigenFunctionTask(TrainingTask):
                 "EigenFunctionTask on MI355X: no kernel instance for nets with layer widths "
                 f"{[d.dims[i] for i in range(d.n_layers + 1)]}. Supported: 1 to 5 hidden layers of at most "
                 f"{max(_hip.EF_HIDDEN_WIDTHS)} units each (kernel widths {_hip.EF_HIDDEN_WIDTHS}, for 4 or 5 hidden layers 20 and 32; "
-                f"other widths are zero-padded to the next one), scalar output, Tanh between layers, k <= {_hip.MAX_NETS} "
+                f"other widths are zero-padded to the next one - not with Sigmoid / Softplus, whose padding would not stay zero), "
+                f"scalar output, ONE activation of include/cvf.h after every hidden layer, k <= {_hip.MAX_NETS} "
                 "(csrc/ef_mfma.hip: ef_shape / ef_dispatch).")
 
         # The frames stay resident in HBM (core.py:343-344 keeps CPU copies and moves every batch, core.py:500).  One process:

@@ -153,7 +153,7 @@ def _act_code(module):
         return ACT_SOFTPLUS
     raise NotImplementedError(
         f"the MI355X kernels implement Tanh, Sigmoid, ReLU, ELU(alpha=1), LeakyReLU(0.01) and Softplus(beta=1, threshold=20) "
-        f"in the autoencoder tasks and Tanh in EigenFunctionTask (got {module})")
+        f"(got {module})")
 
 
 def _chain_layers(seq):
@@ -177,10 +177,8 @@ def mlp_layout(model):
         pos += p.numel()
     if isinstance(model, EigenFunctions):
         chains = [_chain_layers(net) for net in model.eigen_funcs]
-        for chain in chains:   # the eigenfunction kernels carry tanh and its first two derivatives
-            if any(act not in (ACT_NONE, ACT_TANH) for _, act in chain):
-                raise NotImplementedError("EigenFunctionTask on MI355X: the eigenfunction kernels implement Tanh activations only "
-                                          "(they need the activation's first two derivatives); the autoencoder tasks take others")
+        # (the eigenfunction kernels need the activation's first two derivatives: the 16-frame kernels carry tanh's, the
+        #  64-frame kernels take every code above - csrc/ef_mfma.hip: ef_shape; other shapes are rejected by the task)
     elif isinstance(model, AutoEncoder):
         chains = [_chain_layers(model.encoder) + _chain_layers(model.decoder)]
     else:

@@ -91,6 +91,19 @@ __device__ __forceinline__ float cvf_act(int kind, float z) {
     default: return z;
   }
 }
+// f''(z) through the output h (the eigenfunction kernels' generator mode differentiates the nets twice)
+__device__ __forceinline__ float cvf_act_d2(int kind, float h) {
+  switch (kind) {
+    case CVF_ACT_TANH: return -2.0f * h * (1.0f - h * h);
+    case CVF_ACT_SIGMOID: return h * (1.0f - h) * (1.0f - 2.0f * h);
+    case CVF_ACT_ELU: return h > 0.0f ? 0.0f : h + 1.0f;
+    case CVF_ACT_SOFTPLUS: {
+      const float s = h > 20.0f ? 1.0f : 1.0f - expf(-h);
+      return s * (1.0f - s);
+    }
+    default: return 0.0f;   // piecewise linear (ReLU, LeakyReLU) or none
+  }
+}
 __device__ __forceinline__ float cvf_act_d1(int kind, float h) {
   switch (kind) {
     case CVF_ACT_TANH: return 1.0f - h * h;

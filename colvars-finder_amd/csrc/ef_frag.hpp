@@ -230,15 +230,39 @@ __device__ __forceinline__ void set_const(Vec<H, FT>& X, const HConst<H>& b) {
       for (int r = 0; r < 4; ++r) X.v[rt][ft][r] = b.c[rt][r];
 }
 
+// The hidden layers' activation.  `act` (cvf_mlp_desc.act[0], uniform over the launch) defaults to Tanh - the 16-frame kernels,
+// which are instantiated for Tanh only, call without it and the other branch folds away; the 64-frame kernels pass the net's
+// code, so that EigenFunctionTask takes the other activations of include/cvf.h on them (one wave-uniform branch per vector).
+// (the other activations through real calls: inlined into every element of every vector of every kernel instance they
+//  took the compilation of ef_mfma.hip from 2 to 13 minutes; the Tanh path stays inline and pays nothing for them)
+__device__ __attribute__((noinline)) float ef_act_slow(int act, float z) { return cvf_act(act, z); }
+__device__ __attribute__((noinline)) float ef_act_d1_slow(int act, float h) { return cvf_act_d1(act, h); }
+__device__ __attribute__((noinline)) float ef_act_d2_slow(int act, float h) { return cvf_act_d2(act, h); }
+
 template <int H, int FT>
-__device__ __forceinline__ void tanh_inplace(Vec<H, FT>& X) {
+__device__ __forceinline__ void tanh_inplace(Vec<H, FT>& X, int act = CVF_ACT_TANH) {
+  if (act == CVF_ACT_TANH) {
 #pragma unroll
-  for (int rt = 0; rt < Hid<H>::RT; ++rt)
+    for (int rt = 0; rt < Hid<H>::RT; ++rt)
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft)
+      for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * rt + r < Hid<H>::NG) X.v[rt][ft][r] = cvf_tanh(X.v[rt][ft][r]);  // padding groups stay 0
+        for (int r = 0; r < 4; ++r)
+          if (4 * rt + r < Hid<H>::NG) X.v[rt][ft][r] = cvf_tanh(X.v[rt][ft][r]);  // padding groups stay 0
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < Hid<H>::RT; ++rt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * rt + r < Hid<H>::NG) X.v[rt][ft][r] = ef_act_slow(act, X.v[rt][ft][r]);
+  }
+}
+// f'(z) of one element through its output h
+__device__ __forceinline__ float act_d1(int act, float h) {
+  if (act == CVF_ACT_TANH) return 1.0f - h * h;
+  return ef_act_d1_slow(act, h);
 }
 
 // per-lane copy of a length-H vector in hidden order: c[rt][r] = v[hid_feature(rt,r,q)]
@@ -265,12 +289,12 @@ __device__ __forceinline__ void chain_forward(const cvf_mlp_desc& mlp, const flo
   if constexpr (LEAN) {
     init_bias<H, FT>(h[0], theta + mlp.b_off[net][0], q);
     layer0_apply<H, FT, 3>(h[0], pk + L.f0(), mlp.dims[0], in_lane, lane);
-    tanh_inplace<H, FT>(h[0]);
+    tanh_inplace<H, FT>(h[0], mlp.act[0]);
 #pragma unroll
     for (int l = 1; l < NH; ++l) {
       init_bias<H, FT>(h[l], theta + mlp.b_off[net][l], q);
       hidden_apply<H, FT>(h[l], pk + L.fh(l), h[l - 1], lane);
-      tanh_inplace<H, FT>(h[l]);
+      tanh_inplace<H, FT>(h[l], mlp.act[0]);
     }
     return;
   }
@@ -284,13 +308,13 @@ __device__ __forceinline__ void chain_forward(const cvf_mlp_desc& mlp, const flo
   set_const<H, FT>(h[0], bias[0]);
   layer0_apply<H, FT>(h[0], pk + L.f0(), mlp.dims[0], in_lane, lane);
   CVF_STAMP(2);
-  tanh_inplace<H, FT>(h[0]);
+  tanh_inplace<H, FT>(h[0], mlp.act[0]);
   CVF_STAMP(3);
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
     set_const<H, FT>(h[l], bias[l]);
     hidden_mul<H, FT>(h[l], hf[l - 1], h[l - 1]);
-    tanh_inplace<H, FT>(h[l]);
+    tanh_inplace<H, FT>(h[l], mlp.act[0]);
   }
 }
 
@@ -398,18 +422,27 @@ __device__ __forceinline__ void store_image(float* S, const Vec<H, FT>& X, const
     }
 }
 
-// tdot = (1 - h^2) .* t
+// tdot = f'(z) .* t   (Tanh: (1 - h^2) .* t)
 template <int H, int FT>
-__device__ __forceinline__ void tangent_of(Vec<H, FT>& td, const Vec<H, FT>& h, const Vec<H, FT>& t) {
+__device__ __forceinline__ void tangent_of(Vec<H, FT>& td, const Vec<H, FT>& h, const Vec<H, FT>& t, int act = CVF_ACT_TANH) {
+  if (act == CVF_ACT_TANH) {
 #pragma unroll
-  for (int rt = 0; rt < Hid<H>::RT; ++rt)
+    for (int rt = 0; rt < Hid<H>::RT; ++rt)
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft)
+      for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float hv = h.v[rt][ft][r];
-        td.v[rt][ft][r] = (1.0f - hv * hv) * t.v[rt][ft][r];
-      }
+        for (int r = 0; r < 4; ++r) {
+          const float hv = h.v[rt][ft][r];
+          td.v[rt][ft][r] = (1.0f - hv * hv) * t.v[rt][ft][r];
+        }
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < Hid<H>::RT; ++rt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) td.v[rt][ft][r] = ef_act_d1_slow(act, h.v[rt][ft][r]) * t.v[rt][ft][r];
+  }
 }
 
 }  // namespace

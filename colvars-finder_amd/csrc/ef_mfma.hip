@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float hv = h[NH - 1].v[rt][ft][r];
-        d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
+        d.v[rt][ft][r] = wl[rt][r] * act_d1(mlp.act[0], hv);
       }
 #pragma unroll
   for (int l = NH - 1; l >= 1; --l) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float hv = h[l - 1].v[rt][ft][r];
-          d.v[rt][ft][r] = e.v[rt][ft][r] * (1.0f - hv * hv);
+          d.v[rt][ft][r] = e.v[rt][ft][r] * act_d1(mlp.act[0], hv);
         }
   }
   CVF_STAMP(6);
@@ -208,12 +208,12 @@ __global__ __launch_bounds__(64) void ef_fwd_pre_kernel(cvf_mlp_desc mlp, const 
   mul_l0chunk<H, FT, CH>(h[0], c1);
   mul_l0chunk<H, FT, CH>(h[0], c2);
   CVF_STAMP(3);
-  tanh_inplace<H, FT>(h[0]);
+  tanh_inplace<H, FT>(h[0], mlp.act[0]);
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
     set_const<H, FT>(h[l], bias[l]);
     hidden_mul<H, FT>(h[l], hf[l - 1], h[l - 1]);
-    tanh_inplace<H, FT>(h[l]);
+    tanh_inplace<H, FT>(h[l], mlp.act[0]);
   }
   {
     float yv[FT];
@@ -238,14 +238,14 @@ __global__ __launch_bounds__(64) void ef_fwd_pre_kernel(cvf_mlp_desc mlp, const 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float hv = h[NH - 1].v[rt][ft][r];
-        d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
+        d.v[rt][ft][r] = wl[rt][r] * act_d1(mlp.act[0], hv);
       }
 #pragma unroll
   for (int l = NH - 1; l >= 1; --l) {
     Vec<H, FT> e;
     init_bias<H, FT>(e, nullptr, q);
     hidden_mul<H, FT>(e, tf[l - 1], d);
-    tangent_of<H, FT>(d, h[l - 1], e);
+    tangent_of<H, FT>(d, h[l - 1], e, mlp.act[0]);
   }
   CVF_STAMP(5);
   float* gout = g_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + fo;
@@ -440,12 +440,12 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
   mul_l0chunk<H, FT, CH>(h[0], c1);
   mul_l0chunk<H, FT, CH>(h[0], c2);
   CVF_STAMP(56);
-  tanh_inplace<H, FT>(h[0]);
+  tanh_inplace<H, FT>(h[0], mlp.act[0]);
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
     set_const<H, FT>(h[l], bias[l]);
     hidden_mul<H, FT>(h[l], hf[l - 1], h[l - 1]);
-    tanh_inplace<H, FT>(h[l]);
+    tanh_inplace<H, FT>(h[l], mlp.act[0]);
   }
   {
     float yv4[FT];
@@ -482,14 +482,14 @@ __global__ __launch_bounds__(512) void ef_fwd_metric_kernel(cvf_mlp_desc mlp, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float hv = h[NH - 1].v[rt][ft][r];
-          d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
+          d.v[rt][ft][r] = wl[rt][r] * act_d1(mlp.act[0], hv);
         }
 #pragma unroll
     for (int l = NH - 1; l >= 1; --l) {
       Vec<H, FT> e;
       init_bias<H, FT>(e, nullptr, q);
       hidden_mul<H, FT>(e, tf[l - 1], d);
-      tangent_of<H, FT>(d, h[l - 1], e);
+      tangent_of<H, FT>(d, h[l - 1], e, mlp.act[0]);
     }
     const float* pT0 = pk + L.t0();
     float t0[CTMAX][NG];   // requested before the barrier: five dependent round trips otherwise
@@ -621,12 +621,12 @@ __global__ __launch_bounds__(512) void ef_align_fwd_kernel(cvf_mlp_desc mlp, con
   mul_l0chunk<H, FT, CH>(h[0], c0);
   mul_l0chunk<H, FT, CH>(h[0], c1);
   mul_l0chunk<H, FT, CH>(h[0], c2);
-  tanh_inplace<H, FT>(h[0]);
+  tanh_inplace<H, FT>(h[0], mlp.act[0]);
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
     set_const<H, FT>(h[l], bias[l]);
     hidden_mul<H, FT>(h[l], hf[l - 1], h[l - 1]);
-    tanh_inplace<H, FT>(h[l]);
+    tanh_inplace<H, FT>(h[l], mlp.act[0]);
   }
   {
     float yv4[FT];
@@ -717,12 +717,12 @@ __global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const 
     }
   }
   (void)smallD;
-  tanh_inplace<H, FT>(h[0]);
+  tanh_inplace<H, FT>(h[0], mlp.act[0]);
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
     set_const<H, FT>(h[l], bias[l]);
     hidden_apply<H, FT>(h[l], wL + L.fh(l), h[l - 1], lane);
-    tanh_inplace<H, FT>(h[l]);
+    tanh_inplace<H, FT>(h[l], mlp.act[0]);
   }
   {
     float yv[FT];
@@ -751,14 +751,14 @@ __global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float hv = h[NH - 1].v[rt][ft][r];
-        d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
+        d.v[rt][ft][r] = wl[rt][r] * act_d1(mlp.act[0], hv);
       }
 #pragma unroll
   for (int l = NH - 1; l >= 1; --l) {
     Vec<H, FT> e;
     init_bias<H, FT>(e, nullptr, q);
     hidden_apply<H, FT>(e, wL + L.th(l), d, lane);
-    tangent_of<H, FT>(d, h[l - 1], e);
+    tangent_of<H, FT>(d, h[l - 1], e, mlp.act[0]);
   }
   const float* pT0 = wL + L.t0();
   float* gout = g_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + fo;
@@ -971,14 +971,14 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float hv = h[NH - 1].v[rt][ft][r];
-              d.v[rt][ft][r] = wl[rt][r] * (1.0f - hv * hv);
+              d.v[rt][ft][r] = wl[rt][r] * act_d1(mlp.act[0], hv);
             }
 #pragma unroll
         for (int l = NH - 1; l >= 1; --l) {
           init_bias<H, FT>(e[l - 1], nullptr, q);
           if (SAVED == 1) hidden_mul<H, FT>(e[l - 1], tfr[l - 1], d);
           else hidden_apply<H, FT>(e[l - 1], pk + L.th(l), d, lane);
-          tangent_of<H, FT>(d, h[l - 1], e[l - 1]);   // d_{l-1} = (1 - h^2) .* e_{l-1}
+          tangent_of<H, FT>(d, h[l - 1], e[l - 1], mlp.act[0]);   // d_{l-1} = (1 - h^2) .* e_{l-1}
         }
       }
       init_bias<H, FT>(t[0], nullptr, q);
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
 #pragma unroll
       for (int l = 1; l < NH; ++l) {
         Vec<H, FT> td;
-        tangent_of<H, FT>(td, h[l - 1], t[l - 1]);
+        tangent_of<H, FT>(td, h[l - 1], t[l - 1], mlp.act[0]);
         init_bias<H, FT>(t[l], nullptr, q);
         if (SAVED == 1) hidden_mul<H, FT>(t[l], ffr[l - 1], td);
         else hidden_apply<H, FT>(t[l], pk + L.fh(l), td, lane);
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
       store_image<H, FT, false>(SB1, h[NH - 1], one, lane, fo);
       if (tangent) {
         Vec<H, FT> td;
-        tangent_of<H, FT>(td, h[NH - 1], t[NH - 1]);
+        tangent_of<H, FT>(td, h[NH - 1], t[NH - 1], mlp.act[0]);
         store_image<H, FT, false>(SB2, td, one, lane, fo);
       }
       __syncthreads();
@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
       for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
         for (int r = 0; r < 4; ++r) hbar.v[rt][ft][r] = alpha[ft] * wl[rt][r];
+    const int act0 = mlp.act[0];
 #pragma unroll
     for (int l = NH - 1; l >= 0; --l) {
       CVF_STAMP(13 + (NH - 1 - l));
@@ -1051,14 +1052,25 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float hv = h[l].v[rt][ft][r];
-            const float om = 1.0f - hv * hv;
-            float hb = hbar.v[rt][ft][r];
-            if (tangent) {
-              const float ev = (l == NH - 1) ? wl[rt][r] : e[l < NH - 1 ? l : 0].v[rt][ft][r];
-              hb = fmaf(-2.0f * hv * t[l].v[rt][ft][r], ev, hb);
-              dl.v[rt][ft][r] = ev * om;
+            if (act0 == CVF_ACT_TANH) {
+              const float om = 1.0f - hv * hv;
+              float hb = hbar.v[rt][ft][r];
+              if (tangent) {
+                const float ev = (l == NH - 1) ? wl[rt][r] : e[l < NH - 1 ? l : 0].v[rt][ft][r];
+                hb = fmaf(-2.0f * hv * t[l].v[rt][ft][r], ev, hb);
+                dl.v[rt][ft][r] = ev * om;
+              }
+              zbar.v[rt][ft][r] = om * hb;
+            } else {   // zbar = f' hbar + f'' t e  (the derivatives through the stored output)
+              const float d1 = ef_act_d1_slow(act0, hv);
+              float zb = d1 * hbar.v[rt][ft][r];
+              if (tangent) {
+                const float ev = (l == NH - 1) ? wl[rt][r] : e[l < NH - 1 ? l : 0].v[rt][ft][r];
+                zb = fmaf(ef_act_d2_slow(act0, hv) * t[l].v[rt][ft][r], ev, zb);
+                dl.v[rt][ft][r] = ev * d1;
+              }
+              zbar.v[rt][ft][r] = zb;
             }
-            zbar.v[rt][ft][r] = om * hb;
           }
       store_image<H, FT, false>(SA1, zbar, one, lane, fo);
       if (tangent) {
@@ -1069,7 +1081,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
         store_image<H, FT, false>(SB1, h[l - 1], one, lane, fo);
         if (tangent) {
           Vec<H, FT> td;
-          tangent_of<H, FT>(td, h[l - 1], t[l - 1]);
+          tangent_of<H, FT>(td, h[l - 1], t[l - 1], mlp.act[0]);
           store_image<H, FT, false>(SB2, td, one, lane, fo);
         }
         __syncthreads();
@@ -1263,8 +1275,11 @@ bool ef_shape(const cvf_mlp_desc* m, int* H, int* NH) {
   *NH = m->n_layers - 1;
   for (int l = 1; l < m->n_layers; ++l)
     if (m->dims[l] != *H) return false;
+  // one activation for all hidden layers (any code of include/cvf.h with two derivatives through its output), none after the last
+  const int a0 = m->act[0];
+  if (a0 < CVF_ACT_TANH || a0 > CVF_ACT_SOFTPLUS) return false;
   for (int l = 0; l < m->n_layers; ++l)
-    if (m->act[l] != (l + 1 < m->n_layers ? 1 : 0)) return false;
+    if (m->act[l] != (l + 1 < m->n_layers ? a0 : 0)) return false;
   return true;
 }
 

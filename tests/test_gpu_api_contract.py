@@ -223,7 +223,7 @@ def test_unsupported_net_shape_is_rejected_at_construction(dev, tmp_path):
             core.EigenFunctionTask(Traj(traj, w, 1.0), _position_layer(10, ref, dev), model, str(tmp_path), 10.0, [1.0, 0.5], k=2,
                                    device=dev, verbose=False)
     with pytest.raises(NotImplementedError, match="Tanh"):
-        core.EigenFunctionTask(Traj(traj, w, 1.0), _position_layer(10, ref, dev), nn.EigenFunctions([30, 20, 1], 1, torch.nn.ReLU()),
+        core.EigenFunctionTask(Traj(traj, w, 1.0), _position_layer(10, ref, dev), nn.EigenFunctions([30, 20, 1], 1, torch.nn.GELU()),
                                str(tmp_path), 10.0, [1.0], k=1, device=dev, verbose=False)
 
 

@@ -1036,3 +1036,77 @@ def test_transfer_step_ragged_batches_vs_oracle(dev, B, k, dims_h):
     want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
     got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("layout", ["fast", "mixed", "identity"])
+@pytest.mark.parametrize("name,module,fn", ACTIVATIONS[:5], ids=[a[0] for a in ACTIVATIONS[:5]])
+def test_eigenfunction_activations_generator_step_vs_oracle(dev, name, module, fn, layout):
+    """EigenFunctionTask with the other activations (64-frame kernels: the activation's first TWO derivatives through its
+    output): loss, eigenvalues and every parameter gradient of a generator-mode step against the fp64 oracle - on the fast
+    layout (fused forward + derivative launch), a mixed feature list (general kernels) and the identity layer."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    k, B = 2, 150
+    if layout == "identity":
+        traj, w = make_2d_traj(B, seed=8)
+        layer, olayer, d_in, a = torch.nn.Identity(), torch.nn.Identity(), 2, torch.tensor([1.0, 0.5])
+    else:
+        n_atoms = 10 if layout == "mixed" else 9
+        traj, w, ref = make_molecule_traj(n_atoms, B, seed=2300, scale=2.0, sigma=0.3)
+        align = [0, 1, 2, 4, 5, 8] if layout == "mixed" else list(range(n_atoms))
+        spec = dict(align_idx=align, ref_pos=ref[align], features=MIXED if layout == "mixed" else [("position", tuple(range(n_atoms)))],
+                    use_angle_value=False)
+        layer, olayer = make_layer(spec, n_atoms, dev), oracle_layer(spec)
+        d_in, a = layer.d_r, torch.tensor(diag_coeff_for(n_atoms, 3), dtype=torch.float32)
+    dims = [d_in, 16, 16, 1]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(13))
+    model = nn.EigenFunctions(dims, k, module())
+    model.load_state_dict(sd0)
+    task = core.EigenFunctionTask(Traj(traj, w, 1.0), layer, model, "/tmp/cvf_test", 12.0, [1.0, 0.6], diag_coeff=a, beta=1.2, lag_tau=0,
+                                  k=k, device=dev, verbose=False, save_model_every_step=0)
+    assert not task._use_ef16()
+    loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+    X = torch.tensor(traj, dtype=torch.float64, requires_grad=True)
+    lo, eo, no, po, co = losses.ef_loss(sd, k, olayer, X, torch.tensor(w), alpha=12.0, eig_w=[1.0, 0.6], diag_coeff=a.double(), beta=1.2,
+                                        activation=fn)
+    lo.backward()
+    torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=RTOL64)
+    assert list(cvec) == list(co)
+    want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("name,module,fn", [ACTIVATIONS[0], ACTIVATIONS[2], ACTIVATIONS[4]], ids=["sigmoid", "elu", "softplus"])
+def test_eigenfunction_activations_transfer_training_vs_oracle(dev, name, module, fn):
+    """... and a short transfer-operator training run (loss of every step) against the oracle's trainer."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    n_atoms, B, lag, k = 9, 200, 2, 2
+    traj, w, ref = make_molecule_traj(n_atoms, B + lag, seed=2400, scale=2.0, sigma=0.3)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_atoms)))], use_angle_value=False)
+    dims = [27, 12, 12, 1]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(14))
+    model = nn.EigenFunctions(dims, k, module())
+    model.load_state_dict(sd0)
+    task = core.EigenFunctionTask(Traj(traj, w, 0.5), make_layer(spec, n_atoms, dev), model, "/tmp/cvf_test", 12.0, [1.0, 0.6], beta=1.0,
+                                  lag_tau=lag * 0.5, k=k, device=dev, verbose=False, save_model_every_step=0)
+    X, Xl, wt, wl = torch.tensor(traj[:B]), torch.tensor(traj[lag:lag + B]), torch.tensor(w[:B]), torch.tensor(w[lag:lag + B])
+    loss, eig, npl, pen, cvec = task.loss_func(X, wt, Xl, wl)
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+    lo, eo, no, po, co = losses.ef_loss(sd, k, oracle_layer(spec), X.double(), wt.double(), Xl.double(), wl.double(), alpha=12.0,
+                                        eig_w=[1.0, 0.6], lag_idx=lag, dt=0.5, activation=fn)
+    lo.backward()
+    torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=RTOL64)
+    want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
