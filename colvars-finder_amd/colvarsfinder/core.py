@@ -1243,13 +1243,14 @@ class _EncGradPenalty:
         assert dims[0] == task.tot_dim, \
             (f"eta[0] > 0: the gradient-norm penalty reshapes the encoder's input gradient to [-1, {task.tot_dim}] (core.py:907), "
              f"so the preprocessing layer must emit {task.tot_dim} features, not {dims[0]}")
-        if [a for _, a in enc] != [True] * (L - 1) + [False] or L < 2:
-            raise NotImplementedError("eta[0] on MI355X: the encoder must be Linear/Tanh layers ending in a Linear layer")
+        act0 = enc[0][1] if L >= 2 else 0
+        if L < 2 or act0 == 0 or [a for _, a in enc] != [act0] * (L - 1) + [0]:
+            raise NotImplementedError("eta[0] on MI355X: the encoder must be Linear + activation layers (one activation) ending in a Linear layer")
         d = _hip.MLPDesc()
         vd = dims[:-1] + [1]
         d.n_nets, d.n_layers = k, L
         for l in range(L):
-            d.dims[l], d.dims[l + 1], d.act[l] = vd[l], vd[l + 1], int(l < L - 1)
+            d.dims[l], d.dims[l + 1], d.act[l] = vd[l], vd[l + 1], (act0 if l < L - 1 else 0)
         # virtual net i = [shared layers 0..L-2 | row i of the last weight | entry i of the last bias]
         ed = fl.desc
         n_shared = ed.w_off[0][L - 1] - ed.w_off[0][0]
@@ -1352,11 +1353,12 @@ class _RegGenerator:
         self.enc = _chain_layers(m.encoder)
         self.regs = [_chain_layers(r) for r in m.reg]
         Le, Lr = len(self.enc), len(self.regs[0])
-        ok = [a for _, a in self.enc] == [True] * (Le - 1) + [False] and all(
-            len(r) == Lr and [a for _, a in r] == [True] * (Lr - 1) + [False] and r[-1][0].out_features == 1 for r in self.regs)
+        act0 = self.regs[0][0][1] if Lr >= 2 else 0
+        ok = act0 != 0 and [a for _, a in self.enc] == [act0] * (Le - 1) + [0] and all(
+            len(r) == Lr and [a for _, a in r] == [act0] * (Lr - 1) + [0] and r[-1][0].out_features == 1 for r in self.regs)
         if not ok or Lr < 2:
-            raise NotImplementedError("generator-mode regulariser on MI355X: encoder and regulariser nets must be Linear/Tanh chains "
-                                      "ending in a Linear layer, the regulariser nets with at least one hidden layer")
+            raise NotImplementedError("generator-mode regulariser on MI355X: encoder and regulariser nets must be Linear + activation "
+                                      "chains (one activation) ending in a Linear layer, the regulariser nets with at least one hidden layer")
         d_r = self.enc[0][0].in_features
         hidden = [lin.out_features for lin, _ in self.enc[:-1]] + [lin.out_features for lin, _ in self.regs[0][:-1]]
         for r in self.regs:
@@ -1368,8 +1370,13 @@ class _RegGenerator:
                 f"kernels take 1 to 5 hidden layers of at most {max(_hip.EF_HIDDEN_WIDTHS)} units and at most {_hip.MAX_NETS} nets "
                 "(use lag_tau_reg > 0 - the transfer operator - for other shapes)")
         self.H = H = widths[0]
+        from .nn import ACT_SIGMOID, ACT_SOFTPLUS
+        if act0 in (ACT_SIGMOID, ACT_SOFTPLUS) and any(h != H for h in hidden):   # (zero padding needs act(0) = 0)
+            raise NotImplementedError(f"generator-mode regulariser on MI355X with Sigmoid / Softplus: every hidden width of the chain "
+                                      f"{hidden} must be one kernel width (no zero padding)")
         self.pdims = [d_r] + [H] * len(hidden) + [1]
-        model = EigenFunctions(self.pdims, self.K)
+        act_module = next(mod for mod in m.reg[0]._modules.values() if not isinstance(mod, torch.nn.Linear))
+        model = EigenFunctions(self.pdims, self.K, copy.deepcopy(act_module))
         tok = np.zeros((4,) + tuple(np.asarray(task._traj_host).shape[1:]), dtype=np.float32)
 
         class _Tok:

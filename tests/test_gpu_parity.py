@@ -1110,3 +1110,47 @@ def test_eigenfunction_activations_transfer_training_vs_oracle(dev, name, module
     want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
     got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("name,module,fn", [ACTIVATIONS[2], ACTIVATIONS[0]], ids=["elu", "sigmoid"])
+def test_regautoencoder_generator_mode_and_grad_penalty_with_other_activations(dev, name, module, fn):
+    """RegAutoEncoderTask's two eigenfunction-kernel options - the generator-mode regulariser (lag_tau_reg = 0) and eta[0] - with
+    an activation other than Tanh: the first step's loss terms and every parameter gradient against the fp64 oracle."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    rs = np.random.RandomState(31)
+    n, d, K = 400, 6, 2
+    traj = np.cumsum(rs.normal(scale=0.15, size=(n, d)), axis=0).astype(np.float32)
+    traj -= traj.mean(0)
+    w = rs.uniform(0.5, 1.5, size=n)
+    e_dims, d_dims, r_dims = [d, 16, 2], [2, 16, d], [2, 16, 1]          # chain regulariser o encoder: hidden widths (16, 16), no padding
+    sd0 = nnref.init_regautoencoder(e_dims, d_dims, r_dims, K, torch.Generator().manual_seed(8), torch.float32)
+    model = nn.RegAutoEncoder(e_dims, d_dims, r_dims, K, module())
+    model.load_state_dict(sd0)
+    alpha, gamma, eta, eig_w, dt, beta = 0.9, [1.0, 3.0], [0.3, 0.0, 0.0], [1.0, 0.5], 0.5, 1.3
+    task = core.RegAutoEncoderTask(Traj(traj, w, dt), torch.nn.Identity(), model, "/tmp/cvf_test", eig_weights=eig_w, learning_rate=1e-3,
+                                   batch_size=150, num_epochs=1, alpha=alpha, gamma=gamma, eta=eta, lag_tau_ae=1 * dt, lag_tau_reg=0,
+                                   beta=beta, device=dev, verbose=False, save_model_every_step=0)
+    nb = 170
+    idx = torch.arange(nb, device=dev)
+    out = task._step(task._feature_traj, idx, task._weights[:nb].contiguous(), task._weights[:nb].contiguous(), 1, 0,
+                     with_grad=True).cpu().numpy()
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    F, W = torch.tensor(traj, dtype=torch.float64), torch.tensor(w)
+    sd = {k_: p.double().requires_grad_(True) for k_, p in sd0.items()}
+    ae = losses.regae_mse(sd, F[:nb], F[1:1 + nb], W[:nb], activation=fn)
+    eig, npl, pen, cvec = losses.regae_eigen_loss_generator(sd, K, torch.nn.Identity(), F[:nb].clone().requires_grad_(True), W[:nb],
+                                                            eig_w=eig_w, beta=beta, activation=fn)
+    eg = losses.regae_enc_grad(sd, F[:nb], W[:nb], activation=fn)
+    lo = alpha * ae + gamma[0] * npl + gamma[1] * pen + eta[0] * eg
+    lo.backward()
+    torch.set_default_dtype(torch.float32)
+    want = np.asarray([float(lo.detach()), float(ae.detach()), float(npl.detach()), float(pen.detach())] + [float(e) for e in eig] +
+                      [float(eg.detach()), 0.0, 0.0])
+    np.testing.assert_allclose(out, want, rtol=5 * RTOL64, atol=1e-7)
+    gmax = max(float(p.grad.abs().max()) for p in sd.values())
+    for k_, p in model.named_parameters():
+        if k_.startswith("reg.") and k_.endswith(f".{len(r_dims) - 1}.bias"):
+            continue
+        np.testing.assert_allclose(p.grad.cpu().numpy(), sd[k_].grad.numpy(), rtol=20 * RTOL64, atol=20 * RTOL64 * gmax, err_msg=k_)
