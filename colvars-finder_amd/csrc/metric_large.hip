@@ -152,9 +152,21 @@ __global__ __launch_bounds__(64 * kGroup) void metric_large_kernel(cvf_pp_desc p
   for (int net = 0; net < k; ++net) {
     const int64_t base = (tile * k + net) * (int64_t)d_r * CVF_TILE + l0;
     __syncthreads();  // previous net's qL flushed, gL free (first pass: slotC complete)
-    for (int idx = tid; idx < d_r * kGroup; idx += 64 * kGroup) {
-      const int o = idx / kGroup, f = idx % kGroup;
-      gL[idx] = g_tiled[base + (int64_t)o * CVF_TILE + f];
+    // (eight loads in flight per thread, then the LDS writes: one load at a time, each followed by its LDS write, was six
+    //  dependent round trips to memory per net - 26 k of the 48 k cycles a net took)
+    for (int i0 = tid; i0 < d_r * kGroup; i0 += 64 * kGroup * 8) {
+      float gv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + 64 * kGroup * u;
+        const int ic = idx < d_r * kGroup ? idx : d_r * kGroup - 1;
+        gv[u] = g_tiled[base + (int64_t)(ic / kGroup) * CVF_TILE + ic % kGroup];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + 64 * kGroup * u;
+        if (idx < d_r * kGroup) gL[idx] = gv[u];
+      }
     }
     for (int i = lane; i < ns * 3; i += 64) GsL[i] = 0.0f;
     __syncthreads();
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(64 * kGroup) void metric_large_kernel(cvf_pp_desc p
     float Ep = 0.0f;
     V3 usp = v3(0, 0, 0);
     float dHp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 2
+#pragma unroll 5
     for (int sl = lane; sl < ns; sl += 64) {
       const float4 c0 = *reinterpret_cast<const float4*>(slotC + 8 * sl);
       const float4 c1 = *reinterpret_cast<const float4*>(slotC + 8 * sl + 4);
