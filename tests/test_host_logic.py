@@ -106,8 +106,13 @@ def test_mlp_layout_offsets_follow_parameters_order():
     ae = nn.AutoEncoder([6, 4, 2], [2, 3, 6])
     chain = nn.mlp_layout(ae)["nets"][0]
     assert [(c[2], c[3], c[4]) for c in chain] == [(6, 4, 1), (4, 2, 0), (2, 3, 1), (3, 6, 0)]
+    # activation codes of include/cvf.h; modules outside the kernels' set are rejected with a clear error
+    assert [c[4] for c in nn.mlp_layout(nn.EigenFunctions([6, 4, 1], 1, activation=torch.nn.ReLU()))["nets"][0]] == [nn.ACT_RELU, 0]
+    assert [c[4] for c in nn.mlp_layout(nn.AutoEncoder([6, 4, 2], [2, 6], torch.nn.Softplus()))["nets"][0]] == [nn.ACT_SOFTPLUS, 0, 0]
+    with pytest.raises(NotImplementedError, match="Tanh, Sigmoid"):
+        nn.mlp_layout(nn.EigenFunctions([6, 4, 1], 1, activation=torch.nn.GELU()))
     with pytest.raises(NotImplementedError):
-        nn.mlp_layout(nn.EigenFunctions([6, 4, 1], 1, activation=torch.nn.ReLU()))
+        nn.mlp_layout(nn.AutoEncoder([6, 4, 2], [2, 6], torch.nn.ELU(alpha=0.5)))
 
 
 def test_regautoencoder_side_by_side_chain_layout():
