@@ -28,13 +28,14 @@ def _ix(atom_group):
     return np.asarray(atom_group.ix if hasattr(atom_group, "ix") else atom_group, dtype=np.int64)
 
 
-def _batch_records(recs, width=64):
+def _batch_records(recs, width=64, disjoint=False):
     """Greedy packing of slot records ``[type, s0, s1, s2, s3, out]`` into batches of ``width`` such that, inside a
-    batch, no (atom position, slot) pair occurs twice; short batches are padded with ``type = -1`` entries."""
+    batch, no (atom position, slot) pair occurs twice - ``disjoint``: no slot occurs twice at all (CVF_PP_SLOT_DISJOINT);
+    short batches are padded with ``type = -1`` entries."""
     natoms = {_hip.FEAT_POSITION: 1, _hip.FEAT_BOND: 2, _hip.FEAT_ANGLE: 3, _hip.FEAT_DIHEDRAL: 4}
     batches = []   # [records, set of (position, slot)]
     for r in recs:
-        keys = {(j, r[1 + j]) for j in range(natoms[r[0]])}
+        keys = {((0 if disjoint else j), r[1 + j]) for j in range(natoms[r[0]])}
         for b in batches:
             if len(b[0]) < width and b[2] == r[0] and not (keys & b[1]):
                 b[0].append(r)
@@ -140,10 +141,15 @@ class AlignFeatureLayer(torch.nn.Module):
         # wave's lanes on one code path, and a batch in which no two records name the same slot in the same atom
         # position lets the derivative kernel scatter without atomics (CVF_PP_SLOT_BATCHED; the output offset travels
         # with the record, so the order is free; type -1 entries are padding)
-        rec_slot = _batch_records(sorted(rec_slot, key=lambda r: r[0]))
-        self._n_rec_slot = len(rec_slot)
+        by_type = sorted(rec_slot, key=lambda r: r[0])
+        rec_slot = _batch_records(by_type)
+        strict = _batch_records(by_type, disjoint=True)   # batches whose records share no atom at all, when that costs no extra batch
         if w_hat is None:
             self._flags |= _hip.PP_SLOT_BATCHED
+            if len(strict) <= len(rec_slot):
+                rec_slot = strict
+                self._flags |= _hip.PP_SLOT_DISJOINT
+        self._n_rec_slot = len(rec_slot)
         self._n_slot = len(used)
         self.register_buffer("atom_align", torch.tensor(atom_align))
         self.register_buffer("atom_slot", torch.tensor(atom_slot))

@@ -114,6 +114,35 @@ __global__ __launch_bounds__(64 * kGroup) void metric_large_kernel(cvf_pp_desc p
       atomicAdd(g3 + 2, v.z);
     }
   };
+  // CVF_PP_SLOT_DISJOINT: no slot occurs twice in a batch, so all accumulators of ONE record are read first and written
+  // afterwards - one LDS round trip per record instead of one per component (without the flag a lane's slot may be another
+  // lane's slot in a different atom position, and only the component-by-component order is exact)
+  const bool disjoint = batched && (pp.flags & CVF_PP_SLOT_DISJOINT) != 0;
+  auto addG2 = [&](int sa, V3 va, int sb, V3 vb) {
+    if (!disjoint) { addG(sa, va); addG(sb, vb); return; }
+    float* ga = GsL + 3 * sa; float* gb = GsL + 3 * sb;
+    const float a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2];
+    ga[0] = a0 + va.x; ga[1] = a1 + va.y; ga[2] = a2 + va.z;
+    gb[0] = b0 + vb.x; gb[1] = b1 + vb.y; gb[2] = b2 + vb.z;
+  };
+  auto addG3 = [&](int sa, V3 va, int sb, V3 vb, int sc, V3 vc) {
+    if (!disjoint) { addG(sa, va); addG(sb, vb); addG(sc, vc); return; }
+    float* ga = GsL + 3 * sa; float* gb = GsL + 3 * sb; float* gc = GsL + 3 * sc;
+    const float a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2], c0 = gc[0], c1 = gc[1], c2 = gc[2];
+    ga[0] = a0 + va.x; ga[1] = a1 + va.y; ga[2] = a2 + va.z;
+    gb[0] = b0 + vb.x; gb[1] = b1 + vb.y; gb[2] = b2 + vb.z;
+    gc[0] = c0 + vc.x; gc[1] = c1 + vc.y; gc[2] = c2 + vc.z;
+  };
+  auto addG4 = [&](int sa, V3 va, int sb, V3 vb, int sc, V3 vc, int sd, V3 vd) {
+    if (!disjoint) { addG(sa, va); addG(sb, vb); addG(sc, vc); addG(sd, vd); return; }
+    float* ga = GsL + 3 * sa; float* gb = GsL + 3 * sb; float* gc = GsL + 3 * sc; float* gd = GsL + 3 * sd;
+    const float a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2];
+    const float c0 = gc[0], c1 = gc[1], c2 = gc[2], d0 = gd[0], d1 = gd[1], d2 = gd[2];
+    ga[0] = a0 + va.x; ga[1] = a1 + va.y; ga[2] = a2 + va.z;
+    gb[0] = b0 + vb.x; gb[1] = b1 + vb.y; gb[2] = b2 + vb.z;
+    gc[0] = c0 + vc.x; gc[1] = c1 + vc.y; gc[2] = c2 + vc.z;
+    gd[0] = d0 + vd.x; gd[1] = d1 + vd.y; gd[2] = d2 + vd.z;
+  };
   auto make_geo = [&](int r) {
     const int32_t* p = pp.rec_slot + 6 * r;
     Geo ge;
@@ -189,22 +218,16 @@ __global__ __launch_bounds__(64 * kGroup) void metric_large_kernel(cvf_pp_desc p
         M[6] += xc.z * g.x; M[7] += xc.z * g.y; M[8] += xc.z * g.z;
       } else if (ty == CVF_FEAT_BOND) {
         const V3 ga = gp[0] * ge.v0;
-        addG(geo_s0(ge), ga);
-        addG(geo_s1(ge), v3(-ga.x, -ga.y, -ga.z));
+        addG2(geo_s0(ge), ga, geo_s1(ge), v3(-ga.x, -ga.y, -ga.z));
       } else if (ty == CVF_FEAT_ANGLE) {
         float gs = gp[0];
         if (pp.use_angle_value) gs *= ge.sn;
         const V3 ga = gs * ge.v0, gc = gs * ge.v1;
-        addG(geo_s0(ge), ga);
-        addG(geo_s1(ge), v3(-ga.x - gc.x, -ga.y - gc.y, -ga.z - gc.z));
-        addG(geo_s2(ge), gc);
+        addG3(geo_s0(ge), ga, geo_s1(ge), v3(-ga.x - gc.x, -ga.y - gc.y, -ga.z - gc.z), geo_s2(ge), gc);
       } else {
         const float gs = pp.use_angle_value ? gp[0] : (gp[kGroup] * ge.cs - gp[0] * ge.sn);
         const V3 g1 = gs * ge.v0, g4 = gs * ge.v1;
-        addG(geo_s0(ge), g1);
-        addG(geo_s1(ge), (-1.0f - ge.p) * g1 + ge.q * g4);
-        addG(geo_s2(ge), ge.p * g1 + (-1.0f - ge.q) * g4);
-        addG(geo_s3(ge), g4);
+        addG4(geo_s0(ge), g1, geo_s1(ge), (-1.0f - ge.p) * g1 + ge.q * g4, geo_s2(ge), ge.p * g1 + (-1.0f - ge.q) * g4, geo_s3(ge), g4);
       }
     };
 #pragma unroll

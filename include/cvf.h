@@ -52,6 +52,8 @@ enum {
 enum {
   CVF_PP_ALIGN_CONTIG = 1,   /* align_idx[b] == b for all b (the align atoms are the first n_align frame atoms) */
   CVF_PP_PURE_POSITION = 2,  /* record r is {POSITION, atom r, out 3r}: n_rec atoms emit their aligned positions in order */
+  CVF_PP_SLOT_DISJOINT = 8,  /* (with CVF_PP_SLOT_BATCHED) within a batch no slot occurs twice at all: a record's accumulators can be
+                              * read together and written together - one LDS round trip per record instead of one per component */
   CVF_PP_SLOT_BATCHED = 4    /* rec_slot holds n_rec_slot entries in batches of 64 (one per lane of a wave): within a batch no two
                               * records name the same slot in the same atom position, entries of type -1 are padding.  Lets the
                               * derivative kernel scatter with plain read-modify-write instead of LDS float atomics. */

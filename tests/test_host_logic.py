@@ -280,6 +280,22 @@ def test_slot_record_batches_are_conflict_free():
         for j in range(4):
             slots = [r[1 + j] for r in batch if j < natoms[r[0]]]
             assert len(slots) == len(set(slots))
+    # disjoint batches (CVF_PP_SLOT_DISJOINT): no slot twice in a batch, whatever its position in the record
+    strict = pp._batch_records(sorted(recs, key=lambda r: r[0]), disjoint=True)
+    assert sorted(map(tuple, [r for r in strict if r[0] >= 0])) == sorted(map(tuple, recs)) and len(strict) >= len(batched)
+    for b in range(0, len(strict), 64):
+        batch = [r for r in strict[b:b + 64] if r[0] >= 0]
+        assert len({r[0] for r in batch}) <= 1
+        slots = [r[1 + j] for r in batch for j in range(natoms[r[0]])]
+        assert len(slots) == len(set(slots))
+    # the layer takes the disjoint batches only when they cost no extra batch
+    n_at = 400
+    feats = [("dihedral", tuple(int(a) for a in rs.choice(n_at, 4, replace=False))) for _ in range(40)] + [("bond", (1, 2)), ("bond", (2, 3))]
+    lay = pp.AlignFeatureLayer(n_at, list(range(n_at)), rs.normal(size=(n_at, 3)), feats)
+    assert lay._flags & _hip.PP_SLOT_BATCHED
+    chain = [("dihedral", (i, i + 1, i + 2, i + 3)) for i in range(0, 300)]       # a backbone: neighbours share atoms
+    lay2 = pp.AlignFeatureLayer(n_at, list(range(n_at)), rs.normal(size=(n_at, 3)), chain)
+    assert lay2._flags & _hip.PP_SLOT_BATCHED and lay2._n_rec_slot % 64 == 0
 
 
 @pytest.mark.parametrize("angle_value,weighted", [(False, False), (True, False), (False, True)])
