@@ -47,6 +47,7 @@ def test_struct_layouts_match_the_header(built_lib):
     assert ctypes.sizeof(built_lib.PPDesc) == 8 * 4 + 7 * 8 + 2 * 4 + 8
     assert ctypes.sizeof(built_lib.MLPDesc) == 4 * (2 + 13 + 12 + 2 * 8 * 12 + 1)
     assert ctypes.sizeof(built_lib.EFCfg) == 4 * 4 + 8 * 3 + 8 * 8
+    assert ctypes.sizeof(built_lib.AdamArgs) == 3 * 8 + 4 * 8 + 4 * 8     # theta, m, v | lr, beta1, beta2, eps | step_count, mlp, packed, lr_dev
 
 
 def test_no_cpu_fallback():
