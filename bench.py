@@ -404,6 +404,10 @@ def main():
                          "(separate rocprofv3 --pmc passes of this command; gfx950 FETCH_SIZE halving corrected)"),
         "final_loss": final_loss,
     }
+    if scaling == "strong":
+        out["strong_scaling_note"] = (f"this line is the {args.frames_total}-frame job at a global batch of {world * B} frames per step on {world} GPU(s); "
+                                      f"its one-GPU reference is scaling_table.rows['strong:{world * B}'] of the N = 1 line (the same job), not the "
+                                      "N = 1 headline, which is BASELINE config 3 (100 000 frames, 20 000 per step)")
     out.update(extras)
     if world == 1 and not args.no_extras:
         del X, Wt
