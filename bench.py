@@ -205,6 +205,35 @@ def run_steps(task, X, Wt, B, steps, warmup, tag, world, dev, max_batches=8, pre
     return elapsed, lv, step
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves as a CHILD process (never an exec: nothing in
+    this process has touched the GPU yet, and it must stay that way) - `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`, the command the task statement
+    names.  Rank 0's JSON line is the child's stdout and passes through; this process exits with the child's return code.
+    CVF_BENCH_BACKEND=gloo + CVF_BENCH_ONE_GPU=1 put every rank on cuda:0 over gloo (the rehearsal a one-GPU box allows)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n)))
+    print(f"[bench] --gpus {n} without RANK in the environment: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
+    rc = subprocess.run(cmd, env=env).returncode
+    sys.exit(rc)
+
+
+def bench_device():
+    """(backend, device) of this rank: RCCL on its own GPU; CVF_BENCH_ONE_GPU=1 maps every rank to cuda:0 (with
+    CVF_BENCH_BACKEND=gloo: the two-ranks-on-one-GPU rehearsal of tests/test_gpu_api_contract.py)."""
+    backend = os.environ.get("CVF_BENCH_BACKEND", "nccl")
+    local = 0 if os.environ.get("CVF_BENCH_ONE_GPU", "0") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    return backend, torch.device("cuda", local)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +255,8 @@ def main():
     ap.add_argument("--workload", choices=["c3", "c5", "c2", "regae", "transfer"], default="c3",
                     help="c3 = the benchmark line; c5 = config-5 shape, c2 = config-2 AutoEncoderTask (extra measurements)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args.gpus)
     if args.workload == "transfer":
         return main_transfer(args)
     if args.workload == "c5":
@@ -238,11 +269,13 @@ def main():
     from colvarsfinder import _dist, _hip, core, nn, pp
     from tests.synth import Traj, diag_coeff_for
 
-    _dist.init_from_env("nccl")
-    world, rank = _dist.world(), _dist.rank()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    backend, dev = bench_device()
     torch.cuda.set_device(dev)
+    if backend == "nccl" and dev.index != int(os.environ.get("LOCAL_RANK", "0")):
+        raise SystemExit("CVF_BENCH_ONE_GPU=1 needs CVF_BENCH_BACKEND=gloo (RCCL wants one GPU per rank)")
+    _dist.init_from_env(backend)
+    world, rank = _dist.world(), _dist.rank()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     scaling = args.scaling or ("strong" if world > 1 else "weak")
 
     ref = np.random.RandomState(SEED).normal(scale=2.0, size=(N_ATOMS, 3))

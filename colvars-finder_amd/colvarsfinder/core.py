@@ -196,7 +196,10 @@ class _FlatParams:
         for c in chains:
             if [c[0][0].in_features] + [lin.out_features for lin, _ in c] != dims or [a for _, a in c] != [act0] * (L - 1) + [0]:
                 return False
-        H = min(w for w in _hip.ef_widths(L - 1) if w >= max(hidden))
+        cand = [w for w in _hip.ef_widths(L - 1) if w >= max(hidden)]
+        if not cand:                          # e.g. ONE hidden layer of 21..32 units: no kernel width to pad to - the task then
+            return False                      # raises its NotImplementedError (plain layout, no fragment copy)
+        H = min(cand)
         if all(h == H for h in hidden):
             return False                      # already a kernel shape: plain layout
         pdims = [dims[0]] + [H] * (L - 1) + [1]
@@ -519,8 +522,9 @@ class EigenFunctionTask(TrainingTask):
             d = self._flat.desc
             raise NotImplementedError(
                 "EigenFunctionTask on MI355X: no kernel instance for nets with layer widths "
-                f"{[d.dims[i] for i in range(d.n_layers + 1)]}. Supported: 1 to 5 hidden layers of at most "
-                f"{max(_hip.EF_HIDDEN_WIDTHS)} units each (kernel widths {_hip.EF_HIDDEN_WIDTHS}, for 4 or 5 hidden layers 20 and 32; "
+                f"{[d.dims[i] for i in range(d.n_layers + 1)]}. Supported: 2 to 5 hidden layers of at most "
+                f"{max(_hip.EF_HIDDEN_WIDTHS)} units each, ONE hidden layer of at most {max(_hip.ef_widths(1))} units "
+                f"(kernel widths {_hip.EF_HIDDEN_WIDTHS}, for 4 or 5 hidden layers 20 and 32; "
                 f"other widths are zero-padded to the next one - not with Sigmoid / Softplus, whose padding would not stay zero), "
                 f"scalar output, ONE activation of include/cvf.h after every hidden layer, k <= {_hip.MAX_NETS} "
                 "(csrc/ef_mfma.hip: ef_shape / ef_dispatch).")

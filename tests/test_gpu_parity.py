@@ -702,6 +702,31 @@ def test_one_rank_rccl_collectives_inside_the_graphs(dev):
     assert res.returncode == 0 and rep.get("ok"), (rep, res.stderr[-1500:])
 
 
+def test_bench_gpus2_entry_point_on_one_gpu(dev):
+    """the driver's command shape `python bench.py --gpus 2 ...` (no launcher around it) must start its own
+    ranks and print ONE JSON line with n_gpus 2 and strong scaling.  Rehearsed on the one GPU of the test box: both ranks on
+    cuda:0 over gloo (CVF_BENCH_ONE_GPU / CVF_BENCH_BACKEND; RCCL wants one GPU per rank), small sizes."""
+    import json
+    import subprocess
+    import sys
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_gloo_available():
+        pytest.skip("gloo not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(CVF_BENCH_ONE_GPU="1", CVF_BENCH_BACKEND="gloo")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--frames-total", "40000", "--global-batch", "16000", "--no-extras", "--cpu-seconds", "0",
+                          "--preheat-ms", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 4 and out["value"] > 0
+    assert out["config"]["global_batch"] == 16000 and out["config"]["batch_per_gpu"] == 8000
+    assert np.isfinite(out["final_loss"])
+
+
 def test_large_batch_paths_by_duplication(dev):
     """Size-independent check of the large-launch paths (more than 1024 tiles: streaming alignment kernel, the batch sums'
     two-stage reduction, backward workgroups walking several tiles): a batch made of two copies of a 35 200-frame batch has

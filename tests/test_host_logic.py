@@ -342,3 +342,47 @@ def test_shard_batches_partitions_every_global_batch(n, bs, world):
     for pos, nb in plans:
         assert len(pos) == n_batches * nb and abs(nb - bs / world) < 1
     assert _dist.shard_batches(n, bs, 0, 1)[0].tolist() == list(range(n_batches * bs))
+
+
+@pytest.mark.parametrize("width", [21, 24, 30, 32])
+def test_one_wide_hidden_layer_has_no_padded_layout(width):
+    """ADVICE r2: EigenFunctions([d, 21..32, 1]) has no kernel width to pad to (one hidden layer: at most 20 units);
+    _FlatParams._init_padded must answer False - the task then raises NotImplementedError - instead of crashing in min()."""
+    from colvarsfinder import _hip, core, nn
+    assert max(_hip.ef_widths(1)) < width
+    flat = object.__new__(core._FlatParams)
+    assert core._FlatParams._init_padded(flat, nn.EigenFunctions([6, width, 1], 2), torch.device("cpu")) is False
+
+
+def test_bench_gpus_n_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher starts `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a CHILD process (no exec, nothing
+    in the parent touches the GPU) and exits with the child's return code."""
+    import bench
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # inside a launcher (RANK set) the same command line does NOT spawn again
+    monkeypatch.setenv("RANK", "0")
+    seen.clear()
+    with pytest.raises(BaseException):      # (no GPU here: it fails later, but not in launch_ranks)
+        bench.main()
+    assert "cmd" not in seen
