@@ -330,7 +330,8 @@ def main():
     last_calls, task._last_call = (task._last_call or {}), None
     kern_ms = {name: float(np.mean([s_.elapsed_time(e_) for s_, e_ in ev])) for name, ev in events.items()}
 
-    dom = max(kern_ms, key=kern_ms.get)
+    coll_ms = {n: v for n, v in kern_ms.items() if n.startswith("allreduce_")}    # the step's two cross-rank sums (N > 1)
+    dom = max((n for n in kern_ms if n not in coll_ms), key=kern_ms.get)
     # The dominant call once more, 40 launches back to back inside ONE event pair (the GPU parked while they are queued):
     # an event pair around a single launch also times the bracket itself (~3 us here), which is why the per-call averages
     # above sit that much over rocprofv3's kernel durations; this figure is the one `roofline` uses.
@@ -431,6 +432,9 @@ def main():
         "kernel_avg_us": {n: v * 1e3 for n, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
         "kernel_timing": ("HIP events around each C-ABI call over a second, eager pass of the same steps (the timed region "
                           "replays one hipGraph per step)") if graphs else "HIP events around each C-ABI call (eager pass)",
+        "collective_avg_us": ({n: v * 1e3 for n, v in coll_ms.items()} if coll_ms else None),
+        "collective_note": ("HIP events around each all-reduce in the eager per-call pass, rank 0 (includes the wait for the slowest rank: "
+                            "arrival skew shows here); None on one GPU - the single-process step has no collective"),
         "hip_graph": bool(graphs),
         "graph_granularity": "one hipGraph replay per chunk of the resident static batches (as train() replays one per epoch)",
         "traffic_note": (f"roofline.traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from profiles/{prof}_pmc_traffic.json "

@@ -384,6 +384,20 @@ class TrainingTask(ABC):
             rc = fn(*args)
         _hip.check(rc, name)
 
+    def _allreduce(self, name, t):
+        """One of the step's two cross-rank sums, bracketed by HIP events like a C-ABI call when the
+        per-call timing pass is on (bench.py reports them per collective: where a multi-GPU step's time goes)."""
+        ev = self._events
+        if ev is not None and _dist.collectives() and t.is_cuda:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _dist.allreduce_sum_(t)
+            b.record()
+            ev.setdefault(name, []).append((a, b))
+        else:
+            _dist.allreduce_sum_(t)
+        return t
+
     # -- description of r(x) for the kernels
     def _pp_desc(self, n_coord):
         pp = self.preprocessing_layer
@@ -487,6 +501,25 @@ class _EFWorkspace:
     k1_scratch = property(lambda self: self._k1_scratch[self.slot])
 
 
+class _HostFrames:
+    """The trajectory on the host as the tasks touch it: ``shape``, ``rows(idx)`` (the frames a process keeps resident) and
+    ``all()`` (single process: everything, once).  ``traj_obj.trajectory`` may be an array (the reference's
+    ``WeightedTrajectory``: held whole, core.py:343), an ``np.memmap`` (indexing it reads the pages of the rows asked for), or
+    any object with ``shape`` and ``take_rows(rows)`` - ``utils.RowReader`` - so that a rank of a data-parallel job never
+    holds more than its own 1/world of the frames on the host either."""
+
+    def __init__(self, src):
+        self.reader = src if hasattr(src, "take_rows") else None
+        self.array = None if self.reader is not None else np.asarray(src)
+        self.shape = tuple((self.reader if self.reader is not None else self.array).shape)
+
+    def rows(self, idx):
+        return self.reader.take_rows(idx) if self.reader is not None else self.array[idx]
+
+    def all(self):
+        return self.reader.take_rows(np.arange(self.shape[0])) if self.reader is not None else self.array
+
+
 class EigenFunctionTask(TrainingTask):
     """Eigenfunctions of the generator (``lag_tau == 0``) or of the transfer operator (``lag_tau > 0``).
 
@@ -532,13 +565,13 @@ class EigenFunctionTask(TrainingTask):
         # The frames stay resident in HBM (core.py:343-344 keeps CPU copies and moves every batch, core.py:500).  One process:
         # the whole trajectory.  Data-parallel job (one process per GPU): NOT here - train() uploads only the rows of this
         # rank's slices of the static batches, 1/world of the trajectory per GPU.
-        traj = np.asarray(traj_obj.trajectory)
-        self._traj_host, self._n_frames = traj, int(traj.shape[0])
+        self._traj_host = _HostFrames(traj_obj.trajectory)
+        self._n_frames = int(self._traj_host.shape[0])
         self._sharded = _dist.world() > 1
-        self._traj = None if self._sharded else _hip.upload_f32(traj, self.device)
+        self._traj = None if self._sharded else _hip.upload_f32(self._traj_host.all(), self.device)
         self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
         self.resident_bytes = 0 if self._sharded else self._traj.numel() * 4    # frames held in HBM (train() adds its gathers)
-        self.tot_dim = int(traj[0, ...].size)
+        self.tot_dim = int(np.prod(self._traj_host.shape[1:]))
         self._beta = beta
         if self.lag_idx == 0:
             if diag_coeff is not None:
@@ -642,7 +675,7 @@ class EigenFunctionTask(TrainingTask):
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), None, P(w_lag), P(y_lag),
                        P(ws.scratch), P(ws.stats), lv, cf, s)
             if not single:
-                _dist.allreduce_sum_(ws.stats)                                           # collective #1
+                self._allreduce("allreduce_batch_sums", ws.stats)                                           # collective #1
                 self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
             return ws
         if self._use_ef16() and not aligned:
@@ -655,7 +688,7 @@ class EigenFunctionTask(TrainingTask):
             if rows:
                 self._call("cvf_ef16_finish", lib.cvf_ef16_finish, self._cfg, B, P(ws.scratch), P(ws.stats), lv, cf, s)
             if not single:
-                _dist.allreduce_sum_(ws.stats)                                           # collective #1
+                self._allreduce("allreduce_batch_sums", ws.stats)                                           # collective #1
                 self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
             return ws
         if not ws.k1_scratch_checked:
@@ -682,7 +715,7 @@ class EigenFunctionTask(TrainingTask):
                 self._call("cvf_ef_stats_finish_rows", lib.cvf_ef_stats_finish_rows, self._cfg, rows, P(ws.scratch), P(ws.stats),
                            lv, cf, s)
             if not single:
-                _dist.allreduce_sum_(ws.stats)                                           # collective #1
+                self._allreduce("allreduce_batch_sums", ws.stats)                                           # collective #1
                 self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
             return ws
         if with_tr:
@@ -700,7 +733,7 @@ class EigenFunctionTask(TrainingTask):
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), None, P(w_lag), P(y_lag),
                        P(ws.scratch), P(ws.stats), lv, cf, s)
         if not single:
-            _dist.allreduce_sum_(ws.stats)                                               # collective #1
+            self._allreduce("allreduce_batch_sums", ws.stats)                                               # collective #1
             self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
         return ws
 
@@ -724,7 +757,7 @@ class EigenFunctionTask(TrainingTask):
         adam = self.optimizer.fused_args() if fuse_adam else None
         self._call("cvf_slab_reduce", lib.cvf_slab_reduce, P(ws.slab), ws.slab_rows, fl.n, P(fl.grad), adam, _hip.stream())
         if not fuse_adam:
-            _dist.allreduce_sum_(fl.grad)                                                # collective #2
+            self._allreduce("allreduce_gradient", fl.grad)                                                # collective #2
         return adam is not None
 
     def train_step(self, X, w, X_lag=None, w_lag=None, slot=0, aligned=False, prefetch=None, out=None):
@@ -867,8 +900,8 @@ class EigenFunctionTask(TrainingTask):
                 pos, nb = _dist.shard_batches(len(idx), bs, rank, world)
                 rows = np.asarray(idx)[pos]
                 it = torch.as_tensor(rows, device=self.device, dtype=torch.long)
-                X, w = _hip.upload_f32(self._traj_host[rows], self.device), self._weights[it].contiguous()
-                Xl, wl = ((_hip.upload_f32(self._traj_host[rows + lag], self.device), self._weights[it + lag].contiguous())
+                X, w = _hip.upload_f32(self._traj_host.rows(rows), self.device), self._weights[it].contiguous()
+                Xl, wl = ((_hip.upload_f32(self._traj_host.rows(rows + lag), self.device), self._weights[it + lag].contiguous())
                           if lag > 0 else (None, None))
                 bl = [(j * nb, (j + 1) * nb) for j in range(len(pos) // nb)] if nb > 0 else []
             self.resident_bytes += sum(t.numel() * t.element_size() for t in (X, w, Xl, wl) if t is not None)
@@ -969,14 +1002,14 @@ class AutoEncoderTask(TrainingTask):
                          plot_frequency, verbose, debug_mode)
         assert isinstance(model, AutoEncoder), 'model must be an object of the class AutoEncoder'
         self.init_model_and_optimizer()
-        traj = np.asarray(traj_obj.trajectory)
-        self._traj_host, self._n_frames = traj, int(traj.shape[0])
+        self._traj_host = _HostFrames(traj_obj.trajectory)
+        self._n_frames = int(self._traj_host.shape[0])
         self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
-        self._pp = pp = self._pp_desc(int(traj[0, ...].size))
+        self._pp = pp = self._pp_desc(int(np.prod(self._traj_host.shape[1:])))
         # core.py:635: the feature trajectory r(x) of ALL frames, once.  In a data-parallel job (one process per GPU) each
         # rank computes the features of its own rows only, in train(), once the split is known.
         self._sharded = _dist.world() > 1
-        self._feature_traj = None if self._sharded else self._features(traj)
+        self._feature_traj = None if self._sharded else self._features(self._traj_host.all())
         self.resident_bytes = 0 if self._sharded else self._feature_traj.numel() * 4
         assert pp.d_r == self._flat.desc.dims[0] == self._flat.desc.dims[self._flat.desc.n_layers], \
             'autoencoder input/output width must equal the feature dimension'
@@ -1030,7 +1063,7 @@ class AutoEncoderTask(TrainingTask):
         out = self._out2[:2].clone()
         _dist.allreduce_sum_(out)
         if with_grad and adam is None:
-            _dist.allreduce_sum_(fl.grad)
+            self._allreduce("allreduce_gradient", fl.grad)
             if advance:
                 self.optimizer.step(advance=False)
         return out[0] / out[1]
@@ -1071,7 +1104,7 @@ class AutoEncoderTask(TrainingTask):
             assert bs == 0 or bs >= world, f"batch size {bs} is smaller than the number of ranks {world}"
             pos, nb = _dist.shard_batches(len(idx), bs, rank, world)
             rows = np.asarray(idx)[pos]
-            feat = self._features(self._traj_host[rows])
+            feat = self._features(self._traj_host.rows(rows))
             self.resident_bytes += feat.numel() * 4
             wv = self._weights[torch.as_tensor(rows, device=self.device, dtype=torch.long)].contiguous()
             return feat, None, wv, ([(j * nb, (j + 1) * nb) for j in range(len(pos) // nb)] if nb > 0 else [])
@@ -1381,7 +1414,7 @@ class _RegGenerator:
         self.pdims = [d_r] + [H] * len(hidden) + [1]
         act_module = next(mod for mod in m.reg[0]._modules.values() if not isinstance(mod, torch.nn.Linear))
         model = EigenFunctions(self.pdims, self.K, copy.deepcopy(act_module))
-        tok = np.zeros((4,) + tuple(np.asarray(task._traj_host).shape[1:]), dtype=np.float32)
+        tok = np.zeros((4,) + tuple(task._traj_host.shape[1:]), dtype=np.float32)
 
         class _Tok:
             trajectory, weights, dt, n_frames = tok, np.ones(4), task.traj_dt, 4
@@ -1485,8 +1518,8 @@ class RegAutoEncoderTask(TrainingTask):
         assert _dist.world() == 1, "RegAutoEncoderTask runs in one process per model in this round"
         self.init_model_and_optimizer()
         # --- data: the feature trajectory r(x) of every frame, once (the layer has no parameters), resident in HBM
-        traj = np.asarray(traj_obj.trajectory)
-        self.tot_dim = int(traj[0, ...].size)
+        traj = _HostFrames(traj_obj.trajectory).all()
+        self.tot_dim = int(np.prod(traj.shape[1:]))
         self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
         self._pp = self._pp_desc(self.tot_dim)
         self._feature_traj = self._features(torch.as_tensor(traj))

@@ -8,6 +8,9 @@ Not on the accelerated path: these helpers only
 * ``integrate_sde_overdamped``  <- utils.py:257-352  Euler-Maruyama sampler, writes ``traj.txt`` / ``output.csv``
 * ``calc_weights``              <- utils.py:354-417  re-weighting factors exp(-(beta_sys-beta_sim)(V - mean V)), mean 1
 * ``integrate_md_langevin``     <- utils.py:172-255  OpenMM driver: not provided (wraps an external MD engine)
+* ``RowReader`` / ``MappedTrajectory``  (no counterpart in the reference, which holds the whole array in memory, utils.py:106):
+                                                     a trajectory served from a memory-mapped ``.npy`` file row by row, so that a
+                                                     rank of a data-parallel job reads only the frames of its own batch slices
 """
 
 import math
@@ -112,3 +115,49 @@ def calc_weights(csv_filename, sampling_beta, sys_beta, traj_weight_filename='we
     print('\nSummary of weights:\n', weights.describe())
     weights.to_csv(traj_weight_filename, header=False, index=False)
     print(f'weights saved to: {traj_weight_filename}')
+
+
+class RowReader:
+    """Frames ``[n, ...]`` behind an array-like that is read ROW-WISE (an ``np.memmap`` of a ``.npy`` file, an HDF5 dataset, ..):
+    the training tasks call ``take_rows(rows)`` for exactly the frames they keep resident - in a data-parallel job a rank's
+    slices of the static batches, 1/world of the trajectory - instead of holding the whole array in
+    host memory on every rank (the reference's ``WeightedTrajectory`` does, utils.py:106; at BASELINE config 5 that is 120 GB
+    per rank).  ``rows_read`` / ``bytes_read`` count what was asked for (tools/check_dp2.py asserts the 1/world share)."""
+
+    def __init__(self, source):
+        self._src = source
+        self.shape = tuple(source.shape)
+        self.dtype = source.dtype
+        self.rows_read = 0
+        self.bytes_read = 0
+
+    def __len__(self):
+        return self.shape[0]
+
+    def take_rows(self, rows):
+        rows = np.asarray(rows, dtype=np.int64)
+        order = np.argsort(rows, kind="stable")          # ascending file offsets: one forward sweep over the pages
+        out = np.empty((len(rows),) + self.shape[1:], dtype=self.dtype)
+        step = max(1, (64 << 20) // max(1, int(np.prod(self.shape[1:])) * self.dtype.itemsize))
+        for s0 in range(0, len(rows), step):              # bounded temporaries whatever the shard size
+            sel = order[s0:s0 + step]
+            out[sel] = self._src[rows[sel]]
+        self.rows_read += len(rows)
+        self.bytes_read += out.nbytes
+        return out
+
+    def __getitem__(self, key):   # (row 0 for the shapes the constructors look at; anything else reads what it names)
+        return np.asarray(self._src[key])
+
+
+class MappedTrajectory:
+    """``traj_obj`` over a memory-mapped ``.npy`` trajectory: ``trajectory`` is a :class:`RowReader`, ``weights`` (mean one;
+    default all ones) and ``dt`` as in ``WeightedTrajectory``.  A single-process task reads every frame once (the upload);
+    a rank of a data-parallel job reads its own rows only."""
+
+    def __init__(self, traj_npy, weights=None, dt=1.0):
+        self.trajectory = RowReader(np.load(traj_npy, mmap_mode="r"))
+        self.n_frames = self.trajectory.shape[0]
+        self.weights = np.ones(self.n_frames) if weights is None else np.asarray(weights, dtype=np.float64)
+        assert len(self.weights) == self.n_frames, 'length of weights does not match the trajectory data'
+        self.dt = dt

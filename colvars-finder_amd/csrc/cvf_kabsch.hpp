@@ -35,7 +35,6 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // (the solver is __host__ __device__: tests/test_kabsch_host.py runs this very source in hipcc's host pass on the CPU against
 //  an fp64 SVD; only the reciprocal / reciprocal-square-root seeds differ between the passes)
 #define CVF_HD __host__ __device__ __forceinline__
-#define CVF_HD_NOINLINE static __host__ __device__ __noinline__
 CVF_HD float cvf_rsq(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_rsqf(x);
@@ -191,10 +190,6 @@ CVF_HD bool kabsch_guess(const double (&H)[3][3], T (&R0)[3][3]) {
   return lmid - lmin > T(3e-6) * lmax;
 }
 
-// the rare frames the fp32 stage cannot resolve: the same stage in fp64, four sweeps (off-diagonal / diagonal <= 3e-18 over
-// random, rank-deficient and degenerate H), out of line
-CVF_HD_NOINLINE void kabsch_guess_f64(const double (&H)[3][3], double (&R0)[3][3]) { (void)kabsch_guess<double, 4>(H, R0); }
-
 // P = R^T H, K = tr(sym P) I - sym P (symmetric, by cofactors) -> Kinv (6 entries, 0 when K is singular) and
 // omega = Kinv ax(P)
 CVF_HD void kabsch_newton_terms(const double (&R)[3][3], const double (&H)[3][3], double (&Kinv)[6], double (&om)[3]) {
@@ -240,7 +235,10 @@ CVF_HD void kabsch_from_H(const double (&H)[3][3], KabschOut& out) {
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) r0[i][j] = (double)g[i][j];
-    if (!resolved) kabsch_guess_f64(H, r0);   // (lane-divergent and rare: skipped by waves none of whose frames needs it)
+    // the rare frames the fp32 stage cannot resolve: the same stage in fp64, four sweeps (off-diagonal / diagonal <= 3e-18
+    // over random, rank-deficient and degenerate H).  Lane-divergent and skipped by waves none of whose frames needs it;
+    // inlined - a call would put the whole kernel under the function-call ABI (stack, registers saved around the call).
+    if (__builtin_expect(!resolved, 0)) (void)kabsch_guess<double, 4>(H, r0);
   }
   double R[3][3];
   {  // Newton-Schulz: R <- R0 (3 I - R0^T R0) / 2  (an fp32 R0 is orthogonal to ~1e-7; the Newton steps below assume a rotation)

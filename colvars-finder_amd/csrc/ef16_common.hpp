@@ -72,14 +72,14 @@ bool ef16_dispatch(int H, int NH, F&& f) {
   }
 #ifdef CVF_DEV_SHAPES   // developer builds (tools/*.hip probes, -S listings): the config-3 instance only - seconds instead of minutes
   EF_CASE(20, 3)
-  return false;
-#endif
+#else
   EF_CASE(8, 1) EF_CASE(8, 2) EF_CASE(8, 3)
   EF_CASE(12, 1) EF_CASE(12, 2) EF_CASE(12, 3)
   EF_CASE(16, 1) EF_CASE(16, 2) EF_CASE(16, 3)
   EF_CASE(20, 1) EF_CASE(20, 2) EF_CASE(20, 3)
   EF_CASE(24, 2) EF_CASE(24, 3)
   EF_CASE(32, 2) EF_CASE(32, 3)
+#endif
 #undef EF_CASE
   return false;
 }

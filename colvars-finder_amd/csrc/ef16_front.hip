@@ -234,6 +234,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
       for (int g = 0; g < NG; ++g) sv.st((l * NG + g) * 256, h[l].v[g >> 2][0][g & 3]);
     float* ft = feat_tiled + tile * (int64_t)D * CVF_TILE + kU * sub + f;
     const float* fi = featI + f * kImgP;
+#pragma unroll 1
     for (int j = p + 4 * wave; j < D; j += 4 * nw) ft[j * CVF_TILE] = fi[j];
     return;
   }
@@ -464,37 +465,55 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
   {
     float* ft = feat_tiled + tile * (int64_t)D * CVF_TILE + kU * sub + f;
     const float* fi = featI + f * kImgP;
+    // (a plain counted loop: left to itself the compiler unrolls and vectorises this run-time trip count into ~200 vector
+    //  instructions with three remainder paths and spills an address across them - each reload behind a wait for ALL stores)
+#pragma unroll 1
     for (int j = p + 4 * wave; j < D; j += 4 * nw) ft[j * CVF_TILE] = fi[j];
   }
   CVF_STAMP(29);
   if (partial == nullptr) return;   // (uniform) large batches: the caller reduces y / E with cvf_ef_stats
   lds_barrier();                    // y and E of every net are in LDS
 
-  // ---- wave 0: this unit's row of the batch sums [W | S1(k) | S2(i<=j) | E(k)], fp64: lane = (statistic, frame) in rows of
-  // 16 lanes, the 16 frames of a row added by the in-row DPP scan (fixed order); cvf_ef_stats_finish adds the units' rows
+  // ---- wave 0: this unit's row of the batch sums [W | S1(k) | S2(i<=j) | E(k)] in fp64 on the matrix cores: with the frames
+  // as the contraction index (four k-steps of four frames), D1 = [1, y_1..y_k] x [w, w y_1..w y_k] holds W (0,0), S1_j (0,j)
+  // and S2_ij (i,j), D2 = [E_1..E_k] x [w, ..] holds E_i in column 0 - eight v_mfma_f64_16x16x4_f64 instead of the 13
+  // statistic-by-statistic DPP scans (~570 vector instructions, 3-4 k cycles at the end of every block).  Products of two
+  // floats are exact in fp64 and the hardware adds the k-steps in a fixed order: bitwise reproducible, as before.
+  // cvf_ef_stats_finish adds the units' rows.
   if (wave == 0) {
-    const int row = lane >> 4, fr = lane & 15;
-    const double wb = (double)wL[fr];
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
     const int np = CVF_NPAIR(k);
-    for (int t0 = 0; t0 < ns; t0 += 4) {
-      const int t = t0 + row;
-      double term = 0.0;
-      if (t == 0) term = 1.0;
-      else if (t <= k) term = (double)yL[(t - 1) * kU + fr];
-      else if (t <= k + np) {
-        int pi = t - 1 - k, i = 0;
-        while (pi >= k - i) {
-          pi -= k - i;
-          ++i;
-        }
-        term = (double)yL[i * kU + fr] * (double)yL[(i + pi) * kU + fr];
-      } else if (t < ns) term = (double)eL[(t - 1 - k - np) * kU + fr];
-      double v = wb * term;
-      v += dpp_movd<0x111, 0xf>(v);   // row_shr:1
-      v += dpp_movd<0x112, 0xf>(v);   // row_shr:2
-      v += dpp_movd<0x114, 0xf>(v);   // row_shr:4
-      v += dpp_movd<0x118, 0xf>(v);   // row_shr:8 -> lane 15 of the row holds the sum of its 16 frames
-      if (fr == 15 && t < ns) partial[t * (int64_t)gridDim.x + unit] = v;   // [statistic][unit]: coalesced for the finishing launch
+    const int i = lane & 15, kq = lane >> 4;   // operand row / column, k-slot
+    f64x4 d1 = {0.0, 0.0, 0.0, 0.0}, d2 = {0.0, 0.0, 0.0, 0.0};
+    // (yL and eL are adjacent: rows 1..k of the A operand are y, the same index k rows further is E)
+    const float* yrow = yL + (i >= 1 && i <= k ? i - 1 : 0) * kU;
+    const float* erow = eL + (i < k ? i : 0) * kU;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const int fr = 4 * s_ + kq;
+      const double wb = (double)wL[fr];
+      const double yv = (double)yrow[fr];
+      const double a1 = i == 0 ? 1.0 : (i <= k ? yv : 0.0);
+      const double b = i == 0 ? wb : (i <= k ? wb * yv : 0.0);
+      const double a2 = i < k ? (double)erow[fr] : 0.0;
+      d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, d1, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, d2, 0, 0, 0);
+    }
+    // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 r
+    const int cj = lane & 15;
+    const int64_t G = gridDim.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ri = (lane >> 4) + 4 * r;
+      // D1: (0, 0) -> W; (0, j) -> S1_j; (i, j), 1 <= i <= j <= k -> S2 pair (i-1, j-1) in row-major i <= j order
+      int t = -1;
+      if (ri == 0 && cj <= k) t = cj;
+      else if (ri >= 1 && ri <= cj && cj <= k) {
+        const int a_ = ri - 1, b_ = cj - 1;
+        t = 1 + k + a_ * k - (a_ * (a_ - 1)) / 2 + (b_ - a_);
+      }
+      if (t >= 0) partial[t * G + unit] = d1[r];
+      if (cj == 0 && ri < k) partial[(1 + k + np + ri) * G + unit] = d2[r];
     }
   }
   CVF_STAMP(30);
@@ -574,10 +593,14 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
       else go(ef16_front_kernel<kH, kNH, NIT_, false>);                 \
       break;
     switch (nit) {
+#ifndef CVF_DEV_SHAPES
       EF16_GO(1) EF16_GO(2) EF16_GO(3) EF16_GO(4) EF16_GO(5)
+#endif
       default:
         if (allal) go(ef16_front_kernel<kH, kNH, 6, true>);
+#ifndef CVF_DEV_SHAPES
         else go(ef16_front_kernel<kH, kNH, 6, false>);
+#endif
     }
 #undef EF16_GO
   });

@@ -682,8 +682,13 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(dev):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     rep = json.loads(res.stdout.strip().splitlines()[-1])
     assert rep["ok"], rep
-    for kind in ("gen", "tr", "ae"):
+    for kind in ("gen", "tr", "ae", "gen_mm", "ae_mm"):
         assert rep[kind]["max_rel_loss_diff"] < 2e-4, rep
+    # with the trajectory behind a memory-mapped file (utils.MappedTrajectory) a rank also READS only its
+    # own half of the frames on the host; the single process reads the file once
+    for kind in ("gen_mm", "ae_mm"):
+        assert all(h <= 0.505 * rep[kind]["file_bytes"] for h in rep[kind]["host_bytes_read_per_rank"]), rep[kind]
+        assert rep[kind]["host_bytes_read_single_process"] == rep[kind]["file_bytes"]
 
 
 def test_one_rank_rccl_collectives_inside_the_graphs(dev):

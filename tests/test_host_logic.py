@@ -386,3 +386,26 @@ def test_bench_gpus_n_launches_its_own_ranks(monkeypatch):
     with pytest.raises(BaseException):      # (no GPU here: it fails later, but not in launch_ranks)
         bench.main()
     assert "cmd" not in seen
+
+
+def test_row_reader_serves_rows_from_a_memory_mapped_file(tmp_path):
+    """utils.RowReader / MappedTrajectory: rows of a memory-mapped .npy trajectory in the order asked for (read in ascending
+    file order), with the count of what was read - the host side of shard residency (a rank reads its own rows only)."""
+    from colvarsfinder.utils import MappedTrajectory, RowReader
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((1000, 7, 3)).astype(np.float32)
+    path = str(tmp_path / "traj.npy")
+    np.save(path, x)
+    t = MappedTrajectory(path, dt=0.25)
+    assert t.n_frames == 1000 and t.dt == 0.25 and t.weights.shape == (1000,) and t.trajectory.shape == (1000, 7, 3)
+    rows = rs.permutation(1000)[:300]
+    got = t.trajectory.take_rows(rows)
+    assert got.dtype == np.float32 and np.array_equal(got, x[rows])
+    assert t.trajectory.rows_read == 300 and t.trajectory.bytes_read == 300 * 7 * 3 * 4
+    assert np.array_equal(t.trajectory[0], x[0])
+    assert np.array_equal(RowReader(x).take_rows([5, 5, 1]), x[[5, 5, 1]])     # repeats, any order
+    assert RowReader(x).take_rows(np.zeros(0, dtype=np.int64)).shape == (0, 7, 3)
+    from colvarsfinder.core import _HostFrames
+    for src in (x, np.load(path, mmap_mode="r"), t.trajectory):
+        h = _HostFrames(src)
+        assert h.shape == (1000, 7, 3) and np.array_equal(h.rows(rows), x[rows]) and np.array_equal(h.all(), x)

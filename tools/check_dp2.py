@@ -27,18 +27,27 @@ def run(kind, out_path):
         _dist.init_from_env("gloo")
     n_atoms = 22
     traj, w, ref = make_molecule_traj(n_atoms, 5000, seed=123)
+    mapped = kind.endswith("_mm")     # the trajectory behind a memory-mapped .npy file: a rank reads its own rows only
+    kind = kind[:-3] if mapped else kind
+    if mapped:
+        from colvarsfinder.utils import MappedTrajectory
+        path = f"/tmp/dp2_traj_{os.getpid()}.npy"
+        np.save(path, traj.astype(np.float32))
+        traj_obj = MappedTrajectory(path, weights=w, dt=0.5)
+    else:
+        traj_obj = Traj(traj, w, 0.5)
     layer = pp.AlignFeatureLayer(n_atoms, list(range(n_atoms)), ref, [("position", tuple(range(n_atoms)))])
     torch.manual_seed(7)
     np.random.seed(11)
     if kind in ("gen", "tr"):
         model = nn.EigenFunctions([66, 20, 20, 20, 1], 3)
         a = torch.tensor(diag_coeff_for(n_atoms, 5), dtype=torch.float32)
-        task = core.EigenFunctionTask(Traj(traj, w, 0.5), layer, model, "/tmp/cvf_dp2", 20.0, [1.0, 0.7, 0.4], diag_coeff=a, beta=1.0,
+        task = core.EigenFunctionTask(traj_obj, layer, model, "/tmp/cvf_dp2", 20.0, [1.0, 0.7, 0.4], diag_coeff=a, beta=1.0,
                                       lag_tau=0 if kind == "gen" else 1.0, learning_rate=2e-3, k=3, batch_size=1000, num_epochs=2,
                                       device=dev, verbose=False, save_model_every_step=0)
     else:
         model = nn.AutoEncoder([66, 20, 20, 2], [2, 10, 66])
-        task = core.AutoEncoderTask(Traj(traj, w, 0.5), layer, model, "/tmp/cvf_dp2", learning_rate=2e-3, batch_size=1000, num_epochs=2,
+        task = core.AutoEncoderTask(traj_obj, layer, model, "/tmp/cvf_dp2", learning_rate=2e-3, batch_size=1000, num_epochs=2,
                                     device=dev, verbose=False, save_model_every_step=0)
     task.train()
     torch.cuda.synchronize()
@@ -51,7 +60,10 @@ def run(kind, out_path):
         np.savez(out_path, losses=losses, params=params)
     # frames this process keeps in HBM (the trajectory / feature rows and train()'s gathers), for the 1/world check
     with open(out_path.replace(".npz", f"_r{_dist.rank()}.json"), "w") as fh:
-        json.dump(dict(resident_bytes=int(task.resident_bytes), world=_dist.world(), frames=5000, n_atoms=n_atoms), fh)
+        json.dump(dict(resident_bytes=int(task.resident_bytes), world=_dist.world(), frames=5000, n_atoms=n_atoms,
+                       host_bytes_read=int(traj_obj.trajectory.bytes_read) if mapped else None), fh)
+    if mapped:
+        os.remove(path)
     if _dist.world() > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -63,7 +75,7 @@ def main():
         return run(sys.argv[2], sys.argv[3])
     report = {}
     ok = True
-    for kind in ("gen", "tr", "ae"):
+    for kind in ("gen", "tr", "ae", "gen_mm", "ae_mm"):
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
         env["CVF_GRAPH"] = "0"      # eager in both runs: the comparison is about the data-parallel arithmetic
         subprocess.run([sys.executable, __file__, "worker", kind, f"/tmp/dp2_{kind}_w1.npz"], check=True, env=env, timeout=300)
@@ -84,11 +96,19 @@ def main():
         # shard residency: a rank of the two-rank job holds about half of the frames the job touches - its slices
         # of the static batches (+ their lagged partners in transfer mode) - never the whole trajectory
         res = [json.load(open(f"/tmp/dp2_{kind}_w2_r{r}.json"))["resident_bytes"] for r in range(2)]
-        per_frame = {"gen": 22 * 12 + 4, "tr": 2 * (22 * 12 + 4), "ae": 66 * 4}[kind]
+        per_frame = {"gen": 22 * 12 + 4, "tr": 2 * (22 * 12 + 4), "ae": 66 * 4}[kind.replace("_mm", "")]
         whole = 5000 * per_frame
         report[kind] = dict(steps=int(a["losses"].shape[0]), max_rel_loss_diff=dl, max_abs_param_diff=dp,
                             resident_bytes_per_rank=res, whole_set_bytes=whole)
         ok = ok and dl < 2e-4 and dp < 2e-3 and all(0.35 * whole <= r <= 0.505 * whole for r in res)
+        if kind.endswith("_mm"):
+            # host side too: a rank of the two-rank job READS about half of the trajectory file (its slices of the batches),
+            # the single process all of it, once
+            host = [json.load(open(f"/tmp/dp2_{kind}_w2_r{r}.json"))["host_bytes_read"] for r in range(2)]
+            host1 = json.load(open(f"/tmp/dp2_{kind}_w1_r0.json"))["host_bytes_read"]
+            file_bytes = 5000 * 22 * 12
+            report[kind].update(host_bytes_read_per_rank=host, host_bytes_read_single_process=host1, file_bytes=file_bytes)
+            ok = ok and all(0.35 * file_bytes <= h <= 0.505 * file_bytes for h in host) and host1 == file_bytes
     print(json.dumps(dict(check="two ranks (gloo, one GPU) vs one process", ok=ok, **report)))
     if not ok:
         raise SystemExit(1)

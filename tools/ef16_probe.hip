@@ -3,10 +3,10 @@
 // -DCVF_STAMPS, s_memtime phase stamps per wave.
 // Build + run on the GPU box:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCVF_STAMPS -DCVF_STAMP_WPB=4 -Iinclude -Icolvars-finder_amd/csrc -Wno-pass-failed \
-//       tools/ef16_probe.hip colvars-finder_amd/csrc/stats.hip -o /tmp/ef16_probe && /tmp/ef16_probe
+//       tools/ef16_probe.hip -Lcolvars-finder_amd/colvarsfinder -lcvf_hip -Wl,-rpath,\$ORIGIN/../../colvars-finder_amd/colvarsfinder -o tools/build/ef16_probe
 #include "../colvars-finder_amd/csrc/ef16_front.hip"
 #include "../colvars-finder_amd/csrc/ef16_back.hip"
-#include "../colvars-finder_amd/csrc/ef_mfma.hip"
+// (everything else - cvf_ef_pack, the batch sums - comes from the library the probe is linked against)
 #include <cstdio>
 #include <random>
 #include <vector>

@@ -38,7 +38,7 @@ def rel_scale(a, b):
 
 
 def main():
-    tag_out = sys.argv[1] if len(sys.argv) > 1 else "r2"
+    tag_out = sys.argv[1] if len(sys.argv) > 1 else "r3"
     from tests.test_gpu_parity import build_task, make_layer
     from colvarsfinder import core, nn
     dev = torch.device("cuda:0")
@@ -59,6 +59,12 @@ def main():
             loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj[:B]), torch.tensor(w[:B]), Xl, wl)
             row[f"loss_vs_{tag}"] = rel(float(loss), float(g["loss"]))
             row[f"eig_vs_{tag}"] = rel(eig.numpy(), g["eig"])
+            row[f"npl_vs_{tag}"] = rel(float(npl), float(g["npl"]))
+            row[f"pen_vs_{tag}"] = abs(float(pen) - float(g["pen"])) / max(abs(float(g["pen"])), abs(float(g["loss"])) / float(g["alpha"]))
+            task.backward()
+            names = [n for n, _ in task.model.named_parameters()]
+            gmax = max(float(np.abs(g["grad/" + n]).max()) for n in names)
+            row[f"grad_vs_{tag}"] = max(float(np.abs(p_.grad.cpu().numpy() - g["grad/" + n]).max()) for n, p_ in task.model.named_parameters()) / gmax
         row["ref_f32_vs_f64_loss"] = rel(float(g32["loss"]), float(g64["loss"]))
         row["ref_f32_vs_f64_eig"] = rel(g32["eig"], g64["eig"])
         out["kat"][name] = row
@@ -73,6 +79,12 @@ def main():
             tr = np.stack([e[0].numpy() for e in task.loss_list])
             te = np.stack([e[1].numpy() for e in task.loss_list])
             row[f"step_loss_vs_{tag}"] = max(rel(tr[..., 0], np.array(g["train_loss"])[..., 0]), rel(te[..., 0], np.array(g["test_loss"])[..., 0]))
+            # every column of the rows [loss, npl, pen, eig_1..k], as the test compares them: |got - want| / (|want| + 1)
+            row[f"step_rows_vs_{tag}"] = max(float(np.max(np.abs(a_ - np.array(b_)) / (np.abs(np.array(b_)) + 1.0)))
+                                             for a_, b_ in ((tr, g["train_loss"]), (te, g["test_loss"])))
+            last_bias = f".{len(g['layer_dims']) - 1}.bias"
+            row[f"params_vs_{tag}"] = max(float(np.max(np.abs(p_.cpu().numpy() - g["final/" + n]) / (np.abs(g["final/" + n]) + 1.0)))
+                                          for n, p_ in task.model.state_dict().items() if not n.endswith(last_bias))
             cv = task.colvar_model()(torch.tensor(np.array(g["traj"])[:64], dtype=torch.float32)).detach().numpy()
             rc = np.array(g["colvar_probe"])
             row[f"cv_vs_{tag}"] = rel_scale(cv - cv.mean(0), rc - rc.mean(0))
@@ -99,6 +111,8 @@ def main():
             tr = np.stack([e[0].numpy() for e in task.loss_list])
             te = np.stack([e[1].numpy() for e in task.loss_list])
             row[f"step_loss_vs_{tag}"] = max(rel(tr, g["train_loss"]), rel(te, g["test_loss"]))
+            row[f"params_vs_{tag}"] = max(float(np.max(np.abs(p_.cpu().numpy() - g["final/" + n]) / (np.abs(g["final/" + n]) + 1.0)))
+                                          for n, p_ in task.model.state_dict().items())
             cv = task.colvar_model()(torch.tensor(traj[:64], dtype=torch.float32)).detach().numpy()
             row[f"cv_vs_{tag}"] = rel_scale(cv, g["colvar_probe"])
             row["steps"] = int(tr.size)
@@ -138,6 +152,9 @@ def main():
     def worst(key):
         return max(r[key] for sec in ("kat", "ef_train", "ae_train") for r in out[sec].values() if key in r)
 
+    out["_summary_more"] = {key: worst(key) for key in ("loss_vs_f32", "eig_vs_f64", "eig_vs_f32", "npl_vs_f64", "npl_vs_f32", "pen_vs_f64", "pen_vs_f32",
+                                                        "grad_vs_f64", "grad_vs_f32", "step_rows_vs_f64", "step_rows_vs_f32", "params_vs_f64",
+                                                        "params_vs_f32")}
     out["_summary"] = {"worst_loss_vs_f64_single_call": worst("loss_vs_f64"), "worst_step_loss_vs_f64_traces": worst("step_loss_vs_f64"),
                        "worst_step_loss_vs_f32_traces": worst("step_loss_vs_f32"), "worst_cv_vs_f64": worst("cv_vs_f64"),
                        "worst_cv_vs_f32": worst("cv_vs_f32"),
@@ -151,6 +168,7 @@ def main():
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out["_summary"]))
+    print(json.dumps(out["_summary_more"]))
 
 
 if __name__ == "__main__":
