@@ -1351,7 +1351,7 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
   CVF_REQUIRE(mlp && theta && packed && feat_tiled && y_tiled && n_tiles > 0, "cvf_ef_mlp_fwd: bad argument");
   int H, NH;
   CVF_REQUIRE(ef_shape(mlp, &H, &NH),
-              "cvf_ef_mlp_fwd: nets must be d0->H->..->H->1 with tanh between layers (got %d layers)", mlp->n_layers);
+              "cvf_ef_mlp_fwd: nets must be d0->H->..->H->1 with one activation of include/cvf.h after every hidden layer (got %d layers)", mlp->n_layers);
   CVF_REQUIRE(mlp->n_nets >= 1 && mlp->n_nets <= CVF_MAX_NETS, "cvf_ef_mlp_fwd: k=%d out of range", mlp->n_nets);
   // few tiles: split each 64-frame tile over two waves so that the launch still fills the 1024 SIMDs
   bool split = n_tiles * mlp->n_nets < 2048;

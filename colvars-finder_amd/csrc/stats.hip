@@ -93,17 +93,15 @@ __global__ __launch_bounds__(64) void ef_stats_partial_kernel(int64_t B, const f
   }
 }
 
-template <int KT>
-__global__ void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats, double* __restrict__ loss_vec,
-                               double* __restrict__ coef) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) ef_loss_tail<KT>(cfg, stats, loss_vec, coef);
+__global__ __launch_bounds__(64) void ef_loss_kernel(cvf_ef_cfg cfg, const double* __restrict__ stats, double* __restrict__ loss_vec,
+                                                     double* __restrict__ coef) {
+  if (blockIdx.x == 0) ef_loss_tail_wave(cfg, stats, loss_vec, coef);   // one wave, every lane active
 }
 
 // Second reduction stage (+ the scalar tail when loss_vec != NULL, i.e. no cross-rank reduction in between) in ONE
 // launch.  Stat i is summed by one wave: lane l adds rows l, l+64, ... (loads issued eight at a time), the 64 lane
 // sums are combined by the fixed-order DPP reduction -> bitwise reproducible for a given number of rows.
-template <int KT>
-__global__ __launch_bounds__(KT <= 5 ? 1024 : 512) void ef_stats_finish_kernel(cvf_ef_cfg cfg, int ns, int n_rows, int stat_major,
+__global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, int ns, int n_rows, int stat_major,
                                                                const double* __restrict__ partial,
                                                                double* __restrict__ stats, double* __restrict__ loss_vec,
                                                                double* __restrict__ coef) {
@@ -135,7 +133,7 @@ __global__ __launch_bounds__(KT <= 5 ? 1024 : 512) void ef_stats_finish_kernel(c
   }
   if (loss_vec == nullptr) return;
   __syncthreads();
-  if (threadIdx.x == 0) ef_loss_tail<KT>(cfg, fin, loss_vec, coef);
+  if (wave == 0) ef_loss_tail_wave(cfg, fin, loss_vec, coef);
 }
 
 __global__ void adam_kernel(AdamDev a, const float* __restrict__ grad, int64_t n, cvf_mlp_desc mlp) {
@@ -185,13 +183,9 @@ int cvf_ef_stats_finish(const cvf_ef_cfg* cfg, int n_rows, const double* partial
 int cvf_ef_stats_finish_impl(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
                              double* loss_vec, double* coef, hipStream_t s) {
   const int ns = cvf_ef_nstats(cfg->k, cfg->lag_idx);
-  const int wmax = cfg->k <= 5 ? 16 : 8;   // (k > 5: 512 threads at most - the register-resident loss tail wants up to 256 VGPRs at k = 8)
-  const int waves = ns < wmax ? ns : wmax;
-  k_dispatch(cfg->k, [&](auto kc) {
-    constexpr int K = decltype(kc)::value;
-    hipLaunchKernelGGL((ef_stats_finish_kernel<K>), dim3(1), dim3(64 * waves), 0, s, *cfg, ns, n_rows, stat_major, partial, stats,
-                       loss_vec, coef);
-  });
+  const int waves = ns < 16 ? ns : 16;
+  hipLaunchKernelGGL(ef_stats_finish_kernel, dim3(1), dim3(64 * waves), 0, s, *cfg, ns, n_rows, stat_major, partial, stats, loss_vec,
+                     coef);
   return cvf_check_launch("ef_stats_finish_kernel");
 }
 
@@ -225,10 +219,7 @@ extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, co
 extern "C" int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* loss_vec, double* coef, void* stream) {
   CVF_REQUIRE(cfg && stats && loss_vec && coef, "cvf_ef_loss: bad argument");
   CVF_REQUIRE(cfg->k >= 1 && cfg->k <= CVF_MAX_NETS, "cvf_ef_loss: k=%d out of range", cfg->k);
-  k_dispatch(cfg->k, [&](auto kc) {
-    constexpr int K = decltype(kc)::value;
-    hipLaunchKernelGGL((ef_loss_kernel<K>), dim3(1), dim3(64), 0, (hipStream_t)stream, *cfg, stats, loss_vec, coef);
-  });
+  hipLaunchKernelGGL(ef_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *cfg, stats, loss_vec, coef);
   return cvf_check_launch("ef_loss_kernel");
 }
 

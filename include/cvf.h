@@ -37,8 +37,9 @@ extern "C" {
 enum { CVF_FEAT_ANGLE = 0, CVF_FEAT_BOND = 1, CVF_FEAT_DIHEDRAL = 2, CVF_FEAT_POSITION = 3 };
 enum { CVF_PP_IDENTITY = 0, CVF_PP_ALIGN = 1 };
 /* cvf_mlp_desc.act[l]: what follows Linear layer l (nn.py:29-59 takes any torch activation module).  The chain kernels
- * (cvf_ae_*, cvf_regae_*, cvf_mlp_eval_rows) take all of these; the eigenfunction kernels (cvf_ef_*, cvf_ef16_*), which
- * need the activation's first TWO derivatives, take CVF_ACT_TANH between layers only. */
+ * (cvf_ae_*, cvf_regae_*, cvf_mlp_eval_rows) and the eigenfunction kernels on 64-frame tiles (cvf_ef_*: they use the
+ * activation's first TWO derivatives, expressed through its output) take all of these, one code for every hidden layer of a
+ * net; the 16-frames-per-wave kernels (cvf_ef16_*) take CVF_ACT_TANH only - cvf_ef16_supported() answers 0 otherwise. */
 enum {
   CVF_ACT_NONE = 0,
   CVF_ACT_TANH = 1,

@@ -1,12 +1,22 @@
 """GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the golden
 fixtures the reference produced.
 
-Tolerances.  Everything on this path is floating point.  north_star asks for per-step loss and
-learned-CV outputs within 1e-5 relative of the reference's CPU path; the reference's own fp32 run
-differs from its fp64 run by 6.6e-6..6.4e-5 relative, so
-  * against the fp64 fixtures / fp64 oracle (the exact answer) the bar is RTOL64 = 2e-5
-    (fp32 arithmetic of the kernels themselves),
-  * against the fp32 fixtures the bar is RTOL32 = 2e-4 (the reference's own fp32 noise on top).
+Tolerances.  Everything on this path is floating point.  north_star asks for per-step loss and learned-CV outputs within
+1e-5 relative of the reference's CPU path.  The bars below are about THREE TIMES the errors actually achieved, as recorded by
+tools/parity_errors.py in profiles/r3_parity_errors.json (a regression of an order of magnitude must turn
+the suite red, not sit inside a 50x margin):
+
+  quantity (worst over the fixtures)              achieved vs the fp64 run    bar      achieved vs the fp32 run      bar
+  loss / npl / pen of one loss_func call           4.5e-8 / 1.6e-7 / 2.7e-8    1e-6     3.0e-6 / 2.5e-5 / 8e-8        1e-5 / 1e-4
+  eigenvalues of one call                          3.1e-7                      1e-6     3.0e-5 (its own fp32 noise)   1e-4
+  parameter gradient / largest entry               3.2e-6                      1e-5     1.5e-4 (idem)                 5e-4
+  per-step LOSS of the training traces             1.5e-6                      1e-5     5.1e-6                        3e-5
+  the other columns (npl, pen, eig) of the traces  1.9e-6                      1e-5     4.1e-5 (idem)                 1.5e-4
+  final parameters, |d| / (|p| + 1)                1.4e-6                      1e-5     4.4e-5 (idem)                 1.5e-4
+  learned CVs / largest |CV|                       4.4e-6                      1.5e-5   1.7e-5 (= the reference's     5e-5
+                                                                                         own fp32 vs fp64 distance)
+The fp32 fixtures carry the reference's own fp32 rounding (its fp32 and fp64 runs differ by exactly these amounts), which no
+implementation can undercut; against the exact (fp64) answer every figure is inside the north star's 1e-5.
 """
 
 import os
@@ -20,7 +30,10 @@ from tests.synth import Traj, diag_coeff_for, make_2d_traj, make_molecule_traj, 
 
 pytestmark = pytest.mark.gpu
 
-RTOL64, RTOL32 = 2e-5, 2e-4
+RTOL64, RTOL32 = 2e-5, 2e-4          # oracle-vs-kernel tests on random nets / shapes without a recorded error table
+# fixture tests (table in the module docstring): {tag: (loss, npl_and_eig, grad_over_gmax)} and the trace bars
+KAT_TOL = {"f64": (1e-6, 1e-6, 1e-5), "f32": (1e-5, 1e-4, 5e-4)}
+TRACE_TOL = {"f64": dict(loss=1e-5, rows=1e-5, params=1e-5, cv=1.5e-5), "f32": dict(loss=3e-5, rows=1.5e-4, params=1.5e-4, cv=5e-5)}
 
 
 @pytest.fixture(scope="module")
@@ -164,9 +177,10 @@ def build_task(g, dev, tag_dtype=torch.float32):
     return task, model
 
 
-@pytest.mark.parametrize("tag,rtol", [("f64", RTOL64), ("f32", RTOL32)])
+@pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("name", goldens.KAT_CASES)
-def test_loss_func_kat(dev, name, tag, rtol):
+def test_loss_func_kat(dev, name, tag):
+    t_loss, t_eig, t_grad = KAT_TOL[tag]
     g = goldens.load(name, tag)
     task, model = build_task(g, dev)
     lag = int(g["lag_idx"])
@@ -176,10 +190,10 @@ def test_loss_func_kat(dev, name, tag, rtol):
     Xl = torch.tensor(traj[lag:lag + B]) if lag else None
     wl = torch.tensor(w[lag:lag + B]) if lag else None
     loss, eig, npl, pen, cvec = task.loss_func(X, wt, Xl, wl)
-    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=rtol)
-    np.testing.assert_allclose(float(npl), float(g["npl"]), rtol=rtol)
-    np.testing.assert_allclose(float(pen), float(g["pen"]), rtol=rtol, atol=rtol * abs(float(g["loss"])) / float(g["alpha"]))
-    np.testing.assert_allclose(eig.numpy(), g["eig"], rtol=rtol)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=t_loss)
+    np.testing.assert_allclose(float(npl), float(g["npl"]), rtol=t_eig)
+    np.testing.assert_allclose(float(pen), float(g["pen"]), rtol=t_loss, atol=t_loss * abs(float(g["loss"])) / float(g["alpha"]))
+    np.testing.assert_allclose(eig.numpy(), g["eig"], rtol=t_eig)
     assert list(cvec) == list(g["cvec"])
     task.backward()
     # absolute tolerance on the scale of the whole gradient: some entries are analytically zero (the loss
@@ -187,7 +201,7 @@ def test_loss_func_kat(dev, name, tag, rtol):
     # nothing but roundoff, in the reference (1e-13 in fp64, 1e-6..4e-4 in fp32) as well as here
     gmax = max(float(np.abs(g["grad/" + n]).max()) for n, _ in model.named_parameters())
     for n, p in model.named_parameters():
-        np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad/" + n], rtol=20 * rtol, atol=20 * rtol * gmax, err_msg=n)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad/" + n], rtol=0, atol=t_grad * gmax, err_msg=n)
 
 
 def test_stats_are_bitwise_reproducible(dev):
@@ -202,19 +216,28 @@ def test_stats_are_bitwise_reproducible(dev):
 
 
 # ------------------------------------------------------------------------------------------------ train traces
-@pytest.mark.parametrize("tag,rtol", [("f64", 5 * RTOL64), ("f32", RTOL32)])
+def assert_rows(got, want, tol):
+    """Loss rows [loss, npl, pen, eig..]: the loss column to `tol['loss']` relative, every column to `tol['rows']` in
+    |got - want| / (|want| + 1) (entries near zero: the penalty late in training)."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    np.testing.assert_allclose(got[..., 0], want[..., 0], rtol=tol["loss"])
+    assert float(np.max(np.abs(got - want) / (np.abs(want) + 1.0))) <= tol["rows"]
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("name", goldens.EF_TRAIN_CASES)
-def test_ef_train_trace(dev, name, tag, rtol):
+def test_ef_train_trace(dev, name, tag):
+    tol = TRACE_TOL[tag]
     g = goldens.load(name, tag)
     task, model = build_task(g, dev)
     np.random.seed(int(g["seed"]))
     task.train()
     tr = np.stack([e[0].numpy() for e in task.loss_list])
     te = np.stack([e[1].numpy() for e in task.loss_list])
-    np.testing.assert_allclose(tr, g["train_loss"], rtol=rtol, atol=rtol)
-    np.testing.assert_allclose(te, g["test_loss"], rtol=rtol, atol=rtol)
+    assert_rows(tr, g["train_loss"], tol)
+    assert_rows(te, g["test_loss"], tol)
     assert list(task._cvec) == list(g["cvec"])
-    np.testing.assert_allclose(task.train_loss_df.to_numpy(), g["train_loss_df"], rtol=rtol, atol=rtol)
+    assert_rows(task.train_loss_df.to_numpy(), g["train_loss_df"], tol)
     assert list(task.train_loss_df.columns) == [str(s) for s in g["loss_names"]]
     # The last bias of every eigenfunction is excluded: its exact gradient is 0 (shift invariance of the loss),
     # Adam turns the roundoff in it into +-lr steps, and the reference's own fp32 and fp64 runs end 0.016 apart
@@ -223,18 +246,22 @@ def test_ef_train_trace(dev, name, tag, rtol):
     for n, p in model.state_dict().items():
         if n.endswith(last_bias):
             continue
-        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=50 * rtol, atol=50 * rtol, err_msg=n)
+        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=tol["params"], atol=tol["params"], err_msg=n)
     probe = torch.tensor(np.array(g["traj"])[:64], device=dev, dtype=torch.float32)
     cv = task.colvar_model()(probe).detach().cpu().numpy()
     ref_cv = np.array(g["colvar_probe"])
-    np.testing.assert_allclose(cv - cv.mean(0), ref_cv - ref_cv.mean(0), rtol=50 * rtol, atol=50 * rtol)
+    ref_c = ref_cv - ref_cv.mean(0)
+    np.testing.assert_allclose(cv - cv.mean(0), ref_c, rtol=0, atol=tol["cv"] * np.abs(ref_c).max())
 
 
 # ------------------------------------------------------------------------------------------------ autoencoder
-@pytest.mark.parametrize("tag,rtol", [("f64", 5 * RTOL64), ("f32", RTOL32)])
+@pytest.mark.parametrize("tag", ["f64", "f32"])
 @pytest.mark.parametrize("name", goldens.AE_TRAIN_CASES)
-def test_ae_train_trace(dev, name, tag, rtol):
+def test_ae_train_trace(dev, name, tag):
+    # achieved (profiles/r3_parity_errors.json): every step's loss 1.2e-7 (fp64 run) / 3.6e-7 (fp32 run), final parameters
+    # 1e-7, learned CVs 3.6e-7 of the largest - bars at 2e-6; the single call's gradient stays at 1e-5 of its largest entry
     from colvarsfinder import core, nn
+    rtol = 2e-6
     g = goldens.load(name, tag)
     e_dims, d_dims = [int(d) for d in g["e_dims"]], [int(d) for d in g["d_dims"]]
     model = nn.AutoEncoder(e_dims, d_dims)
@@ -251,16 +278,16 @@ def test_ae_train_trace(dev, name, tag, rtol):
     np.testing.assert_allclose(float(l0), float(g["loss0"]), rtol=rtol)
     for n, p in model.named_parameters():
         ref = g["grad/" + n]
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=20 * rtol, atol=20 * rtol * max(1e-3, np.abs(ref).max()), err_msg=n)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * max(1e-3, np.abs(ref).max()), err_msg=n)
     np.random.seed(int(g["seed"]))
     task.train()
     np.testing.assert_allclose(np.stack([e[0].numpy() for e in task.loss_list]), g["train_loss"], rtol=rtol)
     np.testing.assert_allclose(np.stack([e[1].numpy() for e in task.loss_list]), g["test_loss"], rtol=rtol)
     for n, p in model.state_dict().items():
-        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=50 * rtol, atol=50 * rtol, err_msg=n)
+        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=rtol, atol=rtol, err_msg=n)
     probe = torch.tensor(traj[:64], device=dev, dtype=torch.float32)
     cv = task.colvar_model()(probe).detach().cpu().numpy()
-    np.testing.assert_allclose(cv, g["colvar_probe"], rtol=50 * rtol, atol=50 * rtol)
+    np.testing.assert_allclose(cv, g["colvar_probe"], rtol=0, atol=rtol * np.abs(g["colvar_probe"]).max())
 
 
 # ------------------------------------------------------------------------------------------------ Adam
@@ -705,6 +732,51 @@ def test_one_rank_rccl_collectives_inside_the_graphs(dev):
     res = subprocess.run([sys.executable, os.path.join(root, "tools", "check_comm1.py")], capture_output=True, text=True, timeout=900)
     rep = json.loads(res.stdout.strip().splitlines()[-1]) if res.stdout.strip() else {}
     assert res.returncode == 0 and rep.get("ok"), (rep, res.stderr[-1500:])
+
+
+def test_front_launch_batch_sums_over_many_launches(dev):
+    """The batch sums of the 16-frames-per-wave step (unit rows formed on the fp64 matrix cores in the front launch, added in a
+    fixed order by the finishing launch) over many launches that alternate between different batches of several sizes - a
+    stale or missing row would show as a gross error - against the same sums formed in fp64 from the launch's own y / E
+    outputs (agreement to fp64 summation order), and for bitwise reproducibility from launch to launch."""
+    from colvarsfinder import _hip, core, nn
+    n_atoms, k = 22, 3
+    ref = np.random.RandomState(3).normal(scale=2.0, size=(n_atoms, 3))
+    layer = make_layer(dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_atoms)))],
+                            use_angle_value=False), n_atoms, dev)
+    torch.manual_seed(5)
+    model = nn.EigenFunctions([66, 20, 20, 20, 1], k)
+    a = torch.tensor(diag_coeff_for(n_atoms, 2), dtype=torch.float32)
+    tok = np.zeros((64, n_atoms, 3), dtype=np.float32) + ref[None].astype(np.float32)
+    task = core.EigenFunctionTask(Traj(tok, np.ones(64), 1.0), layer, model, "/tmp/cvf_test", 20.0, [1.0, 0.7, 0.4], diag_coeff=a,
+                                  beta=1.0, lag_tau=0, learning_rate=1e-3, k=k, device=dev, verbose=False, save_model_every_step=0)
+    assert task._use_ef16()
+    for B in (20000, 33, 2049, 70001):                       # 1250 / 3 / 129 / 4376 units: whole and ragged groups of 32
+        sets = []
+        for seed in (1, 2):
+            rs = np.random.RandomState(100 * seed + B % 97)
+            traj = (np.einsum("bij,baj->bai", random_rotations(rs, B), ref[None] + rs.normal(scale=0.3, size=(B, n_atoms, 3)))
+                    + rs.normal(size=(B, 1, 3))).astype(np.float32)
+            w = rs.uniform(0.2, 2.0, size=B)
+            sets.append((torch.tensor(traj, device=dev), torch.tensor(w / w.mean(), device=dev, dtype=torch.float32)))
+        seen = [None, None]
+        for rep in range(12):
+            X, w = sets[rep % 2]
+            ws = task._forward(X, w)
+            stats, lv = ws.stats.clone(), ws.loss_vec.clone()
+            T = ws.T
+            y = ws.y.view(T, k, 64).permute(1, 0, 2).reshape(k, -1)[:, :B].double()
+            e = ws.e.view(T, k, 64).permute(1, 0, 2).reshape(k, -1)[:, :B].double()
+            wd = w.double()
+            want = [wd.sum()] + [(wd * y[i]).sum() for i in range(k)]
+            want += [(wd * y[i] * y[j]).sum() for i in range(k) for j in range(i, k)] + [(wd * e[i]).sum() for i in range(k)]
+            want = torch.stack(want)
+            np.testing.assert_allclose(stats.cpu().numpy(), want.cpu().numpy(), rtol=1e-11, atol=1e-11 * float(wd.sum()), err_msg=f"B={B} rep={rep}")
+            assert torch.isfinite(lv).all()
+            if seen[rep % 2] is None:
+                seen[rep % 2] = (stats, lv)
+            else:
+                assert torch.equal(stats, seen[rep % 2][0]) and torch.equal(lv, seen[rep % 2][1]), f"B={B} rep={rep}: not reproducible"
 
 
 def test_bench_gpus2_entry_point_on_one_gpu(dev):

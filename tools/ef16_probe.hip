@@ -7,6 +7,7 @@
 #include "../colvars-finder_amd/csrc/ef16_front.hip"
 #include "../colvars-finder_amd/csrc/ef16_back.hip"
 // (everything else - cvf_ef_pack, the batch sums - comes from the library the probe is linked against)
+#include <algorithm>
 #include <cstdio>
 #include <random>
 #include <vector>
@@ -58,7 +59,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dfeat, Tm * D * 64 * 4)); CK(hipMalloc(&dy, Tm * k * 64 * 4)); CK(hipMalloc(&dsaved, cvf_ef16_saved_floats(&m, Tm) * 4));
   CK(hipMalloc(&dq, Tm * k * D * 64 * 4)); CK(hipMalloc(&de, Tm * k * 64 * 4));
   CK(hipMalloc(&dslab, cvf_ef_backward_slab_rows(Tm) * (size_t)pos * 4));
-  CK(hipMalloc(&dscr, cvf_ef16_scratch_doubles(Bmax, k) * 8)); CK(hipMalloc(&dstats, 64 * 8)); CK(hipMalloc(&dlv, 64 * 8)); CK(hipMalloc(&dcoef, 128 * 8));
+  CK(hipMalloc(&dscr, cvf_ef16_scratch_doubles(Bmax, k) * 8)); CK(hipMemset(dscr, 0, cvf_ef16_scratch_doubles(Bmax, k) * 8)); CK(hipMalloc(&dstats, 64 * 8)); CK(hipMalloc(&dlv, 64 * 8)); CK(hipMalloc(&dcoef, 128 * 8));
   CK(hipMemcpy(dth, theta.data(), pos * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dref, ref.data(), ref.size() * 4, hipMemcpyHostToDevice));
@@ -107,11 +108,11 @@ int main(int argc, char** argv) {
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
     const char* fn[10] = {"stage", "kabsch(w0)+barrier", "weights req + features + barrier", "layer 0", "hidden + y + hand-off", "d chain + g", "pass 1", "pass 2", "pass 3", "stats row"};
     const int units = 4 * (int)cvf_ntiles(B);
-    for (int wv = 0; wv < 2; ++wv) {
+    for (int wv = 0; wv < (CVF_STAMP_WPB < 2 ? CVF_STAMP_WPB : 2); ++wv) {
       double acc[10] = {0}, tot = 0;
       int n = 0;
-      for (int u = 0; u < units && u * 4 + wv < 4096; ++u) {
-        const unsigned long long* s = &st[(size_t)(u * 4 + wv) * 64];
+      for (int u = 0; u < units && u * CVF_STAMP_WPB + wv < 4096; ++u) {
+        const unsigned long long* s = &st[(size_t)(u * CVF_STAMP_WPB + wv) * 64];
         if (s[20] == 0 || s[29] == 0) continue;
         for (int i = 0; i < 9; ++i) acc[i] += double(s[21 + i] - s[20 + i]);
         if (s[30]) acc[9] += double(s[30] - s[29]);
@@ -123,8 +124,8 @@ int main(int argc, char** argv) {
       {  // pass 3 in detail
         double d3[5] = {0};
         int n3 = 0;
-        for (int u = 0; u < units && u * 4 + wv < 4096; ++u) {
-          const unsigned long long* s = &st[(size_t)(u * 4 + wv) * 64];
+        for (int u = 0; u < units && u * CVF_STAMP_WPB + wv < 4096; ++u) {
+          const unsigned long long* s = &st[(size_t)(u * CVF_STAMP_WPB + wv) * 64];
           if (s[28] == 0 || s[34] == 0) continue;
           d3[0] += double(s[31] - s[28]); d3[1] += double(s[32] - s[31]); d3[2] += double(s[33] - s[32]); d3[3] += double(s[34] - s[33]);
           d3[4] += double(s[29] - s[34]);
@@ -141,11 +142,11 @@ int main(int argc, char** argv) {
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
     const char* bn[9] = {"requests + alpha", "-", "tangent chain", "last layer", "reverse l=2", "reverse l=1", "reverse l=0", "flush", "-"};
     const int tiles = (int)cvf_ntiles(B);
-    for (int wv = 0; wv < 4; wv += 3) {
+    for (int wv = 0; wv < CVF_STAMP_WPB; wv += 3) {
       double ab[9] = {0}, tb = 0;
       int nb = 0;
-      for (int t = 0; t < tiles && t * 4 + wv < 4096; ++t) {
-        const unsigned long long* s = &st[(size_t)(t * 4 + wv) * 64];
+      for (int t = 0; t < tiles && t * CVF_STAMP_WPB + wv < 4096; ++t) {
+        const unsigned long long* s = &st[(size_t)(t * CVF_STAMP_WPB + wv) * 64];
         if (s[18] == 0 || s[8] == 0) continue;
         ab[0] += double(s[9] - s[8]); ab[2] += double(s[11] - s[9]); ab[3] += double(s[12] - s[11]);
         ab[4] += double(s[14] - s[12]); ab[5] += double(s[15] - s[14]); ab[6] += double(s[17] - s[15]); ab[7] += double(s[18] - s[17]);
