@@ -6,6 +6,9 @@
 // Each block accumulates its share of the gradient in an LDS image of the flat parameter
 // buffer and writes it to its slab row once; slab rows are then summed in fixed order.
 #include "cvf_adam.hpp"
+#include <stddef.h>
+#include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -498,6 +501,484 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The plain AutoEncoderTask step with the chain in REGISTERS (config 2: 55 us at B = 20 000 on the
+// kernel above, whose every layer reads its operands back from the LDS images - 3-6 k cycles of dependent LDS round trips
+// per layer for ~300 cycles of matrix instructions).  Same block = 64-frame tile, wave = 16 frames, same slab / partial
+// outputs; what changes is the data flow of the two dependent chains:
+//   * a vector of up to 80 units lives in the accumulator layout of v_mfma_f32_16x16x4_f32, PERMUTED so that register
+//     (rt, r) of lane group q holds unit 4 (4 rt + r) + q: the next layer's k-step g then takes units 4 g .. 4 g + 3 straight
+//     from register g of the four lane groups - a layer's output IS the next layer's B operand, no LDS, no lane movement;
+//   * the weights (A operands) come from the block's LDS copy of theta with the matching index arithmetic, requested a
+//     whole row tile ahead of its matrix instructions - they do not depend on the previous layer;
+//   * the [unit][frame] images are still written (the weight gradients contract over the tile's 64 frames and need both
+//     operands transposed), but nothing in the forward or backward-data chain waits for them;
+//   * the reconstruction target is the input vector, already in registers in the same layout.
+// One barrier per layer in the backward pass (the zbar image of all four waves), none in the forward pass.
+// Covers chains whose hidden widths are <= 32 and whose input is <= 80 wide, Tanh / no activation (the reference's own
+// autoencoders); everything else - and RegAutoEncoderTask's heads, lags and latent penalties - stays on the kernel above.
+// ------------------------------------------------------------------------------------------------------------------
+template <int RT>
+struct PVec {
+  f32x4 v[RT];
+};
+constexpr int kAe16Pad = 576;   // > 15 rows x 32 columns + 32: the farthest an unclamped read of the last layer's weights reaches
+struct Ae16Lay {
+  int img[CVF_MAX_LAYERS + 1];    // dword offset of image a_l, l = 1..L-1 (d_l rows + a row of ones)
+  int zimg[CVF_MAX_LAYERS + 1];   // dword offset of image zbar_l, l = 1..L (d_l rows)
+  int w, total;
+};
+__host__ __device__ inline Ae16Lay ae16_layout(const cvf_mlp_desc& m) {
+  Ae16Lay lay = {};
+  int rows = 0;
+  for (int l = 1; l < m.n_layers; ++l) {
+    lay.img[l] = rows * AP;
+    rows += m.dims[l] + 1;
+  }
+  for (int l = 1; l <= m.n_layers; ++l) {
+    lay.zimg[l] = rows * AP;
+    rows += m.dims[l];
+  }
+  // (operand tiles read up to 15 rows past an image: into the next image or the weights below - finite values whose
+  //  products land in output rows / columns that are discarded; the allocation ends 16 rows past the weights' start)
+  lay.w = rows * AP;
+  // behind theta: a zeroed pad that the unclamped weight reads of the last layer run into (at most 15 rows of <= 80 floats)
+  const int wfl = ((m.n_params + 3) & ~3) + kAe16Pad;
+  lay.total = lay.w + (wfl > 16 * AP ? wfl : 16 * AP);
+  return lay;
+}
+__host__ inline bool ae16_shape(const cvf_mlp_desc* m) {
+  if (m->n_nets != 1 || m->n_layers < 2 || m->n_layers > CVF_MAX_LAYERS) return false;
+  if (m->dims[0] > 80 || m->dims[0] != m->dims[m->n_layers]) return false;
+  for (int l = 1; l < m->n_layers; ++l)
+    if (m->dims[l] > 32 || m->dims[l] < 1) return false;
+  return chain_is_tanh(m) && (size_t)ae16_layout(*m).total * sizeof(float) <= 80 * 1024;   // two workgroups per CU
+}
+
+// unit of register r of row tile rt in lane group q / unit computed by A-operand row rho of row tile rt
+__device__ __forceinline__ int pv_unit(int rt, int r, int q) { return 4 * (4 * rt + r) + q; }
+__device__ __forceinline__ int pv_row_unit(int rt, int rho) { return 4 * (4 * rt + (rho & 3)) + (rho >> 2); }
+
+template <int RT>
+__device__ __forceinline__ void ae16_store_image(float* __restrict__ img, const PVec<RT>& x, int d, int kq, int fo) {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = pv_unit(rt, r, kq);
+      if (u < d) img[u * AP + fo] = x.v[rt][r];
+    }
+}
+// one 16x16 tile of  A B^T  over the tile's 64 frames, operands = [row][frame] images (k-slot kq of k-step (j, c) = frame
+// 16 j + 4 kq + c on both: eight 16-byte reads)
+__device__ __forceinline__ f32x4 ae16_outer(const float* __restrict__ A, const float* __restrict__ Bm, int rt, int ct, int lane) {
+  const int row = lane & 15, kq = lane >> 4;
+  const float4* a = reinterpret_cast<const float4*>(A + (16 * rt + row) * AP + 4 * kq);
+  const float4* b = reinterpret_cast<const float4*>(Bm + (16 * ct + row) * AP + 4 * kq);
+  float4 av[4], bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    av[j] = a[4 * j];
+    bv[j] = b[4 * j];
+  }
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    acc = mfma4(av[j].x, bv[j].x, acc);
+    acc = mfma4(av[j].y, bv[j].y, acc);
+    acc = mfma4(av[j].z, bv[j].z, acc);
+    acc = mfma4(av[j].w, bv[j].w, acc);
+  }
+  return acc;
+}
+
+// One layer product in the permuted accumulator layout, in two halves so that the NEXT layer's operands can be requested
+// before the current layer's matrix instructions:
+//   ae16_request: the A values (weights from the block's LDS copy of theta; the bias goes into the accumulators) of every row
+//                 tile - unconditional, UNMASKED and unclamped reads: one base address per row tile plus a constant per
+//                 k-step.  A value past the layer's rows or columns is a neighbouring weight or the zeroed pad behind theta -
+//                 finite - and meets either a B value that is exactly 0 (padded input units are kept at 0) or lands in a
+//                 padded output unit, which the callers set to 0 after the activation.  (A select on the load made the LOAD
+//                 conditional - an exec-masked branch with its own wait per weight, forty serialized LDS round trips in the
+//                 first layer; a 0 / 1 mask still cost three vector instructions per weight.)
+//   ae16_apply:   out = b + W in (TRANSPOSED: out = W^T in), the row tiles' accumulation chains interleaved (a lone chain of
+//                 v_mfma_f32_16x16x4_f32 waits 40 cycles per step for its own accumulator); only the k-steps and row tiles the
+//                 layer has are executed (wave-uniform scalar branches).
+template <int RTO, int RTI, bool TRANSPOSED>
+struct Ae16Frag {
+  float a[RTO][4 * RTI];
+  f32x4 b[RTO];
+};
+template <int RTO, int RTI, bool TRANSPOSED>
+__device__ __forceinline__ void ae16_request(Ae16Frag<RTO, RTI, TRANSPOSED>& f, const float* __restrict__ Wl, const float* __restrict__ bl,
+                                             int din, int lane) {
+  const int rho = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int rt = 0; rt < RTO; ++rt) {
+    const int uo = pv_row_unit(rt, rho);
+    const float* base = TRANSPOSED ? Wl + kq * din + uo : Wl + uo * din + kq;
+#pragma unroll
+    for (int g = 0; g < 4 * RTI; ++g) f.a[rt][g] = TRANSPOSED ? base[4 * g * din] : base[4 * g];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f.b[rt][r] = TRANSPOSED ? 0.0f : bl[pv_unit(rt, r, kq)];
+  }
+}
+template <int RTO, int RTI, bool TRANSPOSED>
+__device__ __forceinline__ void ae16_apply(PVec<RTO>& out, const Ae16Frag<RTO, RTI, TRANSPOSED>& f, int n_in, int n_out,
+                                           const PVec<RTI>& in) {
+  const int ngi = (n_in + 3) >> 2;
+#pragma unroll
+  for (int rt = 0; rt < RTO; ++rt) out.v[rt] = f.b[rt];
+#pragma unroll
+  for (int g = 0; g < 4 * RTI; ++g) {
+    if (g < ngi) {   // wave-uniform
+#pragma unroll
+      for (int rt = 0; rt < RTO; ++rt)
+        if (16 * rt < n_out) out.v[rt] = mfma4(f.a[rt][g], in.v[g >> 2][g & 3], out.v[rt]);   // wave-uniform
+    }
+  }
+}
+template <int RTO, int RTI>
+__device__ __forceinline__ void ae16_mul(PVec<RTO>& out, const float* __restrict__ Wl, const float* __restrict__ bl, int din,
+                                         int dout, const PVec<RTI>& in, int lane) {
+  Ae16Frag<RTO, RTI, false> f;
+  ae16_request<RTO, RTI, false>(f, Wl, bl, din, lane);
+  ae16_apply<RTO, RTI, false>(out, f, din, dout, in);
+}
+// zin = W^T zout
+template <int RTI, int RTO>
+__device__ __forceinline__ void ae16_mul_t(PVec<RTI>& zin, const float* __restrict__ Wl, int din, int dout, const PVec<RTO>& zout,
+                                           int lane) {
+  Ae16Frag<RTI, RTO, true> f;
+  ae16_request<RTI, RTO, true>(f, Wl, nullptr, din, lane);
+  ae16_apply<RTI, RTO, true>(zin, f, dout, din, zout);
+}
+
+template <int RTD, int RTH>
+__global__ __launch_bounds__(256, 2) void ae16_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
+                                                       const float* __restrict__ feat_rows, const int64_t* __restrict__ idx,
+                                                       int64_t B, const float* __restrict__ w, double inv_wsum, int with_grad,
+                                                       float* __restrict__ slab, double* __restrict__ partial,
+                                                       int32_t* __restrict__ step, Ae16Lay lay) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  CVF_STAMP(18);
+  const int col = lane & 15, kq = lane >> 4;
+  const int fo = 16 * wv + col;              // this lane's frame column of the tile
+  __shared__ int s_dims[CVF_MAX_LAYERS + 1], s_woff[CVF_MAX_LAYERS], s_boff[CVF_MAX_LAYERS], s_act[CVF_MAX_LAYERS];
+  __shared__ int s_img[CVF_MAX_LAYERS + 1], s_zimg[CVF_MAX_LAYERS + 1];
+  const int L = mlp.n_layers, d0 = mlp.dims[0];
+  const int64_t T = (B + CVF_TILE - 1) / CVF_TILE;
+  // ---- this lane's frame of a tile: index, weight, and the input vector (= the reconstruction target) in the permuted
+  // accumulator layout.  Requested for the FIRST tile before anything else: the two dependent round trips (index, then the
+  // row) run beside the copy of the weights into LDS.
+  struct Frame {
+    PVec<RTD> x;
+    float wb;
+  };
+  auto load_frame = [&](int64_t tile, int fo, int kq) {
+    Frame f;
+    const int64_t b = tile * CVF_TILE + fo;
+    const bool valid = b < B;
+    const int64_t bb = valid ? b : B - 1;
+    const int64_t frame = idx ? idx[bb] : bb;
+    const float wr = w[bb];
+    f.wb = valid ? wr : 0.0f;
+    const float* __restrict__ frow = feat_rows + frame * d0;
+#pragma unroll
+    for (int rt = 0; rt < RTD; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = pv_unit(rt, r, kq);
+        const float x = frow[u < d0 ? u : d0 - 1];
+        f.x.v[rt][r] = x * (u < d0 ? 1.0f : 0.0f);   // (mask, not select: keeps the loads unconditional and batched)
+      }
+    return f;
+  };
+  Frame fr = load_frame(blockIdx.x < T ? (int64_t)blockIdx.x : T - 1, fo, kq);
+  {
+    // the layer table, one entry per thread, straight from the kernel-argument segment (`mlp` is the first argument): indexed
+    // with a run-time index the by-value struct would be copied to scratch memory first (~6 k cycles of one thread's work)
+    typedef const int __attribute__((address_space(4))) kernarg_int;
+    kernarg_int* ka = (kernarg_int*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int oDims = offsetof(cvf_mlp_desc, dims) / 4, oAct = offsetof(cvf_mlp_desc, act) / 4;
+    constexpr int oW = offsetof(cvf_mlp_desc, w_off) / 4, oB = offsetof(cvf_mlp_desc, b_off) / 4;
+    if (tid <= CVF_MAX_LAYERS) s_dims[tid] = ka[oDims + tid];
+    if (tid < CVF_MAX_LAYERS) {
+      s_woff[tid] = ka[oW + tid];
+      s_boff[tid] = ka[oB + tid];
+      s_act[tid] = ka[oAct + tid];
+    }
+    if (tid == 64) {
+#pragma unroll
+      for (int i = 0; i <= CVF_MAX_LAYERS; ++i) {   // (compile-time indices: scalar moves)
+        s_img[i] = lay.img[i];
+        s_zimg[i] = lay.zimg[i];
+      }
+    }
+  }
+  float* WL = lds + lay.w;
+  {
+    // theta -> LDS: 16-byte pieces, eight requests in flight per thread before the first LDS write (a load -> store loop is one
+    // full memory round trip per 256 floats: twelve of them, 10 k cycles, for the autoencoder of config 2)
+    const int n4 = mlp.n_params >> 2;
+    const float4* t4 = reinterpret_cast<const float4*>(theta);   // (the flat parameter buffer starts 16-byte aligned)
+    float4* w4 = reinterpret_cast<float4*>(WL);
+    for (int v0 = tid; v0 < n4; v0 += 256 * 8) {
+      float4 val[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + 256 * u;
+        val[u] = t4[v < n4 ? v : n4 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + 256 * u;
+        if (v < n4) w4[v] = val[u];
+      }
+    }
+    for (int i = 4 * n4 + tid; i < mlp.n_params; i += 256) WL[i] = theta[i];
+    for (int i = mlp.n_params + tid; i < lay.total - lay.w; i += 256) WL[i] = 0.0f;
+  }
+  __syncthreads();
+  for (int l = 1; l < L; ++l)
+    if (tid < 64) lds[__builtin_amdgcn_readfirstlane(s_img[l]) + __builtin_amdgcn_readfirstlane(s_dims[l]) * AP + tid] = 1.0f;   // the bias column's row of ones
+  double loss_acc = 0.0, w_acc = 0.0;
+  float* out_row = slab + (int64_t)blockIdx.x * mlp.n_params;
+  CVF_STAMP(19);
+  const int lane_outer = lane;
+  for (int64_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
+    // (the lane number made opaque INSIDE the loop: everything below is loop-invariant address arithmetic to the compiler, which
+    //  hoists all of it in front of a loop that normally runs once - ~200 live registers, spills, and the scalar ones parked in
+    //  vector lanes)
+    int lane = lane_outer;
+    asm volatile("" : "+v"(lane));
+    const int col = lane & 15, kq = lane >> 4, fo = 16 * wv + col;
+    const bool first = tile == (int64_t)blockIdx.x;
+    if (!first) fr = load_frame(tile, fo, kq);   // (uniform; launches of more than 2048 tiles only)
+    const PVec<RTD> xin = fr.x;
+    const float wb = fr.wb;
+    CVF_STAMP(20);
+    // ---- forward: first layer, hidden layers (the next layer's weights requested ahead of the current one's matrix
+    // instructions), last layer
+    PVec<RTH> cur;
+    {
+      const int d1 = __builtin_amdgcn_readfirstlane(s_dims[1]), act = __builtin_amdgcn_readfirstlane(s_act[0]);
+      Ae16Frag<RTH, RTD, false> f0;
+      ae16_request<RTH, RTD, false>(f0, WL + __builtin_amdgcn_readfirstlane(s_woff[0]), WL + __builtin_amdgcn_readfirstlane(s_boff[0]), d0, lane);
+      ae16_apply<RTH, RTD, false>(cur, f0, d0, d1, xin);
+#pragma unroll
+      for (int rt = 0; rt < RTH; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cur.v[rt][r] = (pv_unit(rt, r, kq) < d1) ? act_f<true>(act, cur.v[rt][r]) : 0.0f;
+      ae16_store_image<RTH>(lds + __builtin_amdgcn_readfirstlane(s_img[1]), cur, d1, kq, fo);
+    }
+    CVF_STAMP(21);
+    {
+      Ae16Frag<RTH, RTH, false> fh;
+      if (L > 2) ae16_request<RTH, RTH, false>(fh, WL + __builtin_amdgcn_readfirstlane(s_woff[1]), WL + __builtin_amdgcn_readfirstlane(s_boff[1]),
+                                               __builtin_amdgcn_readfirstlane(s_dims[1]), lane);
+      for (int l = 1; l + 1 < L; ++l) {
+        const int din = __builtin_amdgcn_readfirstlane(s_dims[l]), dout = __builtin_amdgcn_readfirstlane(s_dims[l + 1]);
+        const int act = __builtin_amdgcn_readfirstlane(s_act[l]);
+        Ae16Frag<RTH, RTH, false> fn = fh;
+        if (l + 2 < L)   // (uniform) the next hidden layer's weights, while this layer multiplies
+          ae16_request<RTH, RTH, false>(fn, WL + __builtin_amdgcn_readfirstlane(s_woff[l + 1]), WL + __builtin_amdgcn_readfirstlane(s_boff[l + 1]), dout, lane);
+        PVec<RTH> nxt;
+        ae16_apply<RTH, RTH, false>(nxt, fh, din, dout, cur);
+#pragma unroll
+        for (int rt = 0; rt < RTH; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cur.v[rt][r] = (pv_unit(rt, r, kq) < dout) ? act_f<true>(act, nxt.v[rt][r]) : 0.0f;
+        ae16_store_image<RTH>(lds + __builtin_amdgcn_readfirstlane(s_img[l + 1]), cur, dout, kq, fo);
+        fh = fn;
+      }
+    }
+    CVF_STAMP(22);
+    // (the target = the input vector is requested AGAIN here, behind the hidden layers, instead of holding twenty registers
+    //  through them - with the fragments of two layers in flight that was the difference between 256 registers + spills and none;
+    //  the rows are in L2 / the Infinity Cache and the round trip runs beside the last layer's matrix instructions)
+    asm volatile("" ::: "memory");   // (not earlier: the compiler would hoist these loads to the top of the forward pass)
+    const PVec<RTD> xt = load_frame(tile, fo, kq).x;
+    PVec<RTD> zl;   // the output, then zbar_L
+    const int dl1 = __builtin_amdgcn_readfirstlane(s_dims[L - 1]);
+    ae16_mul<RTD, RTH>(zl, WL + __builtin_amdgcn_readfirstlane(s_woff[L - 1]), WL + __builtin_amdgcn_readfirstlane(s_boff[L - 1]), dl1, d0, cur, lane);
+    // ---- weighted squared error and zbar_L = 2 w (out - f) / sum(w)     (core.py:666)
+    {
+      const float scale = (float)(2.0 * (double)wb * inv_wsum);
+      const int act_last = __builtin_amdgcn_readfirstlane(s_act[L - 1]);
+      float err2 = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RTD; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool live = pv_unit(rt, r, kq) < d0;
+          float out = zl.v[rt][r];
+          if (act_last) out = act_f<true>(act_last, out);
+          const float df = live ? out - xt.v[rt][r] : 0.0f;
+          err2 = fmaf(df, df, err2);
+          float zb = scale * df;
+          if (act_last) zb *= act_d<true>(act_last, out);
+          zl.v[rt][r] = zb;
+        }
+      loss_acc += (double)wb * (double)err2;
+      if (kq == 0) w_acc += (double)wb;
+    }
+    CVF_STAMP(23);
+    if (!with_grad) continue;   // (uniform) test pass: no images are read by other waves, no barrier needed
+    // ---- backward data chain, all of it, in registers: zbar_l = (W_{l+1}^T zbar_{l+1}) .* act'(a_l), l = L-1 .. 1, every zbar
+    // into an image of its own - ONE barrier for the whole backward pass instead of one per layer
+    ae16_store_image<RTD>(lds + __builtin_amdgcn_readfirstlane(s_zimg[L]), zl, d0, kq, fo);
+    {
+      PVec<RTH> zc;
+      {
+        const int act = __builtin_amdgcn_readfirstlane(s_act[L - 2]);
+        ae16_mul_t<RTH, RTD>(zc, WL + __builtin_amdgcn_readfirstlane(s_woff[L - 1]), dl1, d0, zl, lane);
+        const float* al = lds + __builtin_amdgcn_readfirstlane(s_img[L - 1]);
+#pragma unroll
+        for (int rt = 0; rt < RTH; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int u = pv_unit(rt, r, kq);
+            const float hv = al[(u < dl1 ? u : 0) * AP + fo];
+            float v = zc.v[rt][r];
+            if (act) v *= act_d<true>(act, hv);
+            zc.v[rt][r] = u < dl1 ? v : 0.0f;
+          }
+        ae16_store_image<RTH>(lds + __builtin_amdgcn_readfirstlane(s_zimg[L - 1]), zc, dl1, kq, fo);
+      }
+      CVF_STAMP(24);
+      Ae16Frag<RTH, RTH, true> th;
+      if (L > 2) ae16_request<RTH, RTH, true>(th, WL + __builtin_amdgcn_readfirstlane(s_woff[L - 2]), nullptr,
+                                              __builtin_amdgcn_readfirstlane(s_dims[L - 2]), lane);
+      for (int l = L - 2; l >= 1; --l) {   // zbar_l from zbar_{l+1}
+        const int din = __builtin_amdgcn_readfirstlane(s_dims[l]), dout = __builtin_amdgcn_readfirstlane(s_dims[l + 1]);
+        const int act = __builtin_amdgcn_readfirstlane(s_act[l - 1]);
+        Ae16Frag<RTH, RTH, true> tn = th;
+        if (l >= 2)
+          ae16_request<RTH, RTH, true>(tn, WL + __builtin_amdgcn_readfirstlane(s_woff[l - 1]), nullptr, __builtin_amdgcn_readfirstlane(s_dims[l - 1]), lane);
+        const float* al = lds + __builtin_amdgcn_readfirstlane(s_img[l]);
+        float hv[RTH][4];
+#pragma unroll
+        for (int rt = 0; rt < RTH; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int u = pv_unit(rt, r, kq);
+            hv[rt][r] = al[(u < din ? u : 0) * AP + fo];
+          }
+        PVec<RTH> zp;
+        ae16_apply<RTH, RTH, true>(zp, th, dout, din, zc);
+#pragma unroll
+        for (int rt = 0; rt < RTH; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int u = pv_unit(rt, r, kq);
+            float v = zp.v[rt][r];
+            if (act) v *= act_d<true>(act, hv[rt][r]);
+            zc.v[rt][r] = u < din ? v : 0.0f;
+          }
+        ae16_store_image<RTH>(lds + __builtin_amdgcn_readfirstlane(s_zimg[l]), zc, din, kq, fo);
+        th = tn;
+      }
+    }
+    CVF_STAMP(25);
+    __syncthreads();   // every zbar image and every activation image of all four waves is in place
+    CVF_STAMP(26);
+    // ---- weight gradients: layer l's = zbar_{l+1} (x) [a_l ; 1] over the 64 frames, 16x16 tiles of ALL layers dealt round-robin
+    // to the four waves (one list, no barrier in between); each tile has exactly one owner and goes straight to the slab row
+    auto emit = [&](int l, int rt, int ct, const f32x4& acc) {
+      const int din = __builtin_amdgcn_readfirstlane(s_dims[l]), dout = __builtin_amdgcn_readfirstlane(s_dims[l + 1]);
+      const int wo = __builtin_amdgcn_readfirstlane(s_woff[l]), bo = __builtin_amdgcn_readfirstlane(s_boff[l]);
+      const int i = 16 * ct + col;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 16 * rt + 4 * kq + r;
+        if (o < dout && i <= din) {
+          float* dstp = out_row + (i < din ? wo + o * din + i : bo + o);
+          *dstp = first ? acc[r] : *dstp + acc[r];
+        }
+      }
+    };
+    int next = wv;   // index of this wave's next tile in the list of all layers' tiles (layers L-1 .. 1, then layer 0)
+    int base = 0;
+    for (int l = L - 1; l >= 1; --l) {
+      const int din = __builtin_amdgcn_readfirstlane(s_dims[l]), dout = __builtin_amdgcn_readfirstlane(s_dims[l + 1]);
+      const int nct = (din + 1 + 15) / 16, nrt = (dout + 15) / 16;
+      const float* Zimg = lds + __builtin_amdgcn_readfirstlane(s_zimg[l + 1]);
+      const float* Aimg = lds + __builtin_amdgcn_readfirstlane(s_img[l]);
+      for (; next < base + nrt * nct; next += 4) {
+        const int pr = next - base, rt = pr / nct, ct = pr - rt * nct;
+        emit(l, rt, ct, ae16_outer(Zimg, Aimg, rt, ct, lane));
+      }
+      base += nrt * nct;
+    }
+    CVF_STAMP(27);
+    {   // l = 0: B = [f ; 1] from global memory: k-slot kq of k-step (j, c) is frame 16 j + 4 kq + c of the tile
+      const int dout = __builtin_amdgcn_readfirstlane(s_dims[1]);
+      const int nct = (d0 + 1 + 15) / 16, nrt = (dout + 15) / 16;
+      const float* Zimg = lds + __builtin_amdgcn_readfirstlane(s_zimg[1]);
+      int64_t foff[16];
+#pragma unroll
+      for (int jc = 0; jc < 16; ++jc) {
+        const int64_t fb = tile * CVF_TILE + 16 * (jc >> 2) + 4 * kq + (jc & 3);
+        const int64_t fbc = fb < B ? fb : B - 1;
+        foff[jc] = (idx ? idx[fbc] : fbc) * d0;
+      }
+      for (; next < base + nrt * nct; next += 4) {
+        const int pr = next - base, rt = pr / nct, ct = pr - rt * nct;
+        const int i = 16 * ct + col;
+        const int ic = i < d0 ? i : d0 - 1;
+        const float pad = i == d0 ? 1.0f : 0.0f;
+        float bvals[16];
+#pragma unroll
+        for (int jc = 0; jc < 16; ++jc) bvals[jc] = feat_rows[foff[jc] + ic];
+        const float4* za = reinterpret_cast<const float4*>(Zimg + (16 * rt + col) * AP + 4 * kq);
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 a = za[4 * j];
+          acc = mfma4(a.x, i < d0 ? bvals[4 * j + 0] : pad, acc);
+          acc = mfma4(a.y, i < d0 ? bvals[4 * j + 1] : pad, acc);
+          acc = mfma4(a.z, i < d0 ? bvals[4 * j + 2] : pad, acc);
+          acc = mfma4(a.w, i < d0 ? bvals[4 * j + 3] : pad, acc);
+        }
+        emit(0, rt, ct, acc);
+      }
+    }
+    CVF_STAMP(28);
+    __syncthreads();   // the next tile's forward overwrites the images
+    CVF_STAMP(29);
+  }
+  // ---- per-block loss partials: fixed-order reduction over the block's four waves (as the kernel above)
+  __shared__ double red[4][2];
+  const double ls = wave_sum(loss_acc), wsum = wave_sum(w_acc);
+  if (lane == 0) {
+    red[wv][0] = ls;
+    red[wv][1] = wsum;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    partial[2 * blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    partial[2 * blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    if (with_grad && step != nullptr && blockIdx.x == 0) *step += 1;  // one gradient per optimiser step
+  }
+}
+
+template <class F>
+bool ae16_dispatch(int d0, int hmax, F&& f) {
+  const int rtd = (d0 + 15) / 16, rth = (hmax + 15) / 16;
+#define AE16_CASE(D_, H_)                                                      \
+  if (rtd == D_ && rth == H_) {                                                \
+    f(std::integral_constant<int, D_>{}, std::integral_constant<int, H_>{});   \
+    return true;                                                               \
+  }
+  AE16_CASE(1, 1) AE16_CASE(2, 1) AE16_CASE(3, 1) AE16_CASE(4, 1) AE16_CASE(5, 1)
+  AE16_CASE(1, 2) AE16_CASE(2, 2) AE16_CASE(3, 2) AE16_CASE(4, 2) AE16_CASE(5, 2)
+#undef AE16_CASE
+  return false;
+}
+
 // out2 = fixed-order sums of the per-block {sum w*err, sum w} (+ their ratio): lane l adds rows l, l+64, ..., then the DPP reduction
 __global__ __launch_bounds__(64) void ae_loss_sum_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out2) {
   const int lane = threadIdx.x;
@@ -560,22 +1041,37 @@ extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const fl
               mlp->dims[mlp->n_layers], mlp->dims[0]);
   CVF_REQUIRE(adam == nullptr || (grad && adam->theta && adam->m && adam->v && adam->step_count),
               "cvf_ae_step: incomplete adam arguments");
-  const AeMLayout lay = ae_mlayout(*mlp, grad != nullptr);
-  const size_t lds = (size_t)lay.total * sizeof(float);
-  CVF_REQUIRE(lds <= 160 * 1024, "cvf_ae_step: the chain needs %zu B of LDS per workgroup (> 160 KiB)", lds);
   const int G = ae_grid(B);
   const int Pn = mlp->n_params;
   // scratch: [slab floats][partials as doubles, 8-byte aligned]
   float* slab = scratch;
   double* partial = reinterpret_cast<double*>(scratch + (((int64_t)G * Pn + 1) & ~(int64_t)1));
   hipStream_t s = (hipStream_t)stream;
-  auto kernel = chain_is_tanh(mlp) ? ae_mfma_kernel<true> : ae_mfma_kernel<false>;
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  AeReg none = {};
-  none.T = none.n_tiles = cvf_ntiles(B);
-  hipLaunchKernelGGL(kernel, dim3(G), dim3(256), lds, s, *mlp, theta, feat_rows, idx, B, w, inv_wsum, grad ? 1 : 0, slab,
-                     partial, grad ? step_count : nullptr, none);
-  int rc = cvf_check_launch("ae_mfma_kernel");
+  static const bool no_fast = getenv("CVF_NO_AE16") != nullptr;
+  int hmax = 1;
+  for (int l = 1; l < mlp->n_layers; ++l) hmax = mlp->dims[l] > hmax ? mlp->dims[l] : hmax;
+  bool fast = !no_fast && ae16_shape(mlp) && (reinterpret_cast<uintptr_t>(theta) & 15) == 0;
+  if (fast) {   // the chain in registers (ae16_kernel)
+    const size_t lds16 = (size_t)ae16_layout(*mlp).total * sizeof(float);
+    fast = ae16_dispatch(mlp->dims[0], hmax, [&](auto d_, auto h_) {
+      auto kernel = ae16_kernel<decltype(d_)::value, decltype(h_)::value>;
+      if (lds16 > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+      hipLaunchKernelGGL(kernel, dim3(G), dim3(256), lds16, s, *mlp, theta, feat_rows, idx, B, w, inv_wsum, grad ? 1 : 0, slab, partial,
+                         grad ? step_count : nullptr, ae16_layout(*mlp));
+    });
+  }
+  if (!fast) {
+    const AeMLayout lay = ae_mlayout(*mlp, grad != nullptr);
+    const size_t lds = (size_t)lay.total * sizeof(float);
+    CVF_REQUIRE(lds <= 160 * 1024, "cvf_ae_step: the chain needs %zu B of LDS per workgroup (> 160 KiB)", lds);
+    auto kernel = chain_is_tanh(mlp) ? ae_mfma_kernel<true> : ae_mfma_kernel<false>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    AeReg none = {};
+    none.T = none.n_tiles = cvf_ntiles(B);
+    hipLaunchKernelGGL(kernel, dim3(G), dim3(256), lds, s, *mlp, theta, feat_rows, idx, B, w, inv_wsum, grad ? 1 : 0, slab,
+                       partial, grad ? step_count : nullptr, none);
+  }
+  int rc = cvf_check_launch(fast ? "ae16_kernel" : "ae_mfma_kernel");
   if (rc) return rc;
   if (grad == nullptr) {   // loss only: the blocks' [sum w e^2, sum w] pairs, fixed order
     hipLaunchKernelGGL(ae_loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, G, out2);

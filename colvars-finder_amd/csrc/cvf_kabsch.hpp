@@ -226,6 +226,9 @@ CVF_HD void kabsch_newton_terms(const double (&R)[3][3], const double (&H)[3][3]
   om[2] = small ? z : 0.0;
 }
 
+// KINV = false: the caller wants the rotation only (features without the derivative's K^-1): ONE Newton step, second order in
+// omega (|R - R*| <= 2e-11 from the fp32 guess, below the fp32 rounding of the stored rotation); out.Kinv is not written.
+template <bool KINV = true>
 CVF_HD void kabsch_from_H(const double (&H)[3][3], KabschOut& out) {
   double r0[3][3];
   {
@@ -272,7 +275,7 @@ CVF_HD void kabsch_from_H(const double (&H)[3][3], KabschOut& out) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) R[i][j] = Rn[i][j];
   }
-  {  // second step (omega ~ 1e-6 .. 1e-12 now: first order), whose K^-1 is the one the derivative kernels use
+  if constexpr (KINV) {  // second step (omega ~ 1e-6 .. 1e-12 now: first order), whose K^-1 is the one the derivative kernels use
     kabsch_newton_terms(R, H, Kinv, om);
     const double x = om[0], y = om[1], z = om[2];
 #pragma unroll
@@ -287,8 +290,10 @@ CVF_HD void kabsch_from_H(const double (&H)[3][3], KabschOut& out) {
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) out.R[3 * i + j] = (float)R[i][j];
+  if constexpr (KINV) {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) out.Kinv[i] = (float)Kinv[i];
+    for (int i = 0; i < 6; ++i) out.Kinv[i] = (float)Kinv[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------

@@ -124,7 +124,13 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
 #pragma unroll
       for (int j = 0; j < 3; ++j) Hm[i][j] = fma(-cd[i], acc[12 + j], acc[3 + 3 * i + j]);
     KabschOut ko;
-    kabsch_from_H(Hm, ko);
+    if (x_lag != nullptr) {   // (uniform) transfer-operator mode: no derivative through the alignment, the rotation alone
+      kabsch_from_H<false>(Hm, ko);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ko.Kinv[i] = 0.0f;
+    } else {
+      kabsch_from_H<true>(Hm, ko);
+    }
     const Centre c = centre_of(cd);
     const float av[kAuxP] = {ko.R[0], ko.R[1], ko.R[2], ko.R[3], ko.R[4], ko.R[5], ko.R[6], ko.R[7], ko.R[8], c.hi[0], c.hi[1], c.hi[2],
                              ko.Kinv[0], ko.Kinv[1], ko.Kinv[2], ko.Kinv[3], ko.Kinv[4], ko.Kinv[5], c.lo[0], c.lo[1], c.lo[2]};

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(64) void k1_stream_kernel(cvf_pp_desc pp, const flo
     }
     if (it == 2) CVF_STAMP(3);
     KabschOut ko;
-    kabsch_from_H(H, ko);
+    if (aux_tiled) kabsch_from_H<true>(H, ko);    // (uniform) rotation + K^-1 for the derivative kernels
+    else kabsch_from_H<false>(H, ko);             // features only: the rotation alone, one Newton step less
     if (it == 2) CVF_STAMP(4);
     if (aux_tiled) {
       float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + lane;

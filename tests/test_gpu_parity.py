@@ -779,6 +779,54 @@ def test_front_launch_batch_sums_over_many_launches(dev):
                 assert torch.equal(stats, seen[rep % 2][0]) and torch.equal(lv, seen[rep % 2][1]), f"B={B} rep={rep}: not reproducible"
 
 
+@pytest.mark.parametrize("dims", [([66, 20, 20, 20, 2], [2, 10, 10, 66]), ([30, 32, 3], [3, 32, 30]), ([9, 8, 8, 1], [1, 8, 9]),
+                                  ([66, 20, 2], [2, 40, 66])],
+                         ids=["config2", "wide32", "narrow", "old_kernel_40"])
+def test_autoencoder_step_at_config2_batch_vs_oracle_and_by_duplication(dev, dims):
+    """cvf_ae_step at the batch sizes of BASELINE config 2 (20 000 frames = 313 workgroups, and 40 000),
+    which no fixture reaches.  (i) loss and every parameter gradient of a 20 000-frame batch against the fp64 oracle
+    (core.py:652-666); (ii) size-independent: the batch made of two copies of it (40 000 frames) has the same loss and
+    gradient - the loss is a ratio of sums; (iii) a ragged batch (20 000 - 37).  `config2` / `wide32` / `narrow` run on the
+    register-resident kernel (ae16_kernel: hidden widths <= 32), `old_kernel_40` (a 40-wide layer) on ae_mfma_kernel."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    e_dims, d_dims = dims
+    n_atoms = e_dims[0] // 3
+    B = 20000
+    traj, w, ref = make_molecule_traj(n_atoms, B, seed=77)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=[("position", tuple(range(n_atoms)))], use_angle_value=False)
+    sd0 = nnref.init_autoencoder(e_dims, d_dims, torch.Generator().manual_seed(11), torch.float32)
+    model = nn.AutoEncoder(e_dims, d_dims)
+    model.load_state_dict(sd0)
+    task = core.AutoEncoderTask(Traj(np.concatenate([traj, traj]), np.concatenate([w, w]), 0.5), make_layer(spec, n_atoms, dev), model,
+                                "/tmp/cvf_test", learning_rate=1e-3, batch_size=B, num_epochs=1, device=dev, verbose=False,
+                                save_model_every_step=0)
+    F, W = task._feature_traj, task._weights
+
+    def loss_and_grad(nb):
+        l_ = float(task.weighted_MSE_loss(F[:nb], W[:nb]))
+        task.backward()
+        return l_, torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+
+    l1, g1 = loss_and_grad(B)
+    l2, g2 = loss_and_grad(2 * B)
+    np.testing.assert_allclose(l2, l1, rtol=2e-6)
+    np.testing.assert_allclose(g2, g1, rtol=1e-4, atol=2e-6 * np.abs(g1).max())
+    torch.set_default_dtype(torch.float64)
+    try:
+        Fo = oracle_layer(spec)(torch.tensor(traj, dtype=torch.float64))
+        for nb in (B, B - 37):
+            sd = {k_: p.double().requires_grad_(True) for k_, p in sd0.items()}
+            lo = losses.ae_loss(sd, Fo[:nb], torch.tensor(w[:nb]))
+            lo.backward()
+            want = torch.cat([sd[n_].grad.reshape(-1) for n_, _ in model.named_parameters()]).numpy()
+            lg, gg = loss_and_grad(nb)
+            np.testing.assert_allclose(lg, float(lo.detach()), rtol=5e-6)
+            np.testing.assert_allclose(gg, want, rtol=0, atol=2e-5 * np.abs(want).max())
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
 def test_bench_gpus2_entry_point_on_one_gpu(dev):
     """the driver's command shape `python bench.py --gpus 2 ...` (no launcher around it) must start its own
     ranks and print ONE JSON line with n_gpus 2 and strong scaling.  Rehearsed on the one GPU of the test box: both ranks on

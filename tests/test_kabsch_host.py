@@ -31,6 +31,9 @@ def solver(tmp_path_factory):
         P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         lib.cvf_test_kabsch(P(H), n, P(R), P(K), P(R0), P(ok))
         Kf = np.stack([K[:, 0], K[:, 1], K[:, 2], K[:, 1], K[:, 3], K[:, 4], K[:, 2], K[:, 4], K[:, 5]], 1).reshape(n, 3, 3)
+        Rr = np.zeros((n, 9), np.float32)
+        lib.cvf_test_kabsch_rotation_only(P(H), n, P(Rr))
+        run.rotation_only = Rr.reshape(n, 3, 3).astype(np.float64)
         return R.reshape(n, 3, 3).astype(np.float64), Kf.astype(np.float64), R0.reshape(n, 3, 3).astype(np.float64), ok.astype(bool)
 
     return run
@@ -88,6 +91,8 @@ def test_rotation_and_kinv_match_the_svd(solver):
     assert ok.sum() > 19900 and np.isfinite(R).all() and np.isfinite(K).all()
     err = np.abs(R - Rr).max((1, 2))
     assert err[ok].max() < 1e-7, err[ok].max()       # fp32 rounding of the stored rotation; the fp64 value is ~1e-12 off
+    # the rotation-only variant (features without K^-1: one Newton step) stores the same rotation up to fp32 rounding
+    assert np.abs(solver.rotation_only - Rr).max((1, 2))[ok].max() < 1.5e-7
     # the fp32 stage alone is orders of magnitude off on ill-conditioned frames - the polish is what carries the precision
     assert np.abs(R0 - Rr).max((1, 2))[ok].max() > 1e-4
     # Kinv = (tr(P) I - P)^-1, P = sym(R^T H)

@@ -1,6 +1,6 @@
-// Developer tool: phase timing of ae_mfma_kernel (config-2 shape) with s_memtime stamps.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCVF_STAMPS -Iinclude -Icolvars-finder_amd/csrc -Wno-pass-failed \
-//       tools/ae_probe.hip colvars-finder_amd/csrc/stats.hip colvars-finder_amd/csrc/ef_mfma.hip -o /tmp/ae_probe
+// Developer tool: phase timing of the AutoEncoderTask step kernel (ae16_kernel, config-2 shape) with s_memtime stamps.
+//   hipcc -O3 -std=c++17 -fno-slp-vectorize --offload-arch=gfx950 -DCVF_STAMPS -DCVF_STAMP_WPB=2 -Iinclude -Icolvars-finder_amd/csrc -Wno-pass-failed \
+//       tools/ae_probe.hip -Lcolvars-finder_amd/colvarsfinder -lcvf_hip -Wl,-rpath,$ORIGIN/../../colvars-finder_amd/colvarsfinder -o tools/build/ae_probe
 #include "../colvars-finder_amd/csrc/ae.hip"
 #include <cstdio>
 #include <random>
@@ -41,31 +41,36 @@ int main() {
   (void)hipDeviceSynchronize();
   std::vector<unsigned long long> st(64 * 4096);
   (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
-  const int ids[] = {18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 40};
-  const char* nm[] = {"", "setup (zero LDS, weights)", "frame index/weight loads", "forward (7 layers)", "error + zbar_L", "barrier l=6", "outer l=6", "bwd-data l=6 + barrier", "outer l=5", "bwd-data l=5 + barrier", "outer l=4", "bwd-data l=4 + barrier", "outer l=3", "bwd-data l=3 + barrier", "outer l=2", "bwd-data l=2 + barrier", "outer l=1", "bwd-data l=1 + barrier", "outer l=0", "(end)"};
+  // ae16_kernel (the chain in registers): stamps 18..29
+  const int ids[] = {18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29};
+  const char* nm[] = {"", "setup (tables, weights -> LDS)", "frame index / weight / input vector", "first layer + image", "hidden layers + images", "last layer + error",
+                      "zbar_{L-1} (registers)", "zbar of the hidden layers", "barrier", "gradient tiles of layers L-1 .. 1", "gradient tiles of layer 0", "barrier"};
   const int NS = sizeof(ids) / sizeof(ids[0]);
-  std::vector<double> acc(NS, 0.0); int cnt = 0;
-  for (int b = 0; b < 313; ++b) {
-    const unsigned long long* s = &st[(b * 2) % 4096 * 64];
-    bool ok = s[18] != 0;
-    for (int i = 1; i < NS; ++i) ok = ok && s[ids[i]] >= s[ids[i - 1]] && s[ids[i]] - s[ids[i - 1]] < 10000000ull;
-    if (!ok) continue;
-    for (int i = 1; i < NS; ++i) acc[i] += double(s[ids[i]] - s[ids[i - 1]]);
-    ++cnt;
-  }
-  double tot = 0;
-  for (int i = 1; i < NS; ++i) { printf("   %-28s %8.0f cycles\n", nm[i], acc[i] / cnt); tot += acc[i] / cnt; }
-  printf("   total %8.0f cycles over %d blocks (wave 0)\n", tot, cnt);
-  {
-    double a[8] = {0}; int c2 = 0;
+  for (int wave = 0; wave < CVF_STAMP_WPB; ++wave) {
+    std::vector<double> acc(NS, 0.0); int cnt = 0;
     for (int b = 0; b < 313; ++b) {
-      const unsigned long long* q = &st[(b * 2) % 4096 * 64];
-      if (q[47] == 0 || q[47] < q[20] || q[47] - q[20] > 10000000ull) continue;
-      a[0] += double(q[41] - q[20]);
-      for (int l = 1; l < 7; ++l) a[l] += double(q[41 + l] - q[40 + l]);
-      ++c2;
+      const unsigned long long* s = &st[(size_t)((b * CVF_STAMP_WPB + wave) % 4096) * 64];
+      bool ok = s[18] != 0;
+      for (int i = 1; i < NS; ++i) ok = ok && s[ids[i]] >= s[ids[i - 1]] && s[ids[i]] - s[ids[i - 1]] < 10000000ull;
+      if (!ok) continue;
+      for (int i = 1; i < NS; ++i) acc[i] += double(s[ids[i]] - s[ids[i - 1]]);
+      ++cnt;
     }
-    for (int l = 0; l < 7; ++l) printf("   forward layer %d (%d -> %d): %8.0f cycles\n", l, dims[l], dims[l + 1], a[l] / c2);
+    double tot = 0;
+    printf("-- ae16_kernel wave %d\n", wave);
+    for (int i = 1; i < NS; ++i) { printf("   %-38s %8.0f cycles\n", nm[i], acc[i] / (cnt ? cnt : 1)); tot += acc[i] / (cnt ? cnt : 1); }
+    printf("   total %8.0f cycles over %d blocks\n", tot, cnt);
+  }
+  {   // launch time
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
+    for (int it = 0; it < 50; ++it) cvf_ae_step(&m, dth, dfeat, didx, B, dw, 1.0 / B, dscr, dout2, dgrad, nullptr, nullptr, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipDeviceSynchronize();
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("cvf_ae_step (step kernel + slab sum): %.1f us per call\n", 1e3 * ms / 50);
   }
   return 0;
 }

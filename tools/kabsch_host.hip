@@ -23,3 +23,15 @@ extern "C" void cvf_test_kabsch(const double* H, int n, float* R, float* Kinv, f
       for (int j = 0; j < 3; ++j) R0[9 * b + 3 * i + j] = g[i][j];
   }
 }
+
+// the rotation-only variant (features without the derivative's K^-1: one Newton step)
+extern "C" void cvf_test_kabsch_rotation_only(const double* H, int n, float* R) {
+  for (int b = 0; b < n; ++b) {
+    double Hm[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Hm[i][j] = H[9 * b + 3 * i + j];
+    KabschOut ko;
+    kabsch_from_H<false>(Hm, ko);
+    for (int i = 0; i < 9; ++i) R[9 * b + i] = ko.R[i];
+  }
+}
