@@ -696,7 +696,21 @@ __global__ __launch_bounds__(256, 2) void ae16_kernel(cvf_mlp_desc mlp, const fl
       }
     return f;
   };
-  Frame fr = load_frame(blockIdx.x < T ? (int64_t)blockIdx.x : T - 1, fo, kq);
+  // Order of the prologue's requests (vector memory returns in issue order): the first tile's frame index and weight, the
+  // weights (theta), then - once the index is there - the frame's row; the LDS copy of theta waits for theta only, and the
+  // barrier behind it for LDS traffic only, so the row's round trip runs into the first layer instead of in front of the barrier.
+  Frame fr;
+  const float* __restrict__ frow0;
+  {
+    const int64_t tile0 = blockIdx.x < T ? (int64_t)blockIdx.x : T - 1;
+    const int64_t b = tile0 * CVF_TILE + fo;
+    const bool valid = b < B;
+    const int64_t bb = valid ? b : B - 1;
+    const int64_t frame = idx ? idx[bb] : bb;
+    const float wr = w[bb];
+    fr.wb = valid ? wr : 0.0f;
+    frow0 = feat_rows + frame * d0;
+  }
   {
     // the layer table, one entry per thread, straight from the kernel-argument segment (`mlp` is the first argument): indexed
     // with a run-time index the by-value struct would be copied to scratch memory first (~6 k cycles of one thread's work)
@@ -721,27 +735,35 @@ __global__ __launch_bounds__(256, 2) void ae16_kernel(cvf_mlp_desc mlp, const fl
   float* WL = lds + lay.w;
   {
     // theta -> LDS: 16-byte pieces, eight requests in flight per thread before the first LDS write (a load -> store loop is one
-    // full memory round trip per 256 floats: twelve of them, 10 k cycles, for the autoencoder of config 2)
+    // full memory round trip per 256 floats)
     const int n4 = mlp.n_params >> 2;
-    const float4* t4 = reinterpret_cast<const float4*>(theta);   // (the flat parameter buffer starts 16-byte aligned)
+    const float4* t4 = reinterpret_cast<const float4*>(theta);   // (the flat parameter buffer starts 16-byte aligned: host check)
     float4* w4 = reinterpret_cast<float4*>(WL);
-    for (int v0 = tid; v0 < n4; v0 += 256 * 8) {
-      float4 val[8];
+    float4 val[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int v = v0 + 256 * u;
-        val[u] = t4[v < n4 ? v : n4 - 1];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int v = v0 + 256 * u;
-        if (v < n4) w4[v] = val[u];
-      }
+    for (int u = 0; u < 8; ++u) {
+      const int v = tid + 256 * u;
+      val[u] = t4[v < n4 ? v : n4 - 1];
     }
+    // the first tile's row (its address needs the index requested above)
+#pragma unroll
+    for (int rt = 0; rt < RTD; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = pv_unit(rt, r, kq);
+        const float x = frow0[u < d0 ? u : d0 - 1];
+        fr.x.v[rt][r] = x * (u < d0 ? 1.0f : 0.0f);
+      }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int v = tid + 256 * u;
+      if (v < n4) w4[v] = val[u];
+    }
+    for (int v0 = tid + 256 * 8; v0 < n4; v0 += 256) w4[v0] = t4[v0];   // (chains of more than 8192 parameters)
     for (int i = 4 * n4 + tid; i < mlp.n_params; i += 256) WL[i] = theta[i];
     for (int i = mlp.n_params + tid; i < lay.total - lay.w; i += 256) WL[i] = 0.0f;
   }
-  __syncthreads();
+  lds_barrier();   // (LDS traffic only: the row requested above is still on its way)
   for (int l = 1; l < L; ++l)
     if (tid < 64) lds[__builtin_amdgcn_readfirstlane(s_img[l]) + __builtin_amdgcn_readfirstlane(s_dims[l]) * AP + tid] = 1.0f;   // the bias column's row of ones
   double loss_acc = 0.0, w_acc = 0.0;
