@@ -452,11 +452,43 @@ def main():
         torch.cuda.empty_cache()
         note("align+feature kernel alone, out of cache")
         out["roofline_align_feature"] = align_feature_roofline(task, ref, dev, pmc_traffic)
+    if world == 1 and not args.no_extras:
+        out["other_configs"] = other_configs()
     if world == 1 and args.cpu_seconds > 0:
         note("CPU baseline")
         xb, wb = device_frames(B, ref, 0.3, SEED + 1, dev)
         out["cpu_baseline"] = cpu_baseline(xb.cpu().numpy(), wb.cpu().numpy().astype(np.float64), ref, a, sd0, B, args.cpu_seconds)
     print(json.dumps(out))
+
+
+def other_configs():
+    """The other BASELINE configurations' steps on this GPU, each as a child `python bench.py --workload X` (its own process:
+    fresh allocator, its own one JSON line): config 2 (AutoEncoderTask), the transfer-operator mode the shipped notebook runs,
+    and the config-5 shape (5000 atoms, k = 6) with its position against the HBM roofline - SURVEY 8d: a generator step reads
+    every frame twice, 2 (12 N + 4) + O(k) = 120 008 B per frame-step at N = 5000.  Extra measurements, not `value`."""
+    import subprocess
+    res = {}
+    for wl, extra in (("c2", []), ("transfer", []), ("c5", ["--batch", "2000"]), ("c5", ["--batch", "16000"])):
+        key = wl if not extra else f"{wl}_batch{extra[1]}"
+        note(f"other configurations: {key}")
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "60", "--warmup", "10"] + extra,
+                               capture_output=True, text=True, timeout=240)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            d = json.loads(line)
+        except Exception as exc:   # (an extra measurement must not take the benchmark line down with it)
+            res[key] = {"error": f"{type(exc).__name__}: {exc}"}
+            continue
+        row = {"workload": d.get("workload"), "us_per_step": d["ms_per_step"] * 1e3, "frames_per_s": d["value"],
+               "call_avg_us": d.get("kernel_avg_us") or d.get("call_avg_us")}
+        if wl == "c5":
+            bpf = 2 * (12 * C5["n_atoms"] + 4) + 8 * C5["k"]
+            gbs = bpf * d["batch_per_gpu"] / (d["ms_per_step"] * 1e-3) / 1e9
+            row["roofline_c5_step"] = {"bound": "hbm", "bytes_per_frame_step": bpf, "frames_per_step": d["batch_per_gpu"], "achieved": gbs,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                       "align_feature_frac_inside_the_step": d.get("align_feature_frac_of_8TBps")}
+        res[key] = row
+    return res
 
 
 def align_feature_roofline(task, ref, dev, pmc_traffic):
@@ -532,15 +564,18 @@ def main_c5(args):
     n_atoms, k = C5["n_atoms"], C5["k"]
     frames = C5["frames"] if args.frames == 100000 else args.frames
     B = C5["batch"] if args.batch == 20000 else args.batch
-    x, w, ref = make_shard(frames, rank, n_atoms, scale=2.0, sigma=0.05)   # nm-like units: 20 A / 0.5 A of SURVEY 8d (in A the tanh nets saturate at init)
+    # nm-like units: 20 A / 0.5 A of SURVEY 8d (in A the tanh nets saturate at init); frames generated on the device
+    ref = np.random.RandomState(SEED).normal(scale=2.0, size=(n_atoms, 3))
     a = torch.tensor(diag_coeff_for(n_atoms, SEED), dtype=torch.float32)
     torch.manual_seed(SEED)
     model = nn.EigenFunctions(C5["layers"], k)
     layer = pp.AlignFeatureLayer(n_atoms, list(range(n_atoms)), ref, c5_features(n_atoms))
-    task = core.EigenFunctionTask(Traj(x, w, 1.0), layer, model, "/tmp/cvf_bench", ALPHA, C5["eig_w"], diag_coeff=a, beta=BETA,
+    tok = np.zeros((64, n_atoms, 3), dtype=np.float32) + ref[None].astype(np.float32)
+    task = core.EigenFunctionTask(Traj(tok, np.ones(64), 1.0), layer, model, "/tmp/cvf_bench", ALPHA, C5["eig_w"], diag_coeff=a, beta=BETA,
                                   lag_tau=0, learning_rate=LR, k=k, batch_size=B, device=dev, verbose=False, save_model_every_step=0)
+    frames = max(frames, B)
     n_batches = frames // B
-    X, Wt = task._traj, task._weights
+    X, Wt = device_frames(frames, ref, 0.05, SEED + 1 + rank, dev, chunk=2000)
     log = torch.zeros(n_batches, 3 + 2 * k, device=dev, dtype=torch.float64)
 
     def step(i):
