@@ -51,7 +51,7 @@ KERNEL_OF_CALL = {"cvf_ef16_front": "ef16_front_kernel", "cvf_ef16_backward": "e
                   "cvf_ef_fwd_metric_stats": "ef_fwd_metric_kernel", "cvf_ef_align_fwd_metric_stats": "ef_fwd_metric_kernel",
                   "cvf_align_feature_fwd": "k1_align_quad_kernel", "cvf_align_feature_fwd@1M": "k1_stream_kernel",
                   "cvf_align_feature_fwd@c5": "k1_large_slice_kernel"}
-PROFILE_TAG = "r2"   # profiles/<tag>_pmc_traffic.json is the committed PMC summary `roofline.traffic` is read from
+PROFILE_TAG = "r3"   # profiles/<tag>_pmc_traffic.json is the committed PMC summary `roofline.traffic` is read from
 
 
 def make_shard(n_frames, rank, n_atoms=N_ATOMS, scale=2.0, sigma=0.3):

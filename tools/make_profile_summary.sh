@@ -2,7 +2,7 @@
 # Collects the round's rocprofv3 outputs (gpurun_out/$TAG/*) into the tracked summaries under profiles/.
 set -e
 cd "$(dirname "$0")/.."
-TAG="${CVF_PROFILE_TAG:-r2}"
+TAG="${CVF_PROFILE_TAG:-r3}"
 cp gpurun_out/$TAG/kt/bench_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
 [ -f gpurun_out/$TAG/kt_k1/k1_kernel_stats.csv ] && cp gpurun_out/$TAG/kt_k1/k1_kernel_stats.csv profiles/${TAG}_k1_roofline_kernel_stats.csv
 (cd gpurun_out/$TAG && {
