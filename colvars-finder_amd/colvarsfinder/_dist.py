@@ -105,10 +105,59 @@ def _abi():
     return _abi_comm
 
 
+_p2p_comm = None   # CVF_COMM=p2p: the one-shot peer-to-peer reduce of include/cvf.h's cvf_p2p_* (csrc/p2p.hip)
+_P2P_MAX_BYTES = int(os.environ.get("CVF_P2P_MAX_BYTES", str(1 << 20)))
+
+
+def _p2p():
+    """With ``CVF_COMM=p2p`` the two sums go through ``cvf_p2p_allreduce_*``: every rank writes its vector into a slot of every
+    peer's IPC-shared window and adds the slots in rank order (one xGMI hop instead of a ring's 2 (N - 1),
+    bitwise the same sum on every rank).  The IPC handles travel over the torch process group, once."""
+    global _p2p_comm
+    if os.environ.get("CVF_COMM", "") != "p2p" or not torch.cuda.is_available():
+        return None
+    if _p2p_comm is None:
+        import ctypes
+        from . import _hip
+        lib = _hip.lib()
+        nb = lib.cvf_p2p_handle_bytes()
+        mine = torch.zeros(nb, dtype=torch.uint8)
+        handle = ctypes.c_void_p()
+        _hip.check(lib.cvf_p2p_create(ctypes.byref(handle), rank(), world(), _P2P_MAX_BYTES, mine.data_ptr()), "cvf_p2p_create")
+        if world() > 1:
+            on_dev = backend() == "nccl"
+            src = mine.cuda() if on_dev else mine
+            parts = [torch.zeros_like(src) for _ in range(world())]
+            dist.all_gather(parts, src)
+            allh = torch.cat([p_.cpu() for p_ in parts]).contiguous()
+        else:
+            allh = mine
+        _hip.check(lib.cvf_p2p_connect(handle, allh.data_ptr()), "cvf_p2p_connect")
+        if world() > 1:
+            dist.barrier()      # every rank has opened every window before the first kernel writes into one
+        _p2p_comm = handle
+    return _p2p_comm
+
+
+def p2p_error():
+    """0, or the number of the all-reduce in which a peer did not arrive (``CVF_COMM=p2p`` only; synchronises the device)."""
+    if _p2p_comm is None:
+        return 0
+    from . import _hip
+    return int(_hip.lib().cvf_p2p_error(_p2p_comm))
+
+
 def allreduce_sum_(t):
     """In-place sum over ranks; a no-op in a single-process run."""
     if collectives():
-        comm = _abi() if t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous() else None
+        plain = t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous()
+        p2p = _p2p() if plain and t.numel() * t.element_size() <= _P2P_MAX_BYTES else None
+        if p2p is not None:
+            from . import _hip
+            fn = _hip.lib().cvf_p2p_allreduce_f64 if t.dtype == torch.float64 else _hip.lib().cvf_p2p_allreduce_f32
+            _hip.check(fn(p2p, _hip.ptr(t), t.numel(), _hip.stream()), "cvf_p2p_allreduce")
+            return t
+        comm = _abi() if plain else None
         if comm is not None:
             from . import _hip
             fn = _hip.lib().cvf_comm_allreduce_f64 if t.dtype == torch.float64 else _hip.lib().cvf_comm_allreduce_f32

@@ -109,6 +109,13 @@ _SIGNATURES = {
     "cvf_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "cvf_comm_allreduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "cvf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "cvf_p2p_handle_bytes": (C.c_int, []),
+    "cvf_p2p_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "cvf_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cvf_p2p_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cvf_p2p_allreduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "cvf_p2p_error": (C.c_int, [C.c_void_p]),
+    "cvf_p2p_destroy": (C.c_int, [C.c_void_p]),
     "cvf_ef_stats_scratch_doubles": (C.c_int64, [C.c_int, C.c_int]),
     "cvf_ef_stats": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -129,8 +129,18 @@ class _CVModel(torch.nn.Sequential):
             return t.device
         return torch.device("cuda")
 
+    _warned_no_graph = False
+
     def forward(self, x):
         x = torch.as_tensor(x)
+        if x.requires_grad and torch.is_grad_enabled() and not _CVModel._warned_no_graph:
+            # (the reference returns a differentiable Sequential; this one runs HIP kernels without an autograd graph - say so
+            #  once instead of handing back a silently detached result.  ADVICE r2)
+            _CVModel._warned_no_graph = True
+            import warnings
+            warnings.warn("colvar_model() / reg_model() on MI355X evaluate the CVs with HIP kernels: the result carries no autograd "
+                          "graph (d xi / d x is not available from it). For gradients of the learned CVs load the TorchScript export "
+                          "written by save_model (scripted_cv_cpu.pt / scripted_cv_gpu.pt), which is differentiable.", stacklevel=2)
         dev = _hip.require_gpu(self._compute_device())
         src_dev, src_dt = x.device, (x.dtype if x.dtype.is_floating_point else torch.float32)
         with torch.cuda.device(dev):
@@ -253,8 +263,9 @@ class _FlatParams:
 class _FusedOptimizer:
     """``optimizer`` attribute of the tasks: Adam / SGD as ONE kernel over the flat buffer (same update rule and
     defaults as the ``torch.optim`` objects built at core.py:163-166), with the parts of the ``torch.optim.Optimizer``
-    surface user code touches: ``param_groups`` (``lr`` may be changed between steps - a scheduler, a manual decay -
-    and is honoured by captured hipGraphs too: the kernels read it from a device scalar), ``zero_grad``, ``step``,
+    surface user code touches: ``param_groups`` (``param_groups[0]['lr']`` may be edited between steps - a manual decay, or a
+    schedule driven by user code; ``torch.optim.lr_scheduler`` classes insist on a ``torch.optim.Optimizer`` and do not take this
+    object - and is honoured by captured hipGraphs too: the kernels read it from a device scalar), ``zero_grad``, ``step``,
     ``state_dict`` / ``load_state_dict`` (the reference never checkpoints the optimizer; SURVEY 8f row 2 asks for it)."""
 
     def __init__(self, flat, name, lr):
@@ -1413,7 +1424,8 @@ class _RegGenerator:
                                       f"{hidden} must be one kernel width (no zero padding)")
         self.pdims = [d_r] + [H] * len(hidden) + [1]
         act_module = next(mod for mod in m.reg[0]._modules.values() if not isinstance(mod, torch.nn.Linear))
-        model = EigenFunctions(self.pdims, self.K, copy.deepcopy(act_module))
+        with torch.random.fork_rng(devices=[]):   # (the virtual nets' initial values are overwritten: leave the caller's RNG stream alone)
+            model = EigenFunctions(self.pdims, self.K, copy.deepcopy(act_module))
         tok = np.zeros((4,) + tuple(task._traj_host.shape[1:]), dtype=np.float32)
 
         class _Tok:
@@ -1422,9 +1434,20 @@ class _RegGenerator:
         if isinstance(task.preprocessing_layer, AlignFeatureLayer):   # (a frame the alignment accepts: the reference itself)
             _Tok.trajectory = np.zeros_like(tok) + np.random.RandomState(0).normal(size=tok.shape[1:]).astype(np.float32)
         g0, g1 = float(task.gamma[0]), float(task.gamma[1])
-        self.inner = EigenFunctionTask(_Tok, task.preprocessing_layer, model, task.model_path, g1 / g0, [float(v) for v in task._eig_w],
+        import tempfile
+        # (its own scratch log directory: a second SummaryWriter must not open event files in the user's model_path)
+        self._logdir = tempfile.mkdtemp(prefix="cvf_reg_generator_")
+        self.inner = EigenFunctionTask(_Tok, task.preprocessing_layer, model, self._logdir, g1 / g0, [float(v) for v in task._eig_w],
                                        diag_coeff=None, beta=beta, lag_tau=0, learning_rate=task.learning_rate, k=self.K,
                                        batch_size=task.batch_size, device=task.device, verbose=False, save_model_every_step=0)
+        try:   # nothing is ever logged or stepped through the inner task: close its writer, drop the directory
+            close = getattr(self.inner.writer, "close", None)
+            if close is not None:
+                close()
+            import shutil
+            shutil.rmtree(self._logdir, ignore_errors=True)
+        except Exception:
+            pass
         self.n = self.inner._flat.n
 
     def _params(self):

@@ -364,6 +364,22 @@ int cvf_comm_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
 int cvf_comm_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
 int cvf_comm_destroy(void* comm);
 
+/* --- the same two sums as a ONE-SHOT peer-to-peer reduce (csrc/p2p.hip): every rank writes its vector
+ * into a slot of every peer's window (fine-grained device memory shared through HIP IPC handles: one xGMI hop, all links at once),
+ * raises a flag there, waits for the `world` flags in its own window and adds the slots in RANK ORDER - every rank forms the same
+ * sum bit for bit, whatever the arrival order.  One process per GPU.  Unlike the rest of this header cvf_p2p_create allocates (the
+ * window, as a communicator does).  Sequence: every rank cvf_p2p_create -> exchange the cvf_p2p_handle_bytes()-byte handles by any
+ * means, rank-major -> cvf_p2p_connect -> cvf_p2p_allreduce_* on a stream (in place, SUM; n * sizeof <= max_bytes; capturable:
+ * the epoch lives on the device).  A peer whose flag does not arrive within 2 s does not hang the GPU: the kernel leaves `buf`
+ * unreduced and sets the communicator's error word, which cvf_p2p_error() returns (0 = none; it synchronises the device). */
+int cvf_p2p_handle_bytes(void);
+int cvf_p2p_create(void** comm, int rank, int world, int64_t max_bytes, void* handle_out_host);
+int cvf_p2p_connect(void* comm, const void* all_handles_host);
+int cvf_p2p_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
+int cvf_p2p_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
+int cvf_p2p_error(void* comm);
+int cvf_p2p_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif
