@@ -28,6 +28,11 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
                                                              float* __restrict__ e_tiled, double* __restrict__ partial, int ns,
                                                              const float* __restrict__ x_lag, int64_t units_x) {
   constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG, SMAX = 18, CTMAX = 5;
+  // NIT == 0: the TRANSFER-OPERATOR instance (cvf_ef16_front_transfer) - the block leaves after y and the hand-off of the hidden
+  // activations, and everything behind that point is compiled out: no g images in LDS (11 KB per block instead of 26) and fewer
+  // registers, so that the 2 x units of the frames and their lagged partners are resident in ONE round (the generator instance
+  // held them in two: 5 blocks per CU by registers and LDS)
+  constexpr bool kTransfer = NIT == 0;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nw = nthreads >> 6;
   // (the wave number through an SGPR: derived from threadIdx.x alone the compiler treats it - and every address formed
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
   if (lagged) x = x_lag;
   const int nc = pp.n_coord, nal = pp.n_align, N = pp.n_rec;
   const int stride = x_tile_stride(nc);
-  const Front16Lds Lo = front16_lds(nc, nal, k);
+  const Front16Lds Lo = front16_lds(nc, nal, k);   // (the transfer instance is launched with Lo.g bytes: no g images)
   float* xt = lds;
   float* refL = lds + Lo.ref;
   float* aL = lds + Lo.a;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
 #pragma unroll
       for (int j = 0; j < 3; ++j) Hm[i][j] = fma(-cd[i], acc[12 + j], acc[3 + 3 * i + j]);
     KabschOut ko;
-    if (x_lag != nullptr) {   // (uniform) transfer-operator mode: no derivative through the alignment, the rotation alone
+    if constexpr (kTransfer) {   // transfer-operator mode: no derivative through the alignment, the rotation alone
       kabsch_from_H<false>(Hm, ko);
 #pragma unroll
       for (int i = 0; i < 6; ++i) ko.Kinv[i] = 0.0f;
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     y_tiled[(tile * k + net) * CVF_TILE + kU * sub + col] = yv;
   }
   CVF_STAMP(25);
-  if (x_lag != nullptr) {   // transfer-operator mode: y, h_1..h_NH and the feature tile are all the backward pass needs
+  if constexpr (kTransfer) {   // transfer-operator mode: y, h_1..h_NH and the feature tile are all the backward pass needs
 #pragma unroll
     for (int l = 0; l < NH; ++l)
 #pragma unroll
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
 #pragma unroll 1
     for (int j = p + 4 * wave; j < D; j += 4 * nw) ft[j * CVF_TILE] = fi[j];
     return;
-  }
+  } else {
   // ---- d chain and g = W_1^T d_1 -> this wave's image [frame][feature]
   {
     // (requested behind the hand-off stores of h - vector-memory operations return in issue order - but the d chain below
@@ -523,6 +528,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     }
   }
   CVF_STAMP(30);
+  }   // (generator instance)
 }
 }  // namespace
 
@@ -632,11 +638,10 @@ extern "C" int cvf_ef16_front_transfer(const cvf_mlp_desc* mlp, const float* the
   const int k = mlp->n_nets;
   const int64_t T = cvf_ntiles(B), units = 4 * T;
   CVF_REQUIRE(2 * units < (int64_t)1 << 31, "cvf_ef16_front_transfer: batch too large for one launch");
-  const size_t lds = (size_t)front16_lds(pp->n_coord, pp->n_align, k).total * sizeof(float);
+  const size_t lds = (size_t)front16_lds(pp->n_coord, pp->n_align, k).g * sizeof(float);   // (up to the g images, which this instance lacks)
   ef16_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    // (the passes' template parameters do not matter here - the block leaves before them: one instance serves)
-    auto kernel = ef16_front_kernel<kH, kNH, 6, true>;
+    auto kernel = ef16_front_kernel<kH, kNH, 0, true>;   // NIT = 0: the transfer-operator instance
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, dim3((unsigned)(2 * units)), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, *pp, x, B,
                        (const float*)nullptr, (const float*)nullptr, feat_tiled, y_tiled, saved, (float*)nullptr, (float*)nullptr,
