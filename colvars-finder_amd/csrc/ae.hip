@@ -905,6 +905,33 @@ __global__ __launch_bounds__(256, 2) void ae16_kernel(cvf_mlp_desc mlp, const fl
       }
     }
     CVF_STAMP(25);
+    // ---- the first layer's gradient tiles need B = [f ; 1] from GLOBAL memory (k-slot kq of k-step (j, c) is frame 16 j + 4 kq + c
+    // of the tile): this wave's (at most kL0) tiles of that layer are known now, so their sixteen values per lane are requested
+    // here, in front of the barrier and of the other layers' tiles - in the layer-0 loop itself each tile waited a full round trip
+    constexpr int kL0 = 3;
+    int base0 = 0;   // tiles of the layers L-1 .. 1 (they come first in the list the waves share round-robin)
+    for (int l = L - 1; l >= 1; --l)
+      base0 += ((__builtin_amdgcn_readfirstlane(s_dims[l]) + 1 + 15) / 16) * ((__builtin_amdgcn_readfirstlane(s_dims[l + 1]) + 15) / 16);
+    const int nct0 = (d0 + 1 + 15) / 16, n0 = nct0 * ((__builtin_amdgcn_readfirstlane(s_dims[1]) + 15) / 16);
+    const int pr0 = (wv - (base0 & 3) + 4) & 3;   // this wave's first tile of layer 0; then every fourth
+    float bpre[kL0][16];
+    {
+      int64_t foff[16];
+#pragma unroll
+      for (int jc = 0; jc < 16; ++jc) {
+        const int64_t fb = tile * CVF_TILE + 16 * (jc >> 2) + 4 * kq + (jc & 3);
+        const int64_t fbc = fb < B ? fb : B - 1;
+        foff[jc] = (idx ? idx[fbc] : fbc) * d0;
+      }
+#pragma unroll
+      for (int t = 0; t < kL0; ++t) {
+        const int pr = pr0 + 4 * t < n0 ? pr0 + 4 * t : 0;
+        const int i = 16 * (pr % nct0) + col;
+        const int ic = i < d0 ? i : d0 - 1;
+#pragma unroll
+        for (int jc = 0; jc < 16; ++jc) bpre[t][jc] = feat_rows[foff[jc] + ic];
+      }
+    }
     __syncthreads();   // every zbar image and every activation image of all four waves is in place
     CVF_STAMP(26);
     // ---- weight gradients: layer l's = zbar_{l+1} (x) [a_l ; 1] over the 64 frames, 16x16 tiles of ALL layers dealt round-robin
@@ -936,25 +963,31 @@ __global__ __launch_bounds__(256, 2) void ae16_kernel(cvf_mlp_desc mlp, const fl
       base += nrt * nct;
     }
     CVF_STAMP(27);
-    {   // l = 0: B = [f ; 1] from global memory: k-slot kq of k-step (j, c) is frame 16 j + 4 kq + c of the tile
-      const int dout = __builtin_amdgcn_readfirstlane(s_dims[1]);
-      const int nct = (d0 + 1 + 15) / 16, nrt = (dout + 15) / 16;
+    {   // l = 0 (B operands requested above; tiles past kL0 per wave - first layers wider than 12 column tiles - load here)
       const float* Zimg = lds + __builtin_amdgcn_readfirstlane(s_zimg[1]);
-      int64_t foff[16];
-#pragma unroll
-      for (int jc = 0; jc < 16; ++jc) {
-        const int64_t fb = tile * CVF_TILE + 16 * (jc >> 2) + 4 * kq + (jc & 3);
-        const int64_t fbc = fb < B ? fb : B - 1;
-        foff[jc] = (idx ? idx[fbc] : fbc) * d0;
-      }
-      for (; next < base + nrt * nct; next += 4) {
-        const int pr = next - base, rt = pr / nct, ct = pr - rt * nct;
+      int t = 0;
+      for (int pr = pr0; pr < n0; pr += 4, ++t) {
+        const int rt = pr / nct0, ct = pr - rt * nct0;
         const int i = 16 * ct + col;
-        const int ic = i < d0 ? i : d0 - 1;
         const float pad = i == d0 ? 1.0f : 0.0f;
         float bvals[16];
+        if (t < kL0) {   // (uniform)
 #pragma unroll
-        for (int jc = 0; jc < 16; ++jc) bvals[jc] = feat_rows[foff[jc] + ic];
+          for (int jc = 0; jc < 16; ++jc) {
+            float v = bpre[0][jc];
+#pragma unroll
+            for (int u = 1; u < kL0; ++u) v = (t == u) ? bpre[u][jc] : v;
+            bvals[jc] = v;
+          }
+        } else {
+          const int ic = i < d0 ? i : d0 - 1;
+#pragma unroll
+          for (int jc = 0; jc < 16; ++jc) {
+            const int64_t fb = tile * CVF_TILE + 16 * (jc >> 2) + 4 * kq + (jc & 3);
+            const int64_t fbc = fb < B ? fb : B - 1;
+            bvals[jc] = feat_rows[(idx ? idx[fbc] : fbc) * d0 + ic];
+          }
+        }
         const float4* za = reinterpret_cast<const float4*>(Zimg + (16 * rt + col) * AP + 4 * kq);
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
