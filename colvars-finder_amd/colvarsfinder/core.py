@@ -1538,7 +1538,13 @@ class RegAutoEncoderTask(TrainingTask):
                 raise NotImplementedError("RegAutoEncoderTask on MI355X: gamma[0] must be positive when gamma[1] is")
             self._beta = beta
         self._use_enc = max(self.eta[1], self.eta[2]) > self._eps
-        assert _dist.world() == 1, "RegAutoEncoderTask runs in one process per model in this round"
+        # Data-parallel job (one process per GPU): the batch's frames are split over the ranks, the three kinds of batch sums
+        # (reconstruction error, latent statistics, regulariser heads) and the gradient are summed across them;
+        # the feature trajectory itself is small (d_r floats per frame) and stays whole on every rank.  The two parts that run on
+        # an inner EigenFunctionTask (generator-mode regulariser, gradient-norm penalty eta[0]) are single-process.
+        if _dist.world() > 1 and ((self._use_reg and self.lag_idx == 0) or self.eta[0] > self._eps):
+            raise NotImplementedError("RegAutoEncoderTask on MI355X, data-parallel: the generator-mode regulariser (lag_tau_reg = 0) and the "
+                                      "gradient-norm penalty eta[0] run in one process only; use lag_tau_reg > 0 / eta[0] = 0 or one GPU")
         self.init_model_and_optimizer()
         # --- data: the feature trajectory r(x) of every frame, once (the layer has no parameters), resident in HBM
         traj = _HostFrames(traj_obj.trajectory).all()
@@ -1625,12 +1631,14 @@ class RegAutoEncoderTask(TrainingTask):
             self._ws[B] = ws
         return ws
 
-    def _step(self, feat, idx, w, w_lag, lag_ae, lag_reg, with_grad, advance=False, wsum=None, out=None, X=None):
+    def _step(self, feat, idx, w, w_lag, lag_ae, lag_reg, with_grad, advance=False, wsum=None, out=None, X=None, dp=False):
         """Loss terms (and, with ``with_grad``, gradient + optimizer step) of one batch: rows ``idx`` of ``feat``
         (``None``: rows 0..B-1), targets at ``+lag_ae``, lagged partners at ``+lag_reg``.  ``wsum``: the batch's weight
         sum when the caller knows it (static batches), else one host read.  Returns (or fills ``out`` with) the device
         vector [loss, ae, npl, pen, eig_1..K, enc_grad, enc_norm, enc_orth] (fp64).  ``X``: the batch's raw coordinates for the
-        generator-mode regulariser (``None``: rows ``idx`` of the resident trajectory)."""
+        generator-mode regulariser (``None``: rows ``idx`` of the resident trajectory).  ``dp``: the batch is this rank's slice of a
+        global batch (``train()`` of a data-parallel job) - batch sums and gradient are summed across the ranks; the public loss
+        functions below evaluate the batch they are handed, on the calling rank alone."""
         lib, fl, P = _hip.lib(), self._flat, _hip.ptr
         B, K = int(w.shape[0]), self.num_reg
         ws = self._workspace(B)
@@ -1645,15 +1653,22 @@ class RegAutoEncoderTask(TrainingTask):
         self._call("cvf_regae_forward", lib.cvf_regae_forward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
                    lag_reg if use_reg else 0, K, P(w), P(ws["scratch"]), P(ws["y"]), self._n_enc_layers,
                    P(ws["enc"]) if use_enc else None, P(ws["out2"]), _hip.stream())
+        if dp:
+            self._allreduce("allreduce_batch_sums", ws["out2"])     # [sum w err, sum w, (ratio: recomputed by cvf_regae_loss_row)]
         if use_enc:   # core.py:912-971: weighted means / variances / covariances of the latent vector, then the two penalties
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._ecfg, B, P(w), P(ws["enc"]), P(ws["ezero"]), None, None,
                        P(ws["esscratch"]), P(ws["estats"]), None, None, _hip.stream())
+            if dp:
+                self._allreduce("allreduce_batch_sums", ws["estats"])
             self._call("cvf_regae_enc_loss", lib.cvf_regae_enc_loss, P(ws["estats"]), self.k, eta1, eta2, P(ws["eterms"]),
                        P(ws["ecoef"]), _hip.stream())
         if use_reg:
             y_lag = ws["y"][ws["T"] * K * 64:]
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws["y"]), None, P(w_lag), P(y_lag),
-                       P(ws["sscratch"]), P(ws["stats"]), P(ws["loss_vec"]), P(ws["coef"]), _hip.stream())
+                       P(ws["sscratch"]), P(ws["stats"]), None if dp else P(ws["loss_vec"]), None if dp else P(ws["coef"]), _hip.stream())
+            if dp:
+                self._allreduce("allreduce_batch_sums", ws["stats"])
+                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws["stats"]), P(ws["loss_vec"]), P(ws["coef"]), _hip.stream())
             self._cvec_dev = ws["loss_vec"][3 + K:3 + 2 * K]
         if out is None:
             out = torch.zeros(7 + K, device=self.device, dtype=torch.float64)
@@ -1666,14 +1681,19 @@ class RegAutoEncoderTask(TrainingTask):
             rows = feat[:B] if idx is None else feat.index_select(0, idx)
         if with_grad:
             if wsum is None:
-                wsum = float(w.sum(dtype=torch.float64))
-            adam = self.optimizer.fused_args() if advance and eg is None and gen is None else None   # (their gradients are added before the update)
+                wsum_t = w.sum(dtype=torch.float64)
+                if dp:
+                    _dist.allreduce_sum_(wsum_t)
+                wsum = float(wsum_t)
+            adam = self.optimizer.fused_args() if advance and eg is None and gen is None and not dp else None   # (their gradients are added before the update)
             self._call("cvf_regae_backward", lib.cvf_regae_backward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
                        lag_reg if use_reg else 0, K, P(w), P(w_lag) if use_reg else None, alpha / wsum,
                        float(self.gamma[0]) if use_reg else 0.0, P(ws["y"]) if use_reg else None,
                        P(ws["coef"]) if use_reg else None, self._n_enc_layers, P(ws["ecoef"]) if use_enc else None,
                        P(ws["scratch"]), P(fl.grad), P(fl.mask),
                        P(self.optimizer.step_count) if advance else None, adam, _hip.stream())
+            if dp:
+                self._allreduce("allreduce_gradient", fl.grad)
         if gen is not None:
             lv = gen.forward(X if X is not None else (self._traj[:B] if idx is None else self._traj.index_select(0, idx)), w, with_grad)
             out[2:4] = lv[1:3]
@@ -1759,21 +1779,36 @@ class RegAutoEncoderTask(TrainingTask):
         ll = n - max(self.lag_idx, self.lag_ae_idx)                      # core.py:1042
         idx_train, idx_test = _split(ll, self.test_ratio)                # core.py:1044 (one draw)
         bs_train, bs_test = min(self.batch_size, len(idx_train)), min(self.batch_size, len(idx_test))
+        world, rank = _dist.world(), _dist.rank()
+        if world > 1:   # rank 0's permutation for everyone, then this rank's contiguous slice of every static batch (_dist.shard_batches)
+            both = torch.as_tensor(np.concatenate([idx_train, idx_test]), device=self.device)
+            _dist.broadcast_(both)
+            both = both.cpu().numpy()
+            idx_train, idx_test = both[:len(idx_train)], both[len(idx_train):]
+            assert min(bs_train, bs_test) >= world or min(len(idx_train), len(idx_test)) == 0, "batch size smaller than the number of ranks"
+            (ptr, nb_tr), (pte, nb_te) = _dist.shard_batches(len(idx_train), bs_train, rank, world), _dist.shard_batches(len(idx_test), bs_test, rank, world)
+            idx_train, idx_test = np.asarray(idx_train)[ptr], np.asarray(idx_test)[pte]
+        else:
+            nb_tr, nb_te = bs_train, bs_test
         itr = torch.as_tensor(idx_train, device=self.device, dtype=torch.long)
         ite = torch.as_tensor(idx_test, device=self.device, dtype=torch.long)
         wtr, wte = self._weights[itr].contiguous(), self._weights[ite].contiguous()
         wtr_lag, wte_lag = self._weights[itr + self.lag_idx].contiguous(), self._weights[ite + self.lag_idx].contiguous()
-        tr_batches = [(s, s + bs_train) for s in range(0, len(idx_train) - bs_train + 1, bs_train)] if bs_train > 0 else []
-        te_batches = [(s, s + bs_test) for s in range(0, len(idx_test) - bs_test + 1, bs_test)] if bs_test > 0 else []
-        # batches are static (shuffle=False): their weight sums are known before the first step
-        wsum_tr = [float(wtr[a:b].sum(dtype=torch.float64)) for a, b in tr_batches]
+        tr_batches = [(s, s + nb_tr) for s in range(0, len(idx_train) - nb_tr + 1, nb_tr)] if nb_tr > 0 else []
+        te_batches = [(s, s + nb_te) for s in range(0, len(idx_test) - nb_te + 1, nb_te)] if nb_te > 0 else []
+        # batches are static (shuffle=False): their (global) weight sums are known before the first step
+        wsum_t = torch.stack([wtr[a:b].sum(dtype=torch.float64) for a, b in tr_batches]) if tr_batches else torch.zeros(0, device=self.device, dtype=torch.float64)
+        if world > 1 and len(tr_batches):
+            _dist.allreduce_sum_(wsum_t)
+        wsum_tr = [float(v) for v in wsum_t.cpu()]
         self.loss_list = []
         min_loss = float("inf")
-        print("\nTraining starts.\n%d epochs in total, batch sizes (train/test): %d/%d" % (self.num_epochs, bs_train, bs_test))
-        print("\nTrain set:\n\t%d data, %d iterations per epoch, %d iterations in total." %
-              (len(idx_train), len(tr_batches), len(tr_batches) * self.num_epochs), flush=True)
-        print("Test set:\n\t%d data, %d iterations per epoch, %d iterations in total." %
-              (len(idx_test), len(te_batches), len(te_batches) * self.num_epochs), flush=True)
+        if rank == 0:
+            print("\nTraining starts.\n%d epochs in total, batch sizes (train/test): %d/%d" % (self.num_epochs, bs_train, bs_test))
+            print("\nTrain set:\n\t%d data, %d iterations per epoch, %d iterations in total." %
+                  (len(idx_train) * world, len(tr_batches), len(tr_batches) * self.num_epochs), flush=True)
+            print("Test set:\n\t%d data, %d iterations per epoch, %d iterations in total." %
+                  (len(idx_test) * world, len(te_batches), len(te_batches) * self.num_epochs), flush=True)
         K = self.num_reg
         loss_names = ['loss', 'ae_loss', 'eigen_non_penalty', 'eigen_penalty'] + ['eig_%d' % i for i in range(K)] + \
                      ['encoder_gradient', 'encoder_norm', 'encoder_orthogonality']
@@ -1795,11 +1830,12 @@ class RegAutoEncoderTask(TrainingTask):
                 self.writer.add_scalar('%s/test' % name, mean_te[i], ep)
 
         elog = _AsyncEpochLog(log_tr, log_te, len(tr_batches), len(te_batches), on_epoch)
-        for epoch in _tqdm(range(self.num_epochs)):
+        dp = _dist.collectives()
+        for epoch in _tqdm(range(self.num_epochs), disable=(rank != 0)):
             self.model.train()
             for it, (a, b) in enumerate(tr_batches):
                 self._step(self._feature_traj, itr[a:b], wtr[a:b], wtr_lag[a:b], self.lag_ae_idx, self.lag_idx, with_grad=True,
-                           advance=True, wsum=wsum_tr[it], out=log_tr[it])
+                           advance=True, wsum=wsum_tr[it], out=log_tr[it], dp=dp)
             saving = self.save_model_every_step > 0 and epoch % self.save_model_every_step == self.save_model_every_step - 1
             plotting = self.plot_frequency > 0 and epoch % self.plot_frequency == self.plot_frequency - 1
             if saving or plotting:                       # (order of the reference: save / plot before the test pass, core.py:1130-1140)
@@ -1812,11 +1848,11 @@ class RegAutoEncoderTask(TrainingTask):
                     min_loss = last
                     self.save_model(epoch, 'best')
             if plotting:
-                if self.plot_class is not None:
+                if self.plot_class is not None and rank == 0:
                     self.plot_class.plot(self.colvar_model(), self.reg_model(), epoch=epoch)
             for it, (a, b) in enumerate(te_batches):
                 self._step(self._feature_traj, ite[a:b], wte[a:b], wte_lag[a:b], self.lag_ae_idx, self.lag_idx, with_grad=False,
-                           out=log_te[it])
+                           out=log_te[it], dp=dp)
             elog.reserve(epoch)
             if self._use_reg and (tr_batches or te_batches):
                 cvec_log[epoch % len(cvec_log)].copy_(self._cvec_dev, non_blocking=True)

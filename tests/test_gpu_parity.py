@@ -697,7 +697,8 @@ def test_generator_step_ragged_batches_vs_oracle(dev, B, k):
 def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(dev):
     """SURVEY 8e on the real kernels: the same training as one process and as two ranks (gloo group, both on cuda:0) - sharded
     batches, all-reduce of the sums before the backward pass, all-reduce of the gradient, identical Adam.  tools/check_dp2.py
-    runs generator mode, transfer mode and the autoencoder and compares every step's loss and the final parameters."""
+    runs generator mode, transfer mode, the autoencoder and the regularised autoencoder (reconstruction + transfer-operator
+    regulariser + latent penalties: three kinds of batch sums reduced) and compares every step's loss and the final parameters."""
     import json
     import subprocess
     import sys
@@ -709,7 +710,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(dev):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     rep = json.loads(res.stdout.strip().splitlines()[-1])
     assert rep["ok"], rep
-    for kind in ("gen", "tr", "ae", "gen_mm", "ae_mm"):
+    for kind in ("gen", "tr", "ae", "gen_mm", "ae_mm", "regae"):
         assert rep[kind]["max_rel_loss_diff"] < 2e-4, rep
     # with the trajectory behind a memory-mapped file (utils.MappedTrajectory) a rank also READS only its
     # own half of the frames on the host; the single process reads the file once

@@ -45,6 +45,11 @@ def run(kind, out_path):
         task = core.EigenFunctionTask(traj_obj, layer, model, "/tmp/cvf_dp2", 20.0, [1.0, 0.7, 0.4], diag_coeff=a, beta=1.0,
                                       lag_tau=0 if kind == "gen" else 1.0, learning_rate=2e-3, k=3, batch_size=1000, num_epochs=2,
                                       device=dev, verbose=False, save_model_every_step=0)
+    elif kind == "regae":   # reconstruction + transfer-operator regulariser + latent penalties; the feature trajectory stays whole per rank
+        model = nn.RegAutoEncoder([66, 20, 2], [2, 20, 66], [2, 20, 1], 2)
+        task = core.RegAutoEncoderTask(traj_obj, layer, model, "/tmp/cvf_dp2", eig_weights=[1.0, 0.6], learning_rate=2e-3,
+                                       batch_size=1000, num_epochs=2, alpha=1.0, gamma=[0.3, 0.2], eta=[0.0, 0.1, 0.1], lag_tau_ae=0.5,
+                                       lag_tau_reg=1.0, device=dev, verbose=False, save_model_every_step=0)
     else:
         model = nn.AutoEncoder([66, 20, 20, 2], [2, 10, 66])
         task = core.AutoEncoderTask(traj_obj, layer, model, "/tmp/cvf_dp2", learning_rate=2e-3, batch_size=1000, num_epochs=2,
@@ -55,12 +60,13 @@ def run(kind, out_path):
         losses = np.concatenate([np.asarray(e[0]).reshape(len(e[0]), -1) for e in task.loss_list])
         # (an eigenfunction's last bias has exact gradient 0 - the loss is shift-invariant - and random-walks on roundoff
         #  under Adam in any run: left out of the comparison, as in tests/test_gpu_parity.py)
-        skip = ".4.bias" if kind in ("gen", "tr") else "\0"
-        params = np.concatenate([p.detach().cpu().numpy().reshape(-1) for n, p in model.named_parameters() if not n.endswith(skip)])
+        skip = (lambda n: n.endswith(".4.bias")) if kind in ("gen", "tr") else \
+               (lambda n: n.startswith("reg.") and n.endswith(".2.bias")) if kind == "regae" else (lambda n: False)
+        params = np.concatenate([p.detach().cpu().numpy().reshape(-1) for n, p in model.named_parameters() if not skip(n)])
         np.savez(out_path, losses=losses, params=params)
     # frames this process keeps in HBM (the trajectory / feature rows and train()'s gathers), for the 1/world check
     with open(out_path.replace(".npz", f"_r{_dist.rank()}.json"), "w") as fh:
-        json.dump(dict(resident_bytes=int(task.resident_bytes), world=_dist.world(), frames=5000, n_atoms=n_atoms,
+        json.dump(dict(resident_bytes=int(getattr(task, "resident_bytes", 0)), world=_dist.world(), frames=5000, n_atoms=n_atoms,
                        host_bytes_read=int(traj_obj.trajectory.bytes_read) if mapped else None), fh)
     if mapped:
         os.remove(path)
@@ -75,7 +81,7 @@ def main():
         return run(sys.argv[2], sys.argv[3])
     report = {}
     ok = True
-    for kind in ("gen", "tr", "ae", "gen_mm", "ae_mm"):
+    for kind in ("gen", "tr", "ae", "gen_mm", "ae_mm", "regae"):
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
         env["CVF_GRAPH"] = "0"      # eager in both runs: the comparison is about the data-parallel arithmetic
         subprocess.run([sys.executable, __file__, "worker", kind, f"/tmp/dp2_{kind}_w1.npz"], check=True, env=env, timeout=300)
@@ -96,7 +102,7 @@ def main():
         # shard residency: a rank of the two-rank job holds about half of the frames the job touches - its slices
         # of the static batches (+ their lagged partners in transfer mode) - never the whole trajectory
         res = [json.load(open(f"/tmp/dp2_{kind}_w2_r{r}.json"))["resident_bytes"] for r in range(2)]
-        per_frame = {"gen": 22 * 12 + 4, "tr": 2 * (22 * 12 + 4), "ae": 66 * 4}[kind.replace("_mm", "")]
+        per_frame = {"gen": 22 * 12 + 4, "tr": 2 * (22 * 12 + 4), "ae": 66 * 4, "regae": 0}[kind.replace("_mm", "")]
         whole = 5000 * per_frame
         report[kind] = dict(steps=int(a["losses"].shape[0]), max_rel_loss_diff=dl, max_abs_param_diff=dp,
                             resident_bytes_per_rank=res, whole_set_bytes=whole)
