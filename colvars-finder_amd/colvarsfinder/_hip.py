@@ -37,7 +37,8 @@ class PPDesc(C.Structure):
                 ("d_r", C.c_int32), ("use_angle_value", C.c_int32), ("has_position", C.c_int32), ("flags", C.c_int32),
                 ("align_idx", C.c_void_p), ("ref_c", C.c_void_p), ("rec", C.c_void_p),
                 ("atom_align", C.c_void_p), ("atom_slot", C.c_void_p), ("rec_slot", C.c_void_p), ("slot_atom", C.c_void_p), ("n_slot", C.c_int32),
-                ("n_rec_slot", C.c_int32), ("align_w", C.c_void_p)]
+                ("n_rec_slot", C.c_int32), ("align_w", C.c_void_p), ("mrec", C.c_void_p), ("slot_row", C.c_void_p),
+                ("n_mrec", C.c_int32), ("n_ref", C.c_int32)]
 
 
 class MLPDesc(C.Structure):
@@ -70,6 +71,7 @@ _SIGNATURES = {
     "cvf_metric_apply_stats": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(EFCfg), C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_metric_dense_doubles": (C.c_int64, [C.POINTER(PPDesc)]),
     "cvf_metric_dense_tensors": (C.c_int, [C.POINTER(PPDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_pack_floats": (C.c_int64, [C.POINTER(MLPDesc)]),
     "cvf_ef_pack": (C.c_int, [C.POINTER(MLPDesc), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -604,7 +604,7 @@ class EigenFunctionTask(TrainingTask):
         # large molecules (streaming alignment path): moments of (diag_coeff, reference) used by the derivative kernel
         self._dense = None
         if self.lag_idx == 0 and _hip.lib().cvf_align_feature_scratch_bytes(self._pp, 64) > 0:
-            self._dense = torch.zeros(42, device=self.device, dtype=torch.float64)
+            self._dense = torch.zeros(_hip.lib().cvf_metric_dense_doubles(self._pp), device=self.device, dtype=torch.float64)
             _hip.check(_hip.lib().cvf_metric_dense_tensors(self._pp, _hip.ptr(self._diag_coeff), _hip.ptr(self._dense),
                                                            _hip.stream()), "cvf_metric_dense_tensors")
         self._ws = {}

@@ -151,6 +151,27 @@ class AlignFeatureLayer(torch.nn.Module):
                 self._flags |= _hip.PP_SLOT_DISJOINT
         self._n_rec_slot = len(rec_slot)
         self._n_slot = len(used)
+        # the derivative kernel of large molecules (csrc/metric_large.hip) scatters J^T g through a table of rows: one row per
+        # (record, atom position) pair, the rows of one slot contiguous (include/cvf.h: mrec, slot_row)
+        natoms = {_hip.FEAT_POSITION: 1, _hip.FEAT_BOND: 2, _hip.FEAT_ANGLE: 3, _hip.FEAT_DIHEDRAL: 4}
+        pairs = sorted((r[1 + j], i, j) for i, r in enumerate(by_type) for j in range(natoms[r[0]]))   # (slot, record, position)
+        row_of = {(i, j): n for n, (_, i, j) in enumerate(pairs)}
+        slot_row = np.zeros(len(used) + 1, dtype=np.int32)
+        for t, _, _ in pairs:
+            slot_row[t + 1] += 1
+        slot_row = np.cumsum(slot_row).astype(np.int32)
+        mrec = []
+        for i, r in enumerate(by_type):
+            na = natoms[r[0]]
+            rows = [row_of[(i, j)] for j in range(na)] + [0] * (4 - na)
+            ur = [int(slot_row[r[1 + j]]) for j in range(na)] + [0] * (4 - na)
+            sl = list(r[1:5])
+            mrec.append([(r[0] + 1) | (r[5] << 3), sl[0] | (sl[1] << 16), sl[2] | (sl[3] << 16), rows[0] | (rows[1] << 16),
+                         rows[2] | (rows[3] << 16), ur[0] | (ur[1] << 16), ur[2] | (ur[3] << 16), 0])
+        self._n_ref = len(pairs)
+        self.register_buffer("mrec", torch.tensor(np.asarray(mrec, dtype=np.int64).astype(np.uint32).view(np.int32)
+                                                  if mrec else np.zeros((0, 8), np.int32)).reshape(-1, 8))
+        self.register_buffer("slot_row", torch.tensor(slot_row, dtype=torch.int32))
         self.register_buffer("atom_align", torch.tensor(atom_align))
         self.register_buffer("atom_slot", torch.tensor(atom_slot))
         self.register_buffer("rec_slot", torch.tensor(rec_slot, dtype=torch.int32).reshape(-1, 6))
@@ -176,6 +197,8 @@ class AlignFeatureLayer(torch.nn.Module):
         d.atom_align, d.atom_slot, d.rec_slot = self.atom_align.data_ptr(), self.atom_slot.data_ptr(), self.rec_slot.data_ptr()
         d.slot_atom, d.n_slot, d.n_rec_slot = self.slot_atom.data_ptr(), self._n_slot, self._n_rec_slot
         d.align_w = self.align_w.data_ptr() if self.align_w is not None else None
+        if self._n_ref < 65536 and self._n_slot < 65536:
+            d.mrec, d.slot_row, d.n_mrec, d.n_ref = self.mrec.data_ptr(), self.slot_row.data_ptr(), self.mrec.shape[0], self._n_ref
         return d
 
     def forward(self, x):

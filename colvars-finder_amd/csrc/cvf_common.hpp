@@ -125,7 +125,7 @@ __device__ __forceinline__ float cvf_act_d1(int kind, float h) {
 static __device__ unsigned long long g_stamps[64 * 4096];
 #define CVF_STAMP(i)                                                                              \
   do {                                                                                            \
-    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 4096 && (threadIdx.x >> 6) < CVF_STAMP_WPB)   \
+    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4096 && (threadIdx.x >> 6) < CVF_STAMP_WPB)   \
       g_stamps[(blockIdx.x * CVF_STAMP_WPB + (threadIdx.x >> 6)) % 4096 * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else

@@ -40,6 +40,13 @@ __device__ __forceinline__ void save_vec(float* __restrict__ base, const Vec<H, 
     for (int w = 0; w < 2; ++w)
       reinterpret_cast<float2*>(base + (g * 2 + w) * 128)[lane] = float2{X.v[g >> 2][2 * w][g & 3], X.v[g >> 2][2 * w + 1][g & 3]};
 }
+// one half (frame groups 2 w, 2 w + 1) of the same layout, written by a forward block that owns half a tile
+template <int H>
+__device__ __forceinline__ void save_vec_half(float* __restrict__ base, const Vec<H, 2>& X, int w, int lane) {
+#pragma unroll
+  for (int g = 0; g < Hid<H>::NG; ++g)
+    reinterpret_cast<float2*>(base + (g * 2 + w) * 128)[lane] = float2{X.v[g >> 2][0][g & 3], X.v[g >> 2][1][g & 3]};
+}
 template <int H>
 __device__ __forceinline__ void load_vec(const float* __restrict__ base, Vec<H, 2>& X, int w, int lane) {
 #pragma unroll
@@ -190,6 +197,28 @@ __device__ __forceinline__ void layer0_apply(Vec<H, FT>& X, const float* __restr
   }
 }
 
+// Wide first layers (hundreds of features; the large-molecule shapes): NB chunks in flight instead of two.  With two, every
+// chunk of CH k-steps waited a full memory round trip (its operands were requested one chunk - ~100 cycles of MFMAs - ahead):
+// 16 chunks x 2.8 k cycles = 45 k of the forward kernel's 79 k at d0 = 384.  The ring is straight-line code per round, so the
+// compiler still counts outstanding loads exactly - as long as they fit the counter: a wave has at most 63 vector loads in
+// flight (vmcnt), i.e. NB x CH x (RT + 1) <= 63 (with eight chunks of six the waits degenerated and the product took 76 k).
+template <int H, int FT, int CH, int NB>
+__device__ __forceinline__ void layer0_apply_deep(Vec<H, FT>& X, const float* __restrict__ pk0, int D,
+                                                  const float* __restrict__ in_lane, int lane) {
+  const int S = (D + 3) >> 2;
+  L0Chunk<H, FT, CH> c[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) load_l0chunk<H, FT, CH>(c[b], pk0, D, S, in_lane, b * CH, lane);
+  for (int s0 = 0; s0 < S; s0 += NB * CH) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      mul_l0chunk<H, FT, CH>(X, c[b]);
+      load_l0chunk<H, FT, CH>(c[b], pk0, D, S, in_lane, s0 + (NB + b) * CH, lane);   // (past S: clamped loads, zeroed operands)
+    }
+  }
+}
+constexpr int kWideD = 128;   // first layers wider than this take the deep ring (and the hand-offs of the wide backward, ef_mfma.hip)
+
 // the same with the first chunk's operands already requested by the caller (ahead of other work)
 template <int H, int FT, int CH>
 __device__ __forceinline__ void layer0_apply_from(Vec<H, FT>& X, const float* __restrict__ pk0, int D,
@@ -306,7 +335,8 @@ __device__ __forceinline__ void chain_forward(const cvf_mlp_desc& mlp, const flo
   for (int l = 1; l < NH; ++l) load_hfrag<H>(hf[l - 1], pk + L.fh(l), lane);
   CVF_STAMP(1);
   set_const<H, FT>(h[0], bias[0]);
-  layer0_apply<H, FT>(h[0], pk + L.f0(), mlp.dims[0], in_lane, lane);
+  if (mlp.dims[0] > kWideD) layer0_apply_deep<H, FT, 6, 3>(h[0], pk + L.f0(), mlp.dims[0], in_lane, lane);
+  else layer0_apply<H, FT>(h[0], pk + L.f0(), mlp.dims[0], in_lane, lane);
   CVF_STAMP(2);
   tanh_inplace<H, FT>(h[0], mlp.act[0]);
   CVF_STAMP(3);

@@ -35,7 +35,7 @@ template <int H, int NH, int FT>
 __global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                           const float* __restrict__ packed,
                                                           const float* __restrict__ feat, float* __restrict__ y_tiled,
-                                                          float* __restrict__ g_tiled) {
+                                                          float* __restrict__ g_tiled, float* __restrict__ saved) {
   constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG;
   constexpr int SUB = 4 / FT;  // blocks per 64-frame tile
   const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
@@ -52,6 +52,14 @@ __global__ __launch_bounds__(64) void ef_fwd_mfma_kernel(cvf_mlp_desc mlp, const
   Vec<H, FT> h[NH];
   chain_forward<H, NH, FT>(mlp, theta, pk, L, net, in_lane, lane, h);
   CVF_STAMP(4);
+  if (saved != nullptr) {   // hidden activations for the backward kernel (the layout of ef_fwd_wg_kernel's hand-off)
+    float* sv = saved + (tile * k + net) * (int64_t)(NH * saved_per_vec<H>());
+#pragma unroll
+    for (int l = 0; l < NH; ++l) {
+      if constexpr (FT == 4) save_vec<H>(sv + l * saved_per_vec<H>(), h[l], lane);
+      else save_vec_half<H>(sv + l * saved_per_vec<H>(), h[l], ft0 / 2, lane);
+    }
+  }
 
   float wl[RT][4];
   load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
@@ -787,6 +795,27 @@ __global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const 
   }
 }
 
+// Wide first layers, generator mode: the tangent chain's first product t0 = W0 q (K = d0) for one (half tile, net), ahead of
+// the backward kernel - there it was a just-in-time double-buffered loop (40 k cycles at d0 = 384: every chunk of three
+// k-steps waited a memory round trip, and the kernel has no registers left for a deeper ring), repeated by every block that
+// shares the (tile, net).  Output: one vector in the hand-off layout, behind the activations (see cvf_ef_saved_floats).
+template <int H>
+__global__ __launch_bounds__(64) void ef_t0_kernel(cvf_mlp_desc mlp, const float* __restrict__ packed,
+                                                    const float* __restrict__ q_tiled, float* __restrict__ t0_out) {
+  constexpr int FT = 2;
+  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
+  const int64_t tile = blockIdx.x / 2;
+  const int w = blockIdx.x % 2, net = blockIdx.y;
+  const int k = mlp.n_nets, D = mlp.dims[0];
+  const PackLayout L = pack_layout(H, mlp.n_layers - 1, D);
+  const float* pk = packed + (int64_t)net * L.per_net;
+  const float* in_lane = q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + 4 * col + 2 * w;
+  Vec<H, FT> t;
+  init_bias<H, FT>(t, nullptr, q);
+  layer0_apply_deep<H, FT, 6, 3>(t, pk + L.f0(), D, in_lane, lane);
+  save_vec_half<H>(t0_out + (tile * k + net) * (int64_t)saved_per_vec<H>(), t, w, lane);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4b
 // ------------------------------------------------------------------------------------------------
@@ -796,6 +825,8 @@ struct EfBwdArgs {
   int64_t B;
   int64_t T;
   int64_t n_tiles;
+  int zs;             // blocks that share a (tile, net): block z takes the first layer's column tiles ct = z (mod zs)
+  const float* t0;    // wide first layers: t0 = W0 q of every (tile, net), computed by ef_t0_kernel (else NULL)
 };
 
 // K4b.  Block = WPB waves sharing one 64-frame tile (and its LDS images); wave w owns the frames
@@ -834,6 +865,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
   const int col = lane & 15, q = lane >> 4, row16 = col, r0 = 4 * q;
   const int ft0 = wave * FT, fo = WPB == 4 ? 16 * wave + col : 4 * col + ft0;   // first frame (of the tile) this lane owns
   const int net = blockIdx.y;
+  const int z = blockIdx.z, zs = args.zs;   // (zs > 1: wide first layers - this block adds only ITS column tiles of layer 0, block 0 everything else)
   const int k = args.k;
   const int D = mlp.dims[0];
   const int CT1 = (D + 1 + 15) / 16;
@@ -961,7 +993,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
       // the tangent chain's first operands (weights, q rows) are requested before the d chain runs: one memory round trip
       // of this wave's dependent chain overlaps that chain's matrix instructions (18.3 k -> 17.0 k cycles for this phase)
       L0Chunk<H, FT, 3> tc0;
-      if (SAVED == 1) load_l0chunk<H, FT, 3>(tc0, pk + L.f0(), D, (D + 3) >> 2, q_tile + fo, 0, lane);
+      const bool have_t0 = FT == 2 && args.t0 != nullptr;   // t0 = W0 q already computed (ef_t0_kernel)
+      if (SAVED == 1 && !have_t0) load_l0chunk<H, FT, 3>(tc0, pk + L.f0(), D, (D + 3) >> 2, q_tile + fo, 0, lane);
       {
         Vec<H, FT> d;
 #pragma unroll
@@ -984,7 +1017,11 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
       init_bias<H, FT>(t[0], nullptr, q);
       // (batches of 4 / 6 / 9 k-steps: 20.1 / 20.6 / 22.0 k cycles for this phase against 18.3 k - spills; requesting the
       //  first layer's first column tile of B operands at the end of the layer-1 step: 73.7 k vs 69.0 k cycles in all - spills)
-      if (SAVED == 1) layer0_apply_from<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane, tc0);
+      if constexpr (FT == 2) {
+        if (have_t0) load_vec<H>(args.t0 + (tile * k + net) * (int64_t)saved_per_vec<H>(), t[0], wave, lane);
+      }
+      if (have_t0) {
+      } else if (SAVED == 1) layer0_apply_from<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane, tc0);
       else layer0_apply<H, FT, 3>(t[0], pk + L.f0(), D, q_tile + fo, lane);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -1005,21 +1042,23 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
     CVF_STAMP(11);
     // ---- last layer (1 x H):  W_L += sum alpha h_{NH-1} + tdot_{NH-1} ; b_L += sum alpha
     {
-      if (q == 0) {
+      if (z == 0) {
+        if (q == 0) {
 #pragma unroll
-        for (int ft = 0; ft < FT; ++ft) {
-          SA1[fo + ft] = alpha[ft];
-          if (tangent) SA2[fo + ft] = 1.0f;
+          for (int ft = 0; ft < FT; ++ft) {
+            SA1[fo + ft] = alpha[ft];
+            if (tangent) SA2[fo + ft] = 1.0f;
+          }
+        }
+        store_image<H, FT, false>(SB1, h[NH - 1], one, lane, fo);
+        if (tangent) {
+          Vec<H, FT> td;
+          tangent_of<H, FT>(td, h[NH - 1], t[NH - 1], mlp.act[0]);
+          store_image<H, FT, false>(SB2, td, one, lane, fo);
         }
       }
-      store_image<H, FT, false>(SB1, h[NH - 1], one, lane, fo);
-      if (tangent) {
-        Vec<H, FT> td;
-        tangent_of<H, FT>(td, h[NH - 1], t[NH - 1], mlp.act[0]);
-        store_image<H, FT, false>(SB2, td, one, lane, fo);
-      }
       __syncthreads();
-      for (int ct = wave; ct < CTH; ct += WPB) {
+      for (int ct = wave; ct < CTH && z == 0; ct += WPB) {
         const f32x4 acc = outer_tile(SA1, SB1, SA2, SB2, 0, ct, tangent, lane);
         if (q == 0) {  // output row 0 lives in register 0 of lanes 0..15
           const int wo = mlp.w_off[net][NH] - gbase, bo = mlp.b_off[net][NH] - gbase;
@@ -1072,20 +1111,24 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
               zbar.v[rt][ft][r] = zb;
             }
           }
-      store_image<H, FT, false>(SA1, zbar, one, lane, fo);
-      if (tangent) {
-        if (l == 0) store_image<H, FT, true>(SA2, dl, gamma, lane, fo);
-        else store_image<H, FT, false>(SA2, dl, one, lane, fo);
+      if (l == 0 || z == 0) {
+        store_image<H, FT, false>(SA1, zbar, one, lane, fo);
+        if (tangent) {
+          if (l == 0) store_image<H, FT, true>(SA2, dl, gamma, lane, fo);
+          else store_image<H, FT, false>(SA2, dl, one, lane, fo);
+        }
       }
       if (l > 0) {
-        store_image<H, FT, false>(SB1, h[l - 1], one, lane, fo);
-        if (tangent) {
-          Vec<H, FT> td;
-          tangent_of<H, FT>(td, h[l - 1], t[l - 1], mlp.act[0]);
-          store_image<H, FT, false>(SB2, td, one, lane, fo);
+        if (z == 0) {
+          store_image<H, FT, false>(SB1, h[l - 1], one, lane, fo);
+          if (tangent) {
+            Vec<H, FT> td;
+            tangent_of<H, FT>(td, h[l - 1], t[l - 1], mlp.act[0]);
+            store_image<H, FT, false>(SB2, td, one, lane, fo);
+          }
         }
         __syncthreads();
-        for (int pr = wave; pr < RTO * CTH; pr += WPB) {
+        for (int pr = wave; pr < RTO * CTH && z == 0; pr += WPB) {
           const int rt = pr / CTH, ct = pr - rt * CTH;
           add_tile(l, H, H, rt, ct, outer_tile(SA1, SB1, SA2, SB2, rt, ct, tangent, lane));
         }
@@ -1171,10 +1214,11 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
           for (int rt = 0; rt < RTO; ++rt)
             if (rt >= rt0 && (rt - rt0) % rstep == 0) add_tile(0, H, D, rt, ct, acc[rt]);
         };
-        if constexpr (WPB == 2) {
-          const int nfull = CT1 & ~1;
-          for (int ct = wave; ct < nfull; ct += WPB) outer0(ct, 0, 1);
-          if (CT1 & 1) outer0(CT1 - 1, wave, WPB);
+        if constexpr (WPB == 2) {   // this block's column tiles z, z + zs, ...: whole ones dealt to the waves, an odd last one split by row tile
+          const int nz = z < CT1 ? (CT1 - z + zs - 1) / zs : 0;
+          const int nfull = nz & ~1;
+          for (int j = wave; j < nfull; j += WPB) outer0(z + j * zs, 0, 1);
+          if (nz & 1) outer0(z + (nz - 1) * zs, wave, WPB);
         } else {   // four waves: the (column tile, row tile) pairs dealt round-robin
           for (int pr = wave; pr < RTO * CT1; pr += WPB) outer0(pr / RTO, pr % RTO, RTO);
         }
@@ -1187,16 +1231,32 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
   // ---- flush this block's partial gradient of `net` into its slab row
   __syncthreads();
   float* out = slab + (int64_t)blockIdx.x * mlp.n_params + gbase;
-  for (int i = tid; i < gspan; i += NT) out[i] = GI[i];
+  if (zs == 1) {
+    for (int i = tid; i < gspan; i += NT) out[i] = GI[i];
+  } else {   // the zs blocks of this (row, net) write disjoint parts of the row: layer-0 columns by column tile, the rest block 0
+    const int w0 = mlp.w_off[net][0] - gbase, b0 = mlp.b_off[net][0] - gbase;
+    for (int ct = z; ct < CT1; ct += zs)
+      for (int e = tid; e < 16 * H; e += NT) {
+        const int o = e >> 4, i = 16 * ct + (e & 15);
+        if (i < D) out[w0 + o * D + i] = GI[w0 + o * D + i];
+        else if (i == D) out[b0 + o] = GI[b0 + o];
+      }
+    if (z == 0)   // (a net's parameters are W0, b0, W1, ... in this order: everything behind b0)
+      for (int i = b0 + H + tid; i < gspan; i += NT) out[i] = GI[i];
+  }
   // one gradient per optimiser step: advance the step counter read by the Adam that follows
-  if (step != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *step += 1;
+  if (step != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && z == 0 && tid == 0) *step += 1;
   CVF_STAMP(18);
 }
 
 // grad[p] = sum over slab rows, fixed order: 32 row groups (strided) per parameter, then the 32
 // sub-sums in sequence -> bitwise reproducible without atomics.  With `adam` set (single-process runs:
 // no cross-rank reduction of the gradient in between) the same thread applies the Adam update.
-constexpr int kSlabPX = 32, kSlabGY = 32, kSlabU = 10;   // parameters per block, row groups, loads in flight per thread
+// kSlabGY row groups: 32 for the hundreds of rows of a dipeptide-sized batch (one round of loads), 4 when there are at most 64
+// rows (large molecules: few tiles, ~50 000 parameters - 1605 blocks of 1024 threads that each read ONE row were 22 us, mostly
+// wave launches)
+constexpr int kSlabPX = 32, kSlabU = 10;   // parameters per block, loads in flight per thread
+template <int kSlabGY>
 __global__ __launch_bounds__(kSlabPX * kSlabGY) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nrows, int P,
                                                                         float* __restrict__ grad, const float* __restrict__ mask,
                                                                         int use_adam, AdamDev adam, cvf_mlp_desc mlp,
@@ -1340,10 +1400,12 @@ static bool fwd_wg_ok(const cvf_mlp_desc* mlp, int H, int NH) {
 
 extern "C" int64_t cvf_ef_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles) {
   int H, NH;
-  if (!mlp || !ef_shape(mlp, &H, &NH) || !fwd_wg_ok(mlp, H, NH) || getenv("CVF_NO_SAVED")) return 0;
+  if (!mlp || !ef_shape(mlp, &H, &NH) || getenv("CVF_NO_SAVED")) return 0;
+  const bool wide = mlp->dims[0] > kWideD;   // (+ one vector per (tile, net) for t0 = W0 q, see ef_backward_impl)
+  if (!fwd_wg_ok(mlp, H, NH) && !wide) return 0;
   int64_t per_vec = 0;
   const bool ok = ef_dispatch(H, NH, [&](auto h_, auto) { per_vec = saved_per_vec<decltype(h_)::value>(); });
-  return ok ? n_tiles * mlp->n_nets * NH * per_vec : 0;
+  return ok ? n_tiles * mlp->n_nets * (NH + (wide ? 1 : 0)) * per_vec : 0;
 }
 
 extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* packed, const float* feat_tiled,
@@ -1356,10 +1418,10 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
   // few tiles: split each 64-frame tile over two waves so that the launch still fills the 1024 SIMDs
   bool split = n_tiles * mlp->n_nets < 2048;
   if (getenv("CVF_FWD_SPLIT")) split = atoi(getenv("CVF_FWD_SPLIT")) != 0;   // developer override
-  const bool pre = mlp->dims[0] <= 72;   // every load up front (see ef_fwd_pre_kernel)
+  const bool pre = mlp->dims[0] <= 72 && saved == nullptr;   // every load up front (see ef_fwd_pre_kernel)
   const size_t wlds = (size_t)pack_layout(H, NH, mlp->dims[0]).per_net * sizeof(float);
   const bool wg = fwd_wg_ok(mlp, H, NH);  // one fetch of the weights per four tiles (see ef_fwd_wg_kernel)
-  CVF_REQUIRE(saved == nullptr || wg, "cvf_ef_mlp_fwd: this shape has no activation hand-off (cvf_ef_saved_floats() == 0)");
+  CVF_REQUIRE(saved == nullptr || cvf_ef_saved_floats(mlp, 1) > 0, "cvf_ef_mlp_fwd: this shape has no activation hand-off (cvf_ef_saved_floats() == 0)");
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
     if (wg) {
@@ -1375,10 +1437,10 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
                          (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
     else if (split)
       hipLaunchKernelGGL((ef_fwd_mfma_kernel<kH, kNH, 2>), dim3((unsigned)(2 * n_tiles), mlp->n_nets), dim3(64), 0,
-                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
+                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled, saved);
     else
       hipLaunchKernelGGL((ef_fwd_mfma_kernel<kH, kNH, 4>), dim3((unsigned)n_tiles, mlp->n_nets), dim3(64), 0,
-                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
+                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled, saved);
   });
   CVF_REQUIRE(launched, "cvf_ef_mlp_fwd: no kernel instance for hidden width %d x %d layers", H, NH);
   return cvf_check_launch("ef_fwd_mfma_kernel");
@@ -1524,7 +1586,15 @@ static int ef_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, cons
   a.T = cvf_ntiles(B);
   a.n_tiles = cfg->lag_idx > 0 ? 2 * a.T : a.T;
   const int64_t G = bwd_grid(a.n_tiles);
-  dim3 grid((unsigned)G, cfg->k);
+  // wide first layers (d0 > kWideD): the first layer's gradient - 2 x 2 x 32 matrix instructions per column tile, 25 tiles at
+  // d0 = 384, 100 k of one SIMD's cycles per (tile, net) - is shared out over up to four blocks per (tile, net) when the grid
+  // would otherwise leave most of the chip idle; with the activation hand-off they also get t0 = W0 q from a launch of its own
+  const bool wide = mlp->dims[0] > kWideD;
+  const int64_t want = (768 + G * cfg->k - 1) / (G * cfg->k);
+  a.zs = wide ? (int)(want < 1 ? 1 : want > 4 ? 4 : want) : 1;
+  if (getenv("CVF_BWD_ZS")) a.zs = atoi(getenv("CVF_BWD_ZS")) > 0 && wide ? atoi(getenv("CVF_BWD_ZS")) : a.zs;   // developer switch
+  a.t0 = nullptr;
+  dim3 grid((unsigned)G, cfg->k, a.zs);
   // the LDS gradient image relies on each net's parameters being one contiguous run of the flat buffer
   const int span = mlp->b_off[0][NH] + 1 - mlp->w_off[0][0];
   int covered = 0;
@@ -1536,9 +1606,22 @@ static int ef_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, cons
     covered += span;
   }
   CVF_REQUIRE(covered == mlp->n_params, "cvf_ef_backward: flat buffer holds parameters outside the nets");
+  // (the shared-out flush assumes the usual order W0, b0, W1, ... inside a net's run)
+  for (int n = 0; n < mlp->n_nets && a.zs > 1; ++n) {
+    if (mlp->b_off[n][0] != mlp->w_off[n][0] + H * mlp->dims[0]) a.zs = 1;
+    for (int l = 1; l <= NH; ++l)
+      if (mlp->w_off[n][l] < mlp->b_off[n][0] + H || mlp->b_off[n][l] < mlp->b_off[n][0] + H) a.zs = 1;
+  }
+  grid.z = a.zs;
   const size_t lds_dyn = (size_t)span * sizeof(float);
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
+    if (saved != nullptr && wide && cfg->lag_idx == 0 && getenv("CVF_NO_T0") == nullptr) {
+      float* t0 = const_cast<float*>(saved) + a.n_tiles * cfg->k * (int64_t)(kNH * saved_per_vec<kH>());   // (behind the activations)
+      hipLaunchKernelGGL((ef_t0_kernel<kH>), dim3((unsigned)(2 * a.T), cfg->k), dim3(64), 0, (hipStream_t)stream, *mlp, packed,
+                         q_tiled, t0);
+      a.t0 = t0;
+    }
     if (saved != nullptr)
       hipLaunchKernelGGL((ef_bwd_mfma_kernel<kH, kNH, 2, 1>), grid, dim3(128), lds_dyn, (hipStream_t)stream, a, *mlp, theta,
                          packed, w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved);
@@ -1579,7 +1662,11 @@ int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, fl
     if (adam->packed) md = *adam->mlp;
   }
   const unsigned nb = (unsigned)((n_params + kSlabPX - 1) / kSlabPX) + (pair_partial != nullptr ? 1u : 0u);
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb), dim3(kSlabPX, kSlabGY), 0, (hipStream_t)stream, slab,
-                     n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md, pair_partial, n_pair, pair_out);
+  if (n_rows > 64)
+    hipLaunchKernelGGL(slab_reduce_kernel<32>, dim3(nb), dim3(kSlabPX, 32), 0, (hipStream_t)stream, slab,
+                       n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md, pair_partial, n_pair, pair_out);
+  else
+    hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3(nb), dim3(kSlabPX, 4), 0, (hipStream_t)stream, slab,
+                       n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md, pair_partial, n_pair, pair_out);
   return cvf_check_launch("slab_reduce_kernel");
 }

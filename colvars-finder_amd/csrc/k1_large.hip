@@ -194,13 +194,16 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
     for (int i = 0; i < 6; ++i) bc[tid][12 + i] = ko.Kinv[i];
     cD[tid][0] = c0; cD[tid][1] = c1; cD[tid][2] = c2;
   } else if (slot_xyz != nullptr && tid >= 64) {
-    // meanwhile the other waves write the compact copy of the feature atoms for the derivative kernels: the
-    // workgroup's kGroup frames are one contiguous run of both the LDS image and slot_xyz (padded frame index)
-    typedef float nt4 __attribute__((ext_vector_type(4)));
-    const nt4* src = reinterpret_cast<const nt4*>(capL - (size_t)fi * nslot * 3);
-    nt4* dst = reinterpret_cast<nt4*>(slot_xyz + f0 * (int64_t)nslot * 3);
-    const int n4 = kGroup * nslot * 3 / 4;
-    for (int i = tid - 64; i < n4; i += 64 * (kGroup - 1)) __builtin_nontemporal_store(src[i], dst + i);   // written once, read by a later kernel
+    // meanwhile the other waves write the compact copy of the feature atoms for the derivative kernel (metric_large.hip), which
+    // works with one frame per lane: coordinate rows of the 64-frame tile, [tile][n_slot * 3][64] - this workgroup's kGroup
+    // frames are kGroup consecutive floats (32 bytes) of every row
+    const float* img = capL - (size_t)fi * nslot * 3;      // [kGroup][nslot * 3]
+    const int ns3 = nslot * 3;
+    float* dst = slot_xyz + (f0 / CVF_TILE) * (int64_t)ns3 * CVF_TILE + (int)(f0 % CVF_TILE);
+    for (int i = tid - 64; i < kGroup * ns3; i += 64 * (kGroup - 1)) {
+      const int fr = i % kGroup, row = i / kGroup;
+      dst[(int64_t)row * CVF_TILE + fr] = img[fr * ns3 + row];
+    }
   }
   __syncthreads();
   CVF_STAMP(5);
@@ -494,7 +497,7 @@ static bool capture_ok(const cvf_pp_desc* pp, bool tiled) {
   const size_t ldsc = ((size_t)kGroup * pp->n_slot * 3 + (tiled ? (size_t)pp->d_r * kGroup : 0)) * sizeof(float);
   return ldsc <= 150 * 1024;
 }
-// bytes of the compact feature-atom copy [padded frames][n_slot][3] written when `scratch` is given
+// bytes of the compact feature-atom copy [tiles][n_slot * 3][64] written when `scratch` is given
 size_t cvf_k1_large_scratch_bytes(const cvf_pp_desc* pp, int64_t B) {
   return capture_ok(pp, true) ? (size_t)cvf_ntiles(B) * CVF_TILE * pp->n_slot * 3 * sizeof(float) : 0;
 }

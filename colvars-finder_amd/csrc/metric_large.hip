@@ -10,60 +10,99 @@
 //     E_dense   = sum_c ( Z_c. T2[c] Z_c.^T - 2 shift_c Z_c. T1[c] + shift_c^2 T0[c] )
 //     usum_dense[c] = Z_c. T1[c] - shift_c T0[c]          dH_dense[c][j] = Z_c. T2[c][.][j] - shift_c T1[c][j]
 // so a frame costs O(n_slot + n_rec) work instead of O(N).
-// One wave per frame, 8 frames per workgroup; per net the g / q columns of the 8 frames move through LDS so that
-// the tiled tensors are read and written in 32-byte segments.
-#include "cvf_kabsch.hpp"
+//
+// Work decomposition (round 3; rounds 1-2 ran one wave per frame with the records over the lanes and scattered into per-frame
+// slot accumulators in LDS - 8 waves per CU, dependent read-modify-write chains, 117 us for 2000 frames x 6 nets):
+//   * one workgroup = F frames (16 when the table below fits the LDS) x ONE net; a lane is (frame f = lane % F, group = lane / F),
+//     the 64/F groups of the 16 waves ("lane groups") share out the RECORDS (phases A, C) and the SLOTS (phase B).  Every table
+//     index is uniform over a group's F lanes, every global access is F consecutive floats of a [row][64 frames] tile
+//     (g, q, aux and - written that way by K1 - the slot coordinates), and sums over records / slots are plain per-lane sums
+//     followed by ONE fixed-order reduction over the lane groups per phase: no cross-lane work inside the loops.
+//   * the scatter J^T g -> slots is a table of contribution rows in LDS, [n_ref][3][F]: atom p of record r owns row
+//     mrec[r].row[p] (nobody else writes it), and the rows of one slot are contiguous (slot_row[t] .. slot_row[t+1]) - phase A
+//     writes rows, phase B sums each slot's rows, adds the rigid-body term, multiplies by a and leaves u_t in the slot's first
+//     row, phase C reads the u rows of its record's atoms.  No atomics, no read-modify-write, no batching constraint on
+//     the record list.
+//   * the records a lane group owns keep their geometry (gradient vectors of the feature) in registers from phase A to C.
+#include "cvf_metric.hpp"
 
 namespace {
 
-constexpr int kGroup = 8;
+constexpr int kNRed = 13;        // values per block reduction (phase A: 12, phase B: 13)
+constexpr int kMrecInts = 8;     // mrec entry (include/cvf.h): (type + 1) | out << 3, slots (2 x 16 bits) x 2, rows x 2, u rows x 2, 0
 
-struct Rec {
-  int type, a0, a1, a2, a3, out;
-};
-
-__device__ __forceinline__ V3 wave_sum3(V3 v) { return V3{wave_sumf(v.x), wave_sumf(v.y), wave_sumf(v.z)}; }
-
-// Everything about a feature record that does not depend on the net: its slots, output offset and the gradient
-// vectors of the feature with respect to its atoms (for a position record: the centred coordinates).  The records
-// a lane owns are evaluated ONCE per frame and kept in registers across the loop over the k nets - the dihedral
-// geometry (cross products, two reciprocal square roots, divisions) used to be recomputed twice per net.
+// Everything about a feature record that does not depend on the net: output offset, the u rows of its atoms and the gradient
+// vectors of the feature with respect to its atoms (for a position record: the centred coordinates).
 struct Geo {
-  int to;      // (type + 1) | out << 3   (type -1 = padding entry)
-  int s01, s23;   // slots, 16 bits each (n_slot < 65536: the LDS budget caps it far lower)
+  int to;              // (type + 1) | out << 3   (type -1 = no record)
+  int u01, u23;        // u rows of the atoms, 16 bits each (n_ref < 65536)
   V3 v0, v1;           // position: v0 = x - c;  bond: v0 = ga (gb = -ga);  angle: ga, gc (gb = -(ga+gc));  dihedral: g1, g4
   float p, q;          // dihedral: g2 = (-1 - p) g1 + q g4,  g3 = p g1 + (-1 - q) g4
   float cs, sn;        // angle: cs (and sn = -1/sqrt(1-cs^2) for angle-value mode);  dihedral: cos, sin
 };
 __device__ __forceinline__ int geo_type(const Geo& g) { return (g.to & 7) - 1; }
 __device__ __forceinline__ int geo_out(const Geo& g) { return g.to >> 3; }
-__device__ __forceinline__ int geo_s0(const Geo& g) { return g.s01 & 0xffff; }
-__device__ __forceinline__ int geo_s1(const Geo& g) { return (unsigned)g.s01 >> 16; }
-__device__ __forceinline__ int geo_s2(const Geo& g) { return g.s23 & 0xffff; }
-__device__ __forceinline__ int geo_s3(const Geo& g) { return (unsigned)g.s23 >> 16; }
-constexpr int kGeoPre = 5;   // records per lane held in registers (<= 320 entries); the rest is evaluated on the fly
 
-__global__ __launch_bounds__(64 * kGroup) void metric_large_kernel(cvf_pp_desc pp, int64_t B, const float* __restrict__ aux_tiled,
+__device__ __forceinline__ float group_xor(float v, int off) {   // lane ^ off, off a multiple of F
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((int)(threadIdx.x & 63) ^ off) << 2, __builtin_bit_cast(int, v)));
+}
+
+// Sum of v[i] over all lane groups of the workgroup, per frame, in a fixed order; result in every lane.  Two barriers.
+template <int F, int kMWaves, int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red, float* fin, int wave, int f, int grp) {
+  constexpr int G = 64 / F;
+#pragma unroll
+  for (int off = F; off < 64; off <<= 1) {   // (butterfly: the same bits in every lane; the NV exchanges of a level in flight together)
+    float o[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = group_xor(v[i], off);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] += o[i];
+  }
+  if (grp == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[(i * kMWaves + wave) * F + f] = v[i];
+  }
+  __syncthreads();
+  for (int i = wave; i < NV; i += kMWaves) {   // wave i adds value i over the waves
+    float acc = 0.0f;
+    for (int j = grp; j < kMWaves; j += G) acc += red[(i * kMWaves + j) * F + f];
+#pragma unroll
+    for (int off = F; off < 64; off <<= 1) acc += group_xor(acc, off);
+    if (grp == 0) fin[i * F + f] = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = fin[i * F + f];
+}
+
+// F frames per workgroup, kMWaves waves, kGeoPre records per lane group held in registers (the rest is evaluated twice)
+template <int F, int kMWaves, int kGeoPre>
+__global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc pp, int64_t B, const float* __restrict__ aux_tiled,
                                                                    const float* __restrict__ a, int k,
                                                                    const float* __restrict__ slot_xyz,
                                                                    const double* __restrict__ dense,
                                                                    const float* __restrict__ g_tiled,
                                                                    float* __restrict__ q_tiled, float* __restrict__ e_tiled) {
   extern __shared__ float dyn[];
-  const int tid = threadIdx.x, lane = tid & 63, fi = tid >> 6;
+  constexpr int G = 64 / F, LG = kMWaves * G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = lane & (F - 1), grp = lane / F, lg = wave * G + grp;
   CVF_STAMP(20);
-  const int ns = pp.n_slot, d_r = pp.d_r, nal = pp.n_align;
-  float* gL = dyn;                                  // [d_r][kGroup]
-  float* qL = gL + d_r * kGroup;                    // [d_r][kGroup]
-  float* xsL = qL + d_r * kGroup + (size_t)fi * ns * 3;          // this wave's slot coordinates
-  float* GsL = qL + d_r * kGroup + (size_t)kGroup * ns * 3 + (size_t)fi * ns * 3;  // this wave's slot accumulators
-  float* slotC = qL + d_r * kGroup + (size_t)2 * kGroup * ns * 3;   // [ns][8]: a (3), ref (3, zero off the align set), align flag, -
-  const int64_t f0 = (int64_t)blockIdx.x * kGroup;
+  const int ns = pp.n_slot, d_r = pp.d_r, nal = pp.n_align, nref = pp.n_ref, nrec = pp.n_mrec;
+  float* rows = dyn;                                   // [nref * 3][F]
+  float* red = rows + (size_t)nref * 3 * F;           // [kNRed][kMWaves][F]
+  float* fin = red + kNRed * kMWaves * F;              // [kNRed][F]
+  // blockIdx -> (frame group, net) such that the k nets of a frame group follow each other on ONE XCD (workgroups go round
+  // the 8 XCDs by blockIdx): they read the same slot coordinates and aux rows, which then come from that XCD's L2
+  const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7, ix = blockIdx.x >> 3;
+  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ix;
+  const int net = work % k;
+  const int64_t f0 = (int64_t)(work / k) * F;
   const int64_t tile = f0 / CVF_TILE;
-  const int l0 = (int)(f0 % CVF_TILE);
-  const int64_t fpad = f0 + fi;                     // index into the padded (tile-complete) frame range
+  const int l0 = (int)(f0 % CVF_TILE) + f;             // this lane's frame inside its tile
   // per-frame constants
-  const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + l0 + fi;
+  const float* ax = aux_tiled + tile * CVF_AUX_ROWS * CVF_TILE + l0;
   float R[9], Kinv[6], c[3];
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = ax[i * CVF_TILE];
@@ -71,23 +110,16 @@ __global__ __launch_bounds__(64 * kGroup) void metric_large_kernel(cvf_pp_desc p
   for (int i = 0; i < 3; ++i) c[i] = ax[(9 + i) * CVF_TILE];
 #pragma unroll
   for (int i = 0; i < 6; ++i) Kinv[i] = ax[(12 + i) * CVF_TILE];
-  const float* xs = slot_xyz + fpad * (int64_t)ns * 3;
-  for (int i = lane; i < ns * 3; i += 64) xsL[i] = xs[i];
-  // per-slot constants, shared by the workgroup's frames (the three dependent table look-ups happen once here
-  // instead of once per slot, frame and net)
-  for (int sl = tid; sl < ns; sl += 64 * kGroup) {
-    const int atom = pp.slot_atom[sl];
-    const int b = pp.atom_align[atom];
-    const int bc = b >= 0 ? b : 0;
-    float* sc = slotC + 8 * sl;
-    sc[0] = a[3 * atom]; sc[1] = a[3 * atom + 1]; sc[2] = a[3 * atom + 2];
-    const float r0 = pp.ref_c[3 * bc], r1 = pp.ref_c[3 * bc + 1], r2 = pp.ref_c[3 * bc + 2];
-    sc[3] = b >= 0 ? r0 : 0.0f; sc[4] = b >= 0 ? r1 : 0.0f; sc[5] = b >= 0 ? r2 : 0.0f;
-    sc[6] = b >= 0 ? 1.0f : 0.0f;
-    sc[7] = 0.0f;
-  }
-  // dense moments: 42 wave-uniform numbers, kept in LDS (as registers they would be 42 VGPRs: v_cvt_f32_f64 has no
-  // scalar form) and read by broadcast where the closed forms need them
+  const float* xs = slot_xyz + tile * (int64_t)ns * 3 * CVF_TILE + l0;     // [ns * 3][64] of this tile
+  const float* gt = g_tiled + (tile * k + net) * (int64_t)d_r * CVF_TILE + l0;
+  float* qt = q_tiled + (tile * k + net) * (int64_t)d_r * CVF_TILE + l0;
+  // per-slot constants [ns][8] = a (3), ref (3, zero off the align set), align flag, rows (start | count << 20), prepared once
+  // by cvf_metric_dense_tensors behind the 42 moments.  Read from global memory: the F lanes of a group name the same address,
+  // which a vector memory load serves as one request - from LDS the two 16-byte reads per slot were serialised over the 16
+  // equal addresses (3.5 k cycles per three slots), and as eight 4-byte broadcast reads they were 24 of the loop's 39 LDS
+  // instructions
+  const float4* slotG = reinterpret_cast<const float4*>(dense + 42);
+  // dense moments: 42 uniform numbers, kept in LDS and read by broadcast where the closed forms need them
   __shared__ float dn[42];
   if (tid < 42) dn[tid] = (float)dense[tid];
   const float* T0 = dn;
@@ -95,277 +127,302 @@ __global__ __launch_bounds__(64 * kGroup) void metric_large_kernel(cvf_pp_desc p
   const float* T2 = dn + 12;
   const float* R1 = dn + 39;
   const float inv_nal = 1.0f / (float)nal;
-  auto xat = [&](int sl) { return V3{xsL[3 * sl], xsL[3 * sl + 1], xsL[3 * sl + 2]}; };
-  auto uat = [&](int sl) { return V3{GsL[3 * sl], GsL[3 * sl + 1], GsL[3 * sl + 2]}; };
-  // Scatter into the slot accumulators.  LDS float atomics cost ~850 cycles per wave instruction here (8 waves share
-  // the unit): with a batched record list (CVF_PP_SLOT_BATCHED) no two lanes of one instruction name the same slot,
-  // and instructions of one wave execute in order, so a plain read-modify-write is exact.
-  const bool batched = (pp.flags & CVF_PP_SLOT_BATCHED) != 0;
-  const int nrs = pp.n_rec_slot > 0 ? pp.n_rec_slot : pp.n_rec;
-  auto addG = [&](int sl, V3 v) {
-    float* g3 = GsL + 3 * sl;
-    if (batched) {
-      g3[0] += v.x;
-      g3[1] += v.y;
-      g3[2] += v.z;
-    } else {
-      atomicAdd(g3, v.x);
-      atomicAdd(g3 + 1, v.y);
-      atomicAdd(g3 + 2, v.z);
-    }
+  auto rowat = [&](int r) { return V3{rows[(3 * r) * F + f], rows[(3 * r + 1) * F + f], rows[(3 * r + 2) * F + f]}; };
+  auto put_row = [&](int r, V3 v) {
+    rows[(3 * r) * F + f] = v.x;
+    rows[(3 * r + 1) * F + f] = v.y;
+    rows[(3 * r + 2) * F + f] = v.z;
   };
-  // CVF_PP_SLOT_DISJOINT: no slot occurs twice in a batch, so all accumulators of ONE record are read first and written
-  // afterwards - one LDS round trip per record instead of one per component (without the flag a lane's slot may be another
-  // lane's slot in a different atom position, and only the component-by-component order is exact)
-  const bool disjoint = batched && (pp.flags & CVF_PP_SLOT_DISJOINT) != 0;
-  auto addG2 = [&](int sa, V3 va, int sb, V3 vb) {
-    if (!disjoint) { addG(sa, va); addG(sb, vb); return; }
-    float* ga = GsL + 3 * sa; float* gb = GsL + 3 * sb;
-    const float a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2];
-    ga[0] = a0 + va.x; ga[1] = a1 + va.y; ga[2] = a2 + va.z;
-    gb[0] = b0 + vb.x; gb[1] = b1 + vb.y; gb[2] = b2 + vb.z;
+  // A record is handled in three steps whose loads are unconditional - table entry; coordinates of its (up to) four atoms and
+  // its (up to) three g values, unused positions naming slot 0 / a clamped row; geometry - so that the loads of SEVERAL
+  // records are in flight together: as one dependent chain per record (entry -> coordinates -> g) phase A was 21 memory
+  // round trips long for the 7 records of a lane group, 22 k of the workgroup's 61 k cycles.
+  struct RecI { int to, s01, s23, r01, r23, u01, u23; };
+  struct RecX { float x[12], g[3]; };
+  auto load_rec = [&](int r) {
+    const int4* p = reinterpret_cast<const int4*>(pp.mrec + kMrecInts * (r < nrec ? r : nrec - 1));
+    const int4 lo = p[0], hi = p[1];
+    return RecI{r < nrec ? lo.x : 0, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z};
   };
-  auto addG3 = [&](int sa, V3 va, int sb, V3 vb, int sc, V3 vc) {
-    if (!disjoint) { addG(sa, va); addG(sb, vb); addG(sc, vc); return; }
-    float* ga = GsL + 3 * sa; float* gb = GsL + 3 * sb; float* gc = GsL + 3 * sc;
-    const float a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2], c0 = gc[0], c1 = gc[1], c2 = gc[2];
-    ga[0] = a0 + va.x; ga[1] = a1 + va.y; ga[2] = a2 + va.z;
-    gb[0] = b0 + vb.x; gb[1] = b1 + vb.y; gb[2] = b2 + vb.z;
-    gc[0] = c0 + vc.x; gc[1] = c1 + vc.y; gc[2] = c2 + vc.z;
+  auto load_x = [&](const RecI& ri) {
+    RecX o;
+    const int sl[4] = {ri.s01 & 0xffff, (int)((unsigned)ri.s01 >> 16), ri.s23 & 0xffff, (int)((unsigned)ri.s23 >> 16)};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) o.x[3 * p + cc] = xs[(int64_t)(3 * sl[p] + cc) * CVF_TILE];
+    const int out = ri.to >> 3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o.g[j] = gt[(int64_t)(out + j < d_r ? out + j : d_r - 1) * CVF_TILE];
+    return o;
   };
-  auto addG4 = [&](int sa, V3 va, int sb, V3 vb, int sc, V3 vc, int sd, V3 vd) {
-    if (!disjoint) { addG(sa, va); addG(sb, vb); addG(sc, vc); addG(sd, vd); return; }
-    float* ga = GsL + 3 * sa; float* gb = GsL + 3 * sb; float* gc = GsL + 3 * sc; float* gd = GsL + 3 * sd;
-    const float a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2];
-    const float c0 = gc[0], c1 = gc[1], c2 = gc[2], d0 = gd[0], d1 = gd[1], d2 = gd[2];
-    ga[0] = a0 + va.x; ga[1] = a1 + va.y; ga[2] = a2 + va.z;
-    gb[0] = b0 + vb.x; gb[1] = b1 + vb.y; gb[2] = b2 + vb.z;
-    gc[0] = c0 + vc.x; gc[1] = c1 + vc.y; gc[2] = c2 + vc.z;
-    gd[0] = d0 + vd.x; gd[1] = d1 + vd.y; gd[2] = d2 + vd.z;
-  };
-  auto make_geo = [&](int r) {
-    const int32_t* p = pp.rec_slot + 6 * r;
+  auto eval = [&](const RecI& ri, const RecX& rx) {
     Geo ge;
-    ge.to = (p[0] + 1) | (p[5] << 3);
-    ge.s01 = p[1] | (p[2] << 16);
-    ge.s23 = p[3] | (p[4] << 16);
+    ge.to = ri.to;
+    ge.u01 = ri.u01; ge.u23 = ri.u23;
     ge.v0 = ge.v1 = v3(0, 0, 0);
     ge.p = ge.q = ge.cs = ge.sn = 0.0f;
-    if (geo_type(ge) < 0) {
-      // padding entry
-    } else if (geo_type(ge) == CVF_FEAT_POSITION) {
-      const V3 xa = xat(geo_s0(ge));
-      ge.v0 = v3(xa.x - c[0], xa.y - c[1], xa.z - c[2]);
-    } else if (geo_type(ge) == CVF_FEAT_BOND) {
-      ge.v0 = bond_eval(xat(geo_s0(ge)), xat(geo_s1(ge))).ga;
-    } else if (geo_type(ge) == CVF_FEAT_ANGLE) {
-      const AngleG e = angle_eval(xat(geo_s0(ge)), xat(geo_s1(ge)), xat(geo_s2(ge)));
+    const int ty = geo_type(ge);
+    const V3 x0 = v3(rx.x[0], rx.x[1], rx.x[2]), x1 = v3(rx.x[3], rx.x[4], rx.x[5]);
+    const V3 x2 = v3(rx.x[6], rx.x[7], rx.x[8]), x3 = v3(rx.x[9], rx.x[10], rx.x[11]);
+    if (ty == CVF_FEAT_POSITION) {
+      ge.v0 = v3(x0.x - c[0], x0.y - c[1], x0.z - c[2]);
+    } else if (ty == CVF_FEAT_BOND) {
+      ge.v0 = bond_eval(x0, x1).ga;
+    } else if (ty == CVF_FEAT_ANGLE) {
+      const AngleG e = angle_eval(x0, x1, x2);
       ge.v0 = e.ga; ge.v1 = e.gc;
       ge.cs = e.cs;
       ge.sn = -1.0f / sqrtf(fmaxf(1.0f - e.cs * e.cs, 1e-30f));
-    } else {
-      const DihedralG e = dihedral_eval(xat(geo_s0(ge)), xat(geo_s1(ge)), xat(geo_s2(ge)), xat(geo_s3(ge)));
+    } else if (ty == CVF_FEAT_DIHEDRAL) {
+      const DihedralG e = dihedral_eval(x0, x1, x2, x3);
       ge.v0 = e.g1; ge.v1 = e.g4;
       ge.p = e.p; ge.q = e.q;
       ge.cs = e.cs; ge.sn = e.sn;
     }
     return ge;
   };
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();   // this wave's xsL is in place (wave-private region)
+  // ---- phase A: contribution rows of J^T g (record r, atom p -> its own row), position sums
+  float sa[kNRed];
+#pragma unroll
+  for (int i = 0; i < kNRed; ++i) sa[i] = 0.0f;   // sump (3), M (9), -
+  auto vjp = [&](const Geo& ge, const RecI& ri, const RecX& rx) {
+    const int ty = geo_type(ge);
+    if (ty < 0) return;
+    const int r0 = ri.r01 & 0xffff, r1 = (unsigned)ri.r01 >> 16, r2 = ri.r23 & 0xffff, r3 = (unsigned)ri.r23 >> 16;
+    if (ty == CVF_FEAT_POSITION) {
+      const V3 g = v3(rx.g[0], rx.g[1], rx.g[2]);
+      const V3 pv = mat_times(R, g);
+      put_row(r0, pv);
+      sa[0] += pv.x; sa[1] += pv.y; sa[2] += pv.z;
+      const V3 xc = ge.v0;
+      sa[3] += xc.x * g.x; sa[4] += xc.x * g.y; sa[5] += xc.x * g.z;
+      sa[6] += xc.y * g.x; sa[7] += xc.y * g.y; sa[8] += xc.y * g.z;
+      sa[9] += xc.z * g.x; sa[10] += xc.z * g.y; sa[11] += xc.z * g.z;
+    } else if (ty == CVF_FEAT_BOND) {
+      const V3 ga = rx.g[0] * ge.v0;
+      put_row(r0, ga);
+      put_row(r1, v3(-ga.x, -ga.y, -ga.z));
+    } else if (ty == CVF_FEAT_ANGLE) {
+      float gs = rx.g[0];
+      if (pp.use_angle_value) gs *= ge.sn;
+      const V3 ga = gs * ge.v0, gc = gs * ge.v1;
+      put_row(r0, ga);
+      put_row(r1, v3(-ga.x - gc.x, -ga.y - gc.y, -ga.z - gc.z));
+      put_row(r2, gc);
+    } else {
+      const float gs = pp.use_angle_value ? rx.g[0] : (rx.g[1] * ge.cs - rx.g[0] * ge.sn);
+      const V3 g1 = gs * ge.v0, g4 = gs * ge.v1;
+      put_row(r0, g1);
+      put_row(r1, (-1.0f - ge.p) * g1 + ge.q * g4);
+      put_row(r2, ge.p * g1 + (-1.0f - ge.q) * g4);
+      put_row(r3, g4);
+    }
+  };
   Geo pre[kGeoPre];
+  constexpr int kChunk = 4;   // records whose coordinates are requested together
+  {
+    RecI ri[kGeoPre];
 #pragma unroll
-  for (int it = 0; it < kGeoPre; ++it) pre[it] = make_geo(lane + 64 * it < nrs ? lane + 64 * it : nrs - 1);
-
-  CVF_STAMP(21);
-  for (int net = 0; net < k; ++net) {
-    const int64_t base = (tile * k + net) * (int64_t)d_r * CVF_TILE + l0;
-    __syncthreads();  // previous net's qL flushed, gL free (first pass: slotC complete)
-    // (eight loads in flight per thread, then the LDS writes: one load at a time, each followed by its LDS write, was six
-    //  dependent round trips to memory per net - 26 k of the 48 k cycles a net took)
-    for (int i0 = tid; i0 < d_r * kGroup; i0 += 64 * kGroup * 8) {
-      float gv[8];
+    for (int it = 0; it < kGeoPre; ++it) ri[it] = load_rec(lg + LG * it);
+    CVF_STAMP(21);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = i0 + 64 * kGroup * u;
-        const int ic = idx < d_r * kGroup ? idx : d_r * kGroup - 1;
-        gv[u] = g_tiled[base + (int64_t)(ic / kGroup) * CVF_TILE + ic % kGroup];
-      }
+    for (int c0 = 0; c0 < kGeoPre; c0 += kChunk) {
+      RecX rx[kChunk];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = i0 + 64 * kGroup * u;
-        if (idx < d_r * kGroup) gL[idx] = gv[u];
-      }
-    }
-    for (int i = lane; i < ns * 3; i += 64) GsL[i] = 0.0f;
-    __syncthreads();
-    if (net == 0) CVF_STAMP(22);
-    // ---- sparse VJP
-    V3 sump = v3(0, 0, 0);
-    float M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto vjp = [&](const Geo& ge) {
-      const int ty = geo_type(ge);
-      if (ty < 0) return;
-      const float* gp = gL + geo_out(ge) * kGroup + fi;
-      if (ty == CVF_FEAT_POSITION) {
-        const V3 g = v3(gp[0], gp[kGroup], gp[2 * kGroup]);
-        const V3 pv = mat_times(R, g);
-        addG(geo_s0(ge), pv);
-        sump = sump + pv;
-        const V3 xc = ge.v0;
-        M[0] += xc.x * g.x; M[1] += xc.x * g.y; M[2] += xc.x * g.z;
-        M[3] += xc.y * g.x; M[4] += xc.y * g.y; M[5] += xc.y * g.z;
-        M[6] += xc.z * g.x; M[7] += xc.z * g.y; M[8] += xc.z * g.z;
-      } else if (ty == CVF_FEAT_BOND) {
-        const V3 ga = gp[0] * ge.v0;
-        addG2(geo_s0(ge), ga, geo_s1(ge), v3(-ga.x, -ga.y, -ga.z));
-      } else if (ty == CVF_FEAT_ANGLE) {
-        float gs = gp[0];
-        if (pp.use_angle_value) gs *= ge.sn;
-        const V3 ga = gs * ge.v0, gc = gs * ge.v1;
-        addG3(geo_s0(ge), ga, geo_s1(ge), v3(-ga.x - gc.x, -ga.y - gc.y, -ga.z - gc.z), geo_s2(ge), gc);
-      } else {
-        const float gs = pp.use_angle_value ? gp[0] : (gp[kGroup] * ge.cs - gp[0] * ge.sn);
-        const V3 g1 = gs * ge.v0, g4 = gs * ge.v1;
-        addG4(geo_s0(ge), g1, geo_s1(ge), (-1.0f - ge.p) * g1 + ge.q * g4, geo_s2(ge), ge.p * g1 + (-1.0f - ge.q) * g4, geo_s3(ge), g4);
-      }
-    };
+      for (int j = 0; j < kChunk; ++j)
+        if (c0 + j < kGeoPre) rx[j] = load_x(ri[c0 + j]);
 #pragma unroll
-    for (int it = 0; it < kGeoPre; ++it)
-      if (lane + 64 * it < nrs) vjp(pre[it]);
-    for (int r = lane + 64 * kGeoPre; r < nrs; r += 64) vjp(make_geo(r));
-    if (net == 0) CVF_STAMP(23);
-    sump = wave_sum3(sump);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) M[i] = wave_sumf(M[i]);
-    float T[9], Z[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * M[j] + R[3 + i] * M[3 + j] + R[6 + i] * M[6 + j];
-    const V3 s = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      Z[3 * i + 0] = R[3 * i + 1] * s.z - R[3 * i + 2] * s.y;
-      Z[3 * i + 1] = -R[3 * i + 0] * s.z + R[3 * i + 2] * s.x;
-      Z[3 * i + 2] = R[3 * i + 0] * s.y - R[3 * i + 1] * s.x;
-    }
-    const float sh[3] = {inv_nal * sump.x, inv_nal * sump.y, inv_nal * sump.z};
-    // ---- dense part from the moments
-    float E = 0.0f, usd[3], dH[9];
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc) {
-      float zt1 = 0.0f, quad = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        zt1 += Z[3 * cc + j] * T1[3 * cc + j];
-        float row = 0.0f;
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) row += Z[3 * cc + kk] * T2[9 * cc + 3 * kk + j];
-        dH[3 * cc + j] = row - sh[cc] * T1[3 * cc + j];
-        quad += row * Z[3 * cc + j];
-      }
-      usd[cc] = zt1 - sh[cc] * T0[cc];
-      E += quad - 2.0f * sh[cc] * zt1 + sh[cc] * sh[cc] * T0[cc];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (net == 0) CVF_STAMP(24);
-    // ---- touched atoms: u_t = a_t .* (s_t + d_t); corrections to E, usum, dH
-    float Ep = 0.0f;
-    V3 usp = v3(0, 0, 0);
-    float dHp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 5
-    for (int sl = lane; sl < ns; sl += 64) {
-      const float4 c0 = *reinterpret_cast<const float4*>(slotC + 8 * sl);
-      const float4 c1 = *reinterpret_cast<const float4*>(slotC + 8 * sl + 4);
-      const V3 at = v3(c0.x, c0.y, c0.z), rf = v3(c0.w, c1.x, c1.y);
-      const float al = c1.z;   // 1 on the align set, else 0 (then rf = 0 as well)
-      const V3 st = uat(sl);
-      const V3 zr = mat_times(Z, rf);
-      const V3 dt = v3(al * (zr.x - sh[0]), al * (zr.y - sh[1]), al * (zr.z - sh[2]));
-      Ep += at.x * (2.0f * st.x * dt.x + st.x * st.x) + at.y * (2.0f * st.y * dt.y + st.y * st.y) +
-            at.z * (2.0f * st.z * dt.z + st.z * st.z);
-      const V3 as = v3(al * at.x * st.x, al * at.y * st.y, al * at.z * st.z);
-      usp = usp + as;
-      dHp[0] += as.x * rf.x; dHp[1] += as.x * rf.y; dHp[2] += as.x * rf.z;
-      dHp[3] += as.y * rf.x; dHp[4] += as.y * rf.y; dHp[5] += as.y * rf.z;
-      dHp[6] += as.z * rf.x; dHp[7] += as.z * rf.y; dHp[8] += as.z * rf.z;
-      GsL[3 * sl] = at.x * (st.x + dt.x);
-      GsL[3 * sl + 1] = at.y * (st.y + dt.y);
-      GsL[3 * sl + 2] = at.z * (st.z + dt.z);
-    }
-    if (net == 0) CVF_STAMP(25);
-    E += wave_sumf(Ep);
-    usp = wave_sum3(usp);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) dH[i] += wave_sumf(dHp[i]);
-    if (lane == 0) e_tiled[(tile * k + net) * CVF_TILE + l0 + fi] = E;
-    const float ub[3] = {inv_nal * (usd[0] + usp.x), inv_nal * (usd[1] + usp.y), inv_nal * (usd[2] + usp.z)};
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) dH[3 * cc + j] -= ub[cc] * R1[j];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * dH[j] + R[3 + i] * dH[3 + j] + R[6 + i] * dH[6 + j];
-    const V3 w = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
-    float dR[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      dR[3 * i + 0] = R[3 * i + 1] * w.z - R[3 * i + 2] * w.y;
-      dR[3 * i + 1] = -R[3 * i + 0] * w.z + R[3 * i + 2] * w.x;
-      dR[3 * i + 2] = R[3 * i + 0] * w.y - R[3 * i + 1] * w.x;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (net == 0) CVF_STAMP(26);
-    // ---- JVP: q = J u
-    auto jvp = [&](const Geo& ge) {
-      const int ty = geo_type(ge);
-      if (ty < 0) return;
-      float* qp = qL + geo_out(ge) * kGroup + fi;
-      if (ty == CVF_FEAT_POSITION) {
-        const V3 u = uat(geo_s0(ge));
-        const V3 qa = row_times(v3(u.x - ub[0], u.y - ub[1], u.z - ub[2]), R) + row_times(ge.v0, dR);
-        qp[0] = qa.x;
-        qp[kGroup] = qa.y;
-        qp[2 * kGroup] = qa.z;
-      } else if (ty == CVF_FEAT_BOND) {
-        qp[0] = dot(ge.v0, uat(geo_s0(ge)) - uat(geo_s1(ge)));
-      } else if (ty == CVF_FEAT_ANGLE) {
-        const V3 ub_ = uat(geo_s1(ge));
-        float dv = dot(ge.v0, uat(geo_s0(ge)) - ub_) + dot(ge.v1, uat(geo_s2(ge)) - ub_);
-        if (pp.use_angle_value) dv *= ge.sn;
-        qp[0] = dv;
-      } else {
-        const V3 u1 = uat(geo_s0(ge)), u2 = uat(geo_s1(ge)), u3 = uat(geo_s2(ge)), u4 = uat(geo_s3(ge));
-        // g1.u1 + g2.u2 + g3.u3 + g4.u4 with g2, g3 expressed through g1, g4
-        const V3 w1 = u1 + (-1.0f - ge.p) * u2 + ge.p * u3;
-        const V3 w4 = u4 + ge.q * u2 + (-1.0f - ge.q) * u3;
-        const float dphi = dot(ge.v0, w1) + dot(ge.v1, w4);
-        if (pp.use_angle_value) {
-          qp[0] = dphi;
-        } else {
-          qp[0] = -ge.sn * dphi;
-          qp[kGroup] = ge.cs * dphi;
+      for (int j = 0; j < kChunk; ++j)
+        if (c0 + j < kGeoPre) {
+          pre[c0 + j] = eval(ri[c0 + j], rx[j]);
+          vjp(pre[c0 + j], ri[c0 + j], rx[j]);
         }
-      }
-    };
-#pragma unroll
-    for (int it = 0; it < kGeoPre; ++it)
-      if (lane + 64 * it < nrs) jvp(pre[it]);
-    for (int r = lane + 64 * kGeoPre; r < nrs; r += 64) jvp(make_geo(r));
-    if (net == 0) CVF_STAMP(27);
-    __syncthreads();
-    for (int idx = tid; idx < d_r * kGroup; idx += 64 * kGroup) {
-      const int o = idx / kGroup, f = idx % kGroup;
-      q_tiled[base + (int64_t)o * CVF_TILE + f] = qL[idx];
     }
-    if (net == 0) CVF_STAMP(28);
   }
-  CVF_STAMP(29);
+  for (int r = lg + LG * kGeoPre; r < nrec; r += LG) {
+    const RecI ri = load_rec(r);
+    const RecX rx = load_x(ri);
+    vjp(eval(ri, rx), ri, rx);
+  }
+  CVF_STAMP(22);
+  block_sum<F, kMWaves, kNRed>(sa, red, fin, wave, f, grp);     // (its barriers also publish the rows and slotC)
+  CVF_STAMP(23);
+  const V3 sump = v3(sa[0], sa[1], sa[2]);
+  const float* M = sa + 3;
+  float T[9], Z[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * M[j] + R[3 + i] * M[3 + j] + R[6 + i] * M[6 + j];
+  const V3 s = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Z[3 * i + 0] = R[3 * i + 1] * s.z - R[3 * i + 2] * s.y;
+    Z[3 * i + 1] = -R[3 * i + 0] * s.z + R[3 * i + 2] * s.x;
+    Z[3 * i + 2] = R[3 * i + 0] * s.y - R[3 * i + 1] * s.x;
+  }
+  const float sh[3] = {inv_nal * sump.x, inv_nal * sump.y, inv_nal * sump.z};
+  // ---- dense part from the moments
+  float E = 0.0f, usd[3], dH[9];
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc) {
+    float zt1 = 0.0f, quad = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      zt1 += Z[3 * cc + j] * T1[3 * cc + j];
+      float row = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) row += Z[3 * cc + kk] * T2[9 * cc + 3 * kk + j];
+      dH[3 * cc + j] = row - sh[cc] * T1[3 * cc + j];
+      quad += row * Z[3 * cc + j];
+    }
+    usd[cc] = zt1 - sh[cc] * T0[cc];
+    E += quad - 2.0f * sh[cc] * zt1 + sh[cc] * sh[cc] * T0[cc];
+  }
+  // ---- phase B: slots.  s_t = sum of the slot's rows; u_t = a_t .* (s_t + d_t), d_t = al_t (Z ref_t - shift), into its first
+  // row.  Accumulated: Es = sum a s^2, usp = sum al a s, dHp = sum (al a s) (x) ref - the cross term 2 sum a s d of E follows
+  // from the last two (2 sum_c (Z_c. dHp_c - shift_c usp_c)) after the reduction.  Three slots per iteration, their LDS reads
+  // requested together.
+  const MatCols Zc = mat_cols(Z);
+  float Es = 0.0f;
+  f2 usp_xy = {0.0f, 0.0f};
+  float usp_z = 0.0f;
+  Outer3 dHo = {{{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}}, {0.0f, 0.0f, 0.0f}};
+  constexpr int kSlots = 3;
+  CVF_STAMP(30);
+#ifdef CVF_STAMPS
+  int itb = 0;
+#endif
+  float4 n0[kSlots], n1[kSlots];   // the next iteration's constants, requested one iteration ahead
+#pragma unroll
+  for (int j = 0; j < kSlots; ++j) {
+    const int sl = lg + LG * j < ns ? lg + LG * j : ns - 1;
+    n0[j] = slotG[2 * sl];
+    n1[j] = slotG[2 * sl + 1];
+  }
+  for (int sl0 = lg; sl0 < ns; sl0 += LG * kSlots) {
+    float4 c0[kSlots], c1[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+      c0[j] = n0[j];
+      c1[j] = n1[j];
+      const int nx = sl0 + LG * (kSlots + j);
+      const int sl = nx < ns ? nx : ns - 1;
+      n0[j] = slotG[2 * sl];
+      n1[j] = slotG[2 * sl + 1];
+    }
+    V3 st[kSlots];
+    int r0[kSlots], cnt[kSlots], mx = 1;
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+      const int rc = __builtin_bit_cast(int, c1[j].w);
+      r0[j] = rc & 0xfffff;
+      cnt[j] = (int)((unsigned)rc >> 20);
+      mx = cnt[j] > mx ? cnt[j] : mx;
+      st[j] = rowat(r0[j]);
+    }
+    for (int e = 1; e < mx; ++e) {   // atoms shared by several records
+#pragma unroll
+      for (int j = 0; j < kSlots; ++j) {
+        const V3 x = rowat(r0[j] + e < nref ? r0[j] + e : nref - 1);
+        const float m = e < cnt[j] ? 1.0f : 0.0f;
+        st[j] = st[j] + m * x;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+      const bool valid = sl0 + LG * j < ns;
+      const float mv = valid ? 1.0f : 0.0f;
+      const V3 at = v3(mv * c0[j].x, mv * c0[j].y, mv * c0[j].z), rf = v3(c0[j].w, c1[j].x, c1[j].y);
+      const float al = c1[j].z;   // 1 on the align set, else 0 (then rf = 0 as well)
+      const V3 as = v3(at.x * st[j].x, at.y * st[j].y, at.z * st[j].z);
+      Es += as.x * st[j].x + as.y * st[j].y + as.z * st[j].z;
+      const V3 asl = al * as;
+      usp_xy += f2{asl.x, asl.y};
+      usp_z += asl.z;
+      outer_acc(dHo, asl, rf);
+      f2 dxy = f2{-al * sh[0], -al * sh[1]};
+      float dz = -al * sh[2];
+      mat_times_acc(Zc, rf, dxy, dz);
+      if (valid) put_row(r0[j], v3(as.x + at.x * dxy.x, as.y + at.y * dxy.y, as.z + at.z * dz));
+    }
+#ifdef CVF_STAMPS
+    if (itb < 8) CVF_STAMP(31 + itb);
+    ++itb;
+#endif
+  }
+  float sb[kNRed];
+  sb[0] = Es;
+  sb[1] = usp_xy.x; sb[2] = usp_xy.y; sb[3] = usp_z;
+  outer_to_array(dHo, *reinterpret_cast<float (*)[9]>(sb + 4));
+  CVF_STAMP(24);
+  block_sum<F, kMWaves, kNRed>(sb, red, fin, wave, f, grp);     // (publishes the u rows)
+  CVF_STAMP(25);
+  E += sb[0];
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc)
+    E += 2.0f * (Z[3 * cc] * sb[4 + 3 * cc] + Z[3 * cc + 1] * sb[5 + 3 * cc] + Z[3 * cc + 2] * sb[6 + 3 * cc] - sh[cc] * sb[1 + cc]);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) dH[i] += sb[4 + i];
+  if (lg == 0) e_tiled[(tile * k + net) * CVF_TILE + l0] = E;
+  const float ub[3] = {inv_nal * (usd[0] + sb[1]), inv_nal * (usd[1] + sb[2]), inv_nal * (usd[2] + sb[3])};
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dH[3 * cc + j] -= ub[cc] * R1[j];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = R[i] * dH[j] + R[3 + i] * dH[3 + j] + R[6 + i] * dH[6 + j];
+  const V3 w = sym_times(Kinv, v3(T[7] - T[5], T[2] - T[6], T[3] - T[1]));
+  float dR[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dR[3 * i + 0] = R[3 * i + 1] * w.z - R[3 * i + 2] * w.y;
+    dR[3 * i + 1] = -R[3 * i + 0] * w.z + R[3 * i + 2] * w.x;
+    dR[3 * i + 2] = R[3 * i + 0] * w.y - R[3 * i + 1] * w.x;
+  }
+  // ---- phase C: q = J u, by the records' owners
+  auto jvp = [&](const Geo& ge) {
+    const int ty = geo_type(ge);
+    if (ty < 0) return;
+    float* qp = qt + (int64_t)geo_out(ge) * CVF_TILE;
+    const int u0 = ge.u01 & 0xffff, u1 = (unsigned)ge.u01 >> 16, u2 = ge.u23 & 0xffff, u3 = (unsigned)ge.u23 >> 16;
+    if (ty == CVF_FEAT_POSITION) {
+      const V3 u = rowat(u0);
+      const V3 qa = row_times(v3(u.x - ub[0], u.y - ub[1], u.z - ub[2]), R) + row_times(ge.v0, dR);
+      qp[0] = qa.x;
+      qp[CVF_TILE] = qa.y;
+      qp[2 * CVF_TILE] = qa.z;
+    } else if (ty == CVF_FEAT_BOND) {
+      qp[0] = dot(ge.v0, rowat(u0) - rowat(u1));
+    } else if (ty == CVF_FEAT_ANGLE) {
+      const V3 ub_ = rowat(u1);
+      float dv = dot(ge.v0, rowat(u0) - ub_) + dot(ge.v1, rowat(u2) - ub_);
+      if (pp.use_angle_value) dv *= ge.sn;
+      qp[0] = dv;
+    } else {
+      const V3 x1 = rowat(u0), x2 = rowat(u1), x3 = rowat(u2), x4 = rowat(u3);
+      // g1.u1 + g2.u2 + g3.u3 + g4.u4 with g2, g3 expressed through g1, g4
+      const V3 w1 = x1 + (-1.0f - ge.p) * x2 + ge.p * x3;
+      const V3 w4 = x4 + ge.q * x2 + (-1.0f - ge.q) * x3;
+      const float dphi = dot(ge.v0, w1) + dot(ge.v1, w4);
+      if (pp.use_angle_value) {
+        qp[0] = dphi;
+      } else {
+        qp[0] = -ge.sn * dphi;
+        qp[CVF_TILE] = ge.cs * dphi;
+      }
+    }
+  };
+#pragma unroll
+  for (int it = 0; it < kGeoPre; ++it) jvp(pre[it]);
+  for (int r = lg + LG * kGeoPre; r < nrec; r += LG) {
+    const RecI ri = load_rec(r);
+    jvp(eval(ri, load_x(ri)));
+  }
+  CVF_STAMP(26);
 }
 
 // dense[42] = T0[3], T1[3][3], T2[3][3][3], R1[3] in fp64; one block
@@ -404,25 +461,62 @@ __global__ void metric_dense_kernel(cvf_pp_desc pp, const float* __restrict__ a,
   }
   __syncthreads();
   if (tid < 42) dense[tid] = red[tid];
+  // the derivative kernel's per-slot constants behind the moments: [n_slot][8] floats (see metric_rows_kernel)
+  if (pp.slot_row != nullptr) {
+    float* sc0 = reinterpret_cast<float*>(dense + 42);
+    for (int sl = tid; sl < pp.n_slot; sl += blockDim.x) {
+      const int atom = pp.slot_atom[sl];
+      const int b = pp.atom_align[atom];
+      const int bc = b >= 0 ? b : 0;
+      const int r0 = pp.slot_row[sl], r1 = pp.slot_row[sl + 1];
+      float* sc = sc0 + 8 * sl;
+      sc[0] = a[3 * atom]; sc[1] = a[3 * atom + 1]; sc[2] = a[3 * atom + 2];
+      sc[3] = b >= 0 ? pp.ref_c[3 * bc] : 0.0f; sc[4] = b >= 0 ? pp.ref_c[3 * bc + 1] : 0.0f; sc[5] = b >= 0 ? pp.ref_c[3 * bc + 2] : 0.0f;
+      sc[6] = b >= 0 ? 1.0f : 0.0f;
+      sc[7] = __builtin_bit_cast(float, r0 | ((r1 - r0) << 20));
+    }
+  }
 }
 
 }  // namespace
 
-size_t cvf_metric_large_lds(const cvf_pp_desc* pp) {
-  return ((size_t)2 * pp->d_r * kGroup + (size_t)2 * kGroup * pp->n_slot * 3 + (size_t)8 * pp->n_slot) * sizeof(float);
+static size_t metric_rows_lds(const cvf_pp_desc* pp, int F, int waves) {
+  return ((size_t)pp->n_ref * 3 * F + (size_t)kNRed * waves * F + (size_t)kNRed * F) * sizeof(float);
 }
+size_t cvf_metric_large_lds(const cvf_pp_desc* pp) { return metric_rows_lds(pp, 4, 8); }   // the smallest layout
 
 int cvf_metric_large_launch(const cvf_pp_desc* pp, int64_t B, const float* aux_tiled, const float* a, int k,
                             const float* slot_xyz, const double* dense, const float* g_tiled, float* q_tiled, float* e_tiled,
                             hipStream_t s) {
-  const size_t lds = cvf_metric_large_lds(pp);
-  CVF_REQUIRE(lds <= 158 * 1024, "cvf_metric_apply: %d feature atoms x %d features need %zu B of LDS (> 158 KiB)", pp->n_slot,
-              pp->d_r, lds);
-  (void)hipFuncSetAttribute((const void*)metric_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int64_t groups = cvf_ntiles(B) * (CVF_TILE / kGroup);
-  hipLaunchKernelGGL(metric_large_kernel, dim3((unsigned)groups), dim3(64 * kGroup), lds, s, *pp, B, aux_tiled, a, k, slot_xyz,
-                     dense, g_tiled, q_tiled, e_tiled);
-  return cvf_check_launch("metric_large_kernel");
+  CVF_REQUIRE(pp->mrec && pp->slot_row && pp->n_mrec > 0 && pp->n_ref >= pp->n_slot && pp->n_ref < 65536,
+              "cvf_metric_apply: large molecules need the record / row tables (mrec, slot_row, n_mrec, n_ref) of cvf_pp_desc");
+  constexpr size_t kBudget = 158 * 1024;
+  static const int waves = getenv("CVF_METRIC_WAVES") ? atoi(getenv("CVF_METRIC_WAVES")) : 8;   // developer switch: 8 | 16
+  const int W = waves == 16 ? 16 : 8;
+  const int F = metric_rows_lds(pp, 16, W) <= kBudget ? 16 : metric_rows_lds(pp, 8, W) <= kBudget ? 8 : 4;
+  const size_t lds = metric_rows_lds(pp, F, W);
+  CVF_REQUIRE(lds <= kBudget, "cvf_metric_apply: %d feature-atom references need %zu B of LDS (> 158 KiB)", pp->n_ref, lds);
+  const int64_t groups = cvf_ntiles(B) * (CVF_TILE / F) * k;
+  CVF_REQUIRE(groups < (int64_t)1 << 31, "cvf_metric_apply: batch too large");
+  auto go = [&](auto kernel) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)groups), dim3(64 * W), lds, s, *pp, B, aux_tiled, a, k, slot_xyz, dense,
+                       g_tiled, q_tiled, e_tiled);
+  };
+  if (W == 16) {
+    if (F == 16) go(metric_rows_kernel<16, 16, 2>);
+    else if (F == 8) go(metric_rows_kernel<8, 16, 2>);
+    else go(metric_rows_kernel<4, 16, 2>);
+  } else {
+    if (F == 16) go(metric_rows_kernel<16, 8, 7>);
+    else if (F == 8) go(metric_rows_kernel<8, 8, 4>);
+    else go(metric_rows_kernel<4, 8, 2>);
+  }
+  return cvf_check_launch("metric_rows_kernel");
+}
+
+extern "C" int64_t cvf_metric_dense_doubles(const cvf_pp_desc* pp) {
+  return 42 + (pp && pp->slot_row ? 4 * (int64_t)pp->n_slot : 0);
 }
 
 extern "C" int cvf_metric_dense_tensors(const cvf_pp_desc* pp, const float* a, double* dense, void* stream) {

@@ -89,6 +89,17 @@ typedef struct cvf_pp_desc {
    *   align_w[b] = n_align * w_b / sum w   (mean 1), and ref_c[b] = align_w[b] * (ref_b - weighted centroid of ref),
    * flags must be 0 and 3 N must fit the lane-per-frame kernels (the layouts built for speed assume uniform weights). */
   const float* align_w;      /* [n_align] or NULL */
+  /* large molecules, derivative kernel (cvf_metric_apply; csrc/metric_large.hip): the scatter J^T g -> feature atoms as a table
+   * of rows.  Every (record, atom position) pair owns one row; the rows of one slot are contiguous:
+   *   slot_row[t] .. slot_row[t+1]-1 (slot_row[n_slot] = n_ref = total number of pairs, < 65536).
+   * mrec[r] = { (type + 1) | out_offset << 3, slot[0] | slot[1] << 16, slot[2] | slot[3] << 16, row[0] | row[1] << 16,
+   *             row[2] | row[3] << 16, urow[0] | urow[1] << 16, urow[2] | urow[3] << 16, 0 }   (16-byte aligned)
+   * with urow[p] = slot_row[slot[p]] (unused positions 0; n_slot, n_ref < 65536); records of one type side by side keep a
+   * wave on one code path. */
+  const int32_t* mrec;       /* [n_mrec*8] */
+  const int32_t* slot_row;   /* [n_slot+1] */
+  int32_t n_mrec;
+  int32_t n_ref;
 } cvf_pp_desc;
 
 /* k identical feed-forward nets (colvarsfinder.nn.EigenFunctions, nn.py:242-293) or one
@@ -148,7 +159,8 @@ const char* cvf_last_error(void);
  * (either may be NULL); aux_tiled [T][18][64] (may be NULL; identity mode ignores it).
  * Frames of thousands of atoms take the streaming path (one wave per frame, 8 frames per workgroup).
  * `scratch` (may be NULL; cvf_align_feature_scratch_bytes() bytes): on the streaming path it receives the compact
- * copy [padded frames][n_slot][3] of the atoms the features use, which cvf_metric_apply consumes as `slot_xyz`. */
+ * copy [T][n_slot*3][64] (coordinate rows of 64-frame tiles, like feat_tiled) of the atoms the features use, which
+ * cvf_metric_apply consumes as `slot_xyz`. */
 int64_t cvf_align_feature_scratch_bytes(const cvf_pp_desc* pp, int64_t B); /* 0 for small molecules */
 int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
                           float* aux_tiled, void* scratch, void* stream);
@@ -170,8 +182,11 @@ int cvf_metric_apply_stats(const cvf_pp_desc* pp, const float* x, int64_t B, con
                            int k, const float* g_tiled, float* q_tiled, float* e_tiled, const float* slot_xyz,
                            const double* dense, const cvf_ef_cfg* cfg, const float* w, const float* y_tiled,
                            double* scratch, double* stats, double* loss_vec, double* coef, void* stream);
-/* large molecules only (slot_xyz / dense may be NULL otherwise): dense[42] = moments of (a, ref) over the align atoms,
- * T0[c] = sum a_bc, T1[c][j] = sum a_bc ref_bj, T2[c][j][k] = sum a_bc ref_bj ref_bk, R1[j] = sum ref_bj (fp64). */
+/* large molecules only (slot_xyz / dense may be NULL otherwise): dense[cvf_metric_dense_doubles(pp)], prepared once per (pp, a):
+ * dense[0..41] = moments of (a, ref) over the align atoms, T0[c] = sum a_bc, T1[c][j] = sum a_bc ref_bj,
+ * T2[c][j][k] = sum a_bc ref_bj ref_bk, R1[j] = sum ref_bj (fp64); behind them n_slot x 8 floats of per-slot constants
+ * (a, ref, align flag, rows of the slot) for the derivative kernel. */
+int64_t cvf_metric_dense_doubles(const cvf_pp_desc* pp);
 int cvf_metric_dense_tensors(const cvf_pp_desc* pp, const float* a, double* dense, void* stream);
 
 /* --- packed MFMA weight fragments of the nets (a second copy of the weights in the order the

@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 def test_struct_layouts_match_the_header(built_lib):
     # sizes computed from include/cvf.h by hand: any drift between the C structs and ctypes breaks every call
-    assert ctypes.sizeof(built_lib.PPDesc) == 8 * 4 + 7 * 8 + 2 * 4 + 8
+    assert ctypes.sizeof(built_lib.PPDesc) == 8 * 4 + 7 * 8 + 2 * 4 + 8 + 2 * 8 + 2 * 4   # (+ mrec, slot_row, n_mrec, n_ref)
     assert ctypes.sizeof(built_lib.MLPDesc) == 4 * (2 + 13 + 12 + 2 * 8 * 12 + 1)
     assert ctypes.sizeof(built_lib.EFCfg) == 4 * 4 + 8 * 3 + 8 * 8
     assert ctypes.sizeof(built_lib.AdamArgs) == 3 * 8 + 4 * 8 + 4 * 8     # theta, m, v | lr, beta1, beta2, eps | step_count, mlp, packed, lr_dev

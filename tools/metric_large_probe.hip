@@ -13,7 +13,7 @@ size_t cvf_k1_large_scratch_bytes(const cvf_pp_desc* pp, int64_t B);
 
 int main(int argc, char** argv) {
   const int N = 5000, nc = 3 * N;
-  const int64_t B = argc > 1 ? atoll(argv[1]) : 20000;
+  const int64_t B = argc > 1 ? atoll(argv[1]) : 2000;
   std::mt19937 rng(5);
   std::normal_distribution<float> G(0.0f, 1.0f);
   std::vector<float> ref(nc);
@@ -60,6 +60,28 @@ int main(int argc, char** argv) {
   pp.rec_slot = (const int32_t*)up(rec_slot.data(), rec_slot.size() * 4); pp.slot_atom = (const int32_t*)up(slot_atom.data(), slot_atom.size() * 4);
   pp.n_slot = (int)used.size();
   pp.n_rec_slot = n_rec_slot;
+  {  // row tables of the derivative kernel (as pp.py builds them): rows sorted by (slot, record, position)
+    struct Pair { int slot, rec, pos; };
+    std::vector<Pair> pairs;
+    for (size_t i = 0; i < recs.size(); ++i)
+      for (int j = 0; j < natoms(recs[i][0]); ++j) pairs.push_back({atom_slot[recs[i][1 + j]], (int)i, j});
+    std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) {
+      return a.slot != b.slot ? a.slot < b.slot : a.rec != b.rec ? a.rec < b.rec : a.pos < b.pos; });
+    std::vector<int32_t> slot_row(used.size() + 1, 0), mrec(recs.size() * 8, 0), rowof(recs.size() * 4, 0);
+    for (size_t n = 0; n < pairs.size(); ++n) { slot_row[pairs[n].slot + 1]++; rowof[pairs[n].rec * 4 + pairs[n].pos] = (int)n; }
+    for (size_t t = 0; t < used.size(); ++t) slot_row[t + 1] += slot_row[t];
+    for (size_t i = 0; i < recs.size(); ++i) {
+      int32_t* m = &mrec[i * 8];
+      const int na = natoms(recs[i][0]);
+      int sl[4] = {0, 0, 0, 0}, rw[4] = {0, 0, 0, 0}, ur[4] = {0, 0, 0, 0};
+      for (int j = 0; j < na; ++j) { sl[j] = atom_slot[recs[i][1 + j]]; rw[j] = rowof[i * 4 + j]; ur[j] = slot_row[sl[j]]; }
+      m[0] = (recs[i][0] + 1) | (recs[i][5] << 3);
+      m[1] = sl[0] | (sl[1] << 16); m[2] = sl[2] | (sl[3] << 16); m[3] = rw[0] | (rw[1] << 16); m[4] = rw[2] | (rw[3] << 16);
+      m[5] = ur[0] | (ur[1] << 16); m[6] = ur[2] | (ur[3] << 16);
+    }
+    pp.mrec = (const int32_t*)up(mrec.data(), mrec.size() * 4); pp.slot_row = (const int32_t*)up(slot_row.data(), slot_row.size() * 4);
+    pp.n_mrec = (int)recs.size(); pp.n_ref = (int)pairs.size();
+  }
   const int64_t T = (B + 63) / 64;
   float *dx, *dfeat, *daux, *dslot;
   const size_t xb = (size_t)B * nc * 4;
@@ -82,7 +104,7 @@ int main(int argc, char** argv) {
     for (auto& v : g) v = G(rng);
     float *dg, *dq, *de, *da; double* ddense;
     (void)hipMalloc(&dg, g.size() * 4); (void)hipMalloc(&dq, g.size() * 4); (void)hipMalloc(&de, T * k * 64 * 4); (void)hipMalloc(&da, nc * 4);
-    (void)hipMalloc(&ddense, 42 * 8);
+    (void)hipMalloc(&ddense, cvf_metric_dense_doubles(&pp) * 8);
     (void)hipMemcpy(dg, g.data(), g.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(da, av.data(), nc * 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(metric_dense_kernel, dim3(1), dim3(256), 0, 0, pp, da, ddense);
@@ -97,26 +119,34 @@ int main(int argc, char** argv) {
     (void)hipEventElapsedTime(&ms, e0, e1);
     printf("metric_large B=%lld k=%d: %.1f us/launch\n", (long long)B, k, 1e3 * ms / reps);
     (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
-    const char* mn[10] = {"", "prologue (slots, tables, geometry)", "net 0: g staged", "net 0: VJP", "net 0: sums + dense part", "net 0: touched atoms", "net 0: sums + dR", "net 0: JVP", "net 0: flush", "nets 1..5"};
-    double am[10] = {0}; int c2 = 0;
-    for (int b = 0; b < 2000; ++b) {
-      const unsigned long long* q = &st[(b * 2) % 4096 * 64];
-      bool ok = q[20] != 0;
-      for (int i = 21; i <= 29; ++i) ok = ok && q[i] >= q[i - 1] && q[i] - q[i - 1] < 10000000ull;
-      if (!ok) continue;
-      for (int i = 1; i < 10; ++i) am[i] += double(q[20 + i] - q[19 + i]);
-      ++c2;
-    }
-    for (int i = 1; i < 10; ++i) printf("   %-36s %8.0f cycles\n", mn[i], am[i] / c2);
-    {
-      double v[4] = {0}; int c3 = 0;
+    const char* mn[7] = {"", "prologue (slot constants, aux)", "phase A: geometry + rows", "block sum", "dense + phase B: slots", "block sum", "phase C: q"};
+    for (int wv = 0; wv < CVF_STAMP_WPB; ++wv) {
+      double am[7] = {0}; int c2 = 0;
       for (int b = 0; b < 2000; ++b) {
-        const unsigned long long* q = &st[(b * 2) % 4096 * 64];
-        if (q[33] == 0 || q[33] < q[22] || q[33] - q[22] > 10000000ull) continue;
-        v[0] += double(q[30] - q[22]); v[1] += double(q[31] - q[30]); v[2] += double(q[32] - q[31]); v[3] += double(q[33] - q[32]);
-        ++c3;
+        const unsigned long long* q = &st[(size_t)((b * CVF_STAMP_WPB + wv) % 4096) * 64];
+        bool ok = q[20] != 0;
+        for (int i = 21; i <= 26; ++i) ok = ok && q[i] >= q[i - 1] && q[i] - q[i - 1] < 10000000ull;
+        if (!ok) continue;
+        for (int i = 1; i < 7; ++i) am[i] += double(q[20 + i] - q[19 + i]);
+        ++c2;
       }
-      printf("   VJP record batches: %.0f %.0f %.0f %.0f cycles\n", v[0] / c3, v[1] / c3, v[2] / c3, v[3] / c3);
+      printf(" wave %d (%d blocks sampled)\n", wv, c2);
+      double tot = 0;
+      for (int i = 1; i < 7; ++i) { printf("   %-36s %8.0f cycles\n", mn[i], am[i] / c2); tot += am[i] / c2; }
+      printf("   %-36s %8.0f cycles\n", "total", tot);
+      {   // phase B in detail: stamp 30 after the dense part, 31.. after each iteration of the slot loop
+        double d[9] = {0}; int c3 = 0;
+        for (int b = 0; b < 2000; ++b) {
+          const unsigned long long* q = &st[(size_t)((b * CVF_STAMP_WPB + wv) % 4096) * 64];
+          if (q[30] == 0 || q[30] < q[23] || q[36] < q[30] || q[36] - q[23] > 10000000ull) continue;
+          d[0] += double(q[30] - q[23]);
+          for (int i = 0; i < 6; ++i) d[1 + i] += double(q[31 + i] - q[30 + i]);
+          ++c3;
+        }
+        printf("   phase B: dense %.0f | iterations", d[0] / c3);
+        for (int i = 0; i < 6; ++i) printf(" %.0f", d[1 + i] / c3);
+        printf("\n");
+      }
     }
   }
   return 0;

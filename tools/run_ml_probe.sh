@@ -1,7 +1,11 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: builds tools/metric_large_probe.hip with the phase stamps; output to gpurun_out/r2/$1.
-mkdir -p gpurun_out/r2
-hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCVF_STAMPS -Iinclude -Icolvars-finder_amd/csrc -Wno-pass-failed \
-    tools/metric_large_probe.hip colvars-finder_amd/csrc/stats.hip colvars-finder_amd/csrc/k1_large.hip -o /tmp/metric_large_probe 2>gpurun_out/r2/ml_build.err || { tail -5 gpurun_out/r2/ml_build.err; exit 1; }
-timeout -k 10 120 /tmp/metric_large_probe > gpurun_out/r2/$1 2>&1 || { tail -5 gpurun_out/r2/$1; exit 1; }
-cat gpurun_out/r2/$1
+# Runs ON THE GPU BOX: tools/build/metric_large_probe (built here with the phase stamps, see the header of
+# tools/metric_large_probe.hip) at two batch sizes; output to gpurun_out/r3/$1.
+mkdir -p gpurun_out/r3
+for W in ${WAVES:-8 16}; do
+for B in 2000 16000; do
+  echo "== CVF_METRIC_WAVES=$W B=$B"
+  CVF_METRIC_WAVES=$W timeout -k 10 120 tools/build/metric_large_probe $B || exit 1
+done
+done > gpurun_out/r3/$1 2>&1
+cat gpurun_out/r3/$1

@@ -6,8 +6,9 @@
 #include <vector>
 #include <random>
 
-int main() {
-  const int k = 3, D = 66, H = 20, NHl = 3, B = 20000;
+int main(int argc, char** argv) {
+  // usage: stamp_ef [D] [k] [B]   (defaults: the dipeptide benchmark shape; 384 6 2000 = the config-5 shape)
+  const int D = argc > 1 ? atoi(argv[1]) : 66, k = argc > 2 ? atoi(argv[2]) : 3, H = 20, NHl = 3, B = argc > 3 ? atoi(argv[3]) : 20000;
   const int64_t T = (B + 63) / 64;
   cvf_mlp_desc m = {};
   m.n_nets = k; m.n_layers = NHl + 1;
@@ -41,7 +42,7 @@ int main() {
   const char* names[8] = {"start", "loads issued", "chunk0 done", "layer0 done", "chain+y done", "dchain done", "g done", "-"};
   double acc[8] = {0};
   int n = 0;
-  for (int b = 0; b < 1252 && b < 4096; ++b) {
+  for (int b = 0; b < 2 * T && b < 4096; ++b) {
     if (b & 1) continue;
     const unsigned long long* s = &st[b * 64];
     if (s[7] == 0) continue;
@@ -74,11 +75,22 @@ int main() {
       if (rc) { printf("bwd failed: %s\n", cvf_last_error()); return 1; }
     }
     hipDeviceSynchronize();
+    {
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      hipEventRecord(e0, nullptr);
+      for (int it = 0; it < 10; ++it) cvf_ef_backward(&cfg, &m, dth, dpk, B, dw, nullptr, dfeat, dy, dq, dcoef, dslab, nullptr, dsaved, nullptr);
+      hipEventRecord(e1, nullptr);
+      hipDeviceSynchronize();
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("cvf_ef_backward D=%d k=%d B=%d: %.1f us/launch\n", D, k, B, 100.0f * ms);
+    }
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
     const char* bn[11] = {"alpha", "fwd chain", "d+tangent", "last layer", "hbar init", "reverse l=2", "reverse l=1", "reverse l=0", "-", "flush", "end"};
     double ab[11] = {0};
     int nb = 0;
-    for (int b = 0; b < 626; ++b) {
+    for (int b = 0; b < 2 * T && b < 4096; ++b) {
       const unsigned long long* s = &st[b * 64];
       if (s[18] == 0 || s[8] == 0) continue;
       ab[0] += double(s[9] - s[8]); ab[1] += double(s[10] - s[9]); ab[2] += double(s[11] - s[10]); ab[3] += double(s[12] - s[11]);
