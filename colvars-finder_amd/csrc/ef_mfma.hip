@@ -795,25 +795,207 @@ __global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const 
   }
 }
 
-// Wide first layers, generator mode: the tangent chain's first product t0 = W0 q (K = d0) for one (half tile, net), ahead of
-// the backward kernel - there it was a just-in-time double-buffered loop (40 k cycles at d0 = 384: every chunk of three
-// k-steps waited a memory round trip, and the kernel has no registers left for a deeper ring), repeated by every block that
-// shares the (tile, net).  Output: one vector in the hand-off layout, behind the activations (see cvf_ef_saved_floats).
+// ------------------------------------------------------------------------------------------------
+// Wide first layers (d0 > kWideD: the large-molecule shapes, e.g. 384 features)
+// ------------------------------------------------------------------------------------------------
+// X += W0 [H x D] * in for one 64-frame tile, the k-steps shared out over the kWW waves of the block: a wave's operands
+// (12 k-steps = 36 loads at d0 = 384) are requested in one go, the partial sums meet in LDS and are added in wave order.
+// One wave per (half) tile walked the 96 k-steps of d0 = 384 behind a two-chunk operand ring - 16 dependent memory round
+// trips, 45 k of the forward kernel's 79 k cycles; a wave cannot keep more than 63 loads in flight, so a deeper ring does
+// not help, more waves do.  On return every wave holds the sum.
+constexpr int kWW = 8;
 template <int H>
-__global__ __launch_bounds__(64) void ef_t0_kernel(cvf_mlp_desc mlp, const float* __restrict__ packed,
-                                                    const float* __restrict__ q_tiled, float* __restrict__ t0_out) {
-  constexpr int FT = 2;
-  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
-  const int64_t tile = blockIdx.x / 2;
-  const int w = blockIdx.x % 2, net = blockIdx.y;
+__device__ __forceinline__ void wide_layer0(Vec<H, 4>& X, const float* __restrict__ pk0, int D,
+                                            const float* __restrict__ in_lane, int lane, int wave, float* part, float* tot) {
+  constexpr int RT = Hid<H>::RT, CH = 12, NV = RT * 16;
+  const int S = (D + 3) >> 2;
+  const int per = (S + kWW - 1) / kWW;
+  const int s_end = (wave + 1) * per < S ? (wave + 1) * per : S;
+  Vec<H, 4> P;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) P.v[rt][ft] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int s0 = wave * per; s0 < s_end; s0 += CH) {
+    L0Chunk<H, 4, CH> c;
+    load_l0chunk<H, 4, CH>(c, pk0, D, s_end, in_lane, s0, lane);   // (steps past s_end: clamped loads, zeroed weights)
+    __builtin_amdgcn_sched_barrier(0);   // all requests first: left alone, the scheduler sinks every load to its use (one round trip per k-step)
+    mul_l0chunk<H, 4, CH>(P, c);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(wave * NV + (rt * 4 + ft) * 4 + r) * 64 + lane] = P.v[rt][ft][r];
+  __syncthreads();
+  for (int i = wave; i < NV; i += kWW) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kWW; ++j) acc += part[(j * NV + i) * 64 + lane];
+    tot[i * 64 + lane] = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X.v[rt][ft][r] += tot[((rt * 4 + ft) * 4 + r) * 64 + lane];
+}
+template <int H>
+constexpr size_t wide_lds_bytes() { return (size_t)(kWW + 1) * Hid<H>::RT * 16 * 64 * sizeof(float); }
+
+// K4a for wide first layers: one block of kWW waves per (tile, net).  First layer by wide_layer0; the short rest of the chain
+// (hidden layers, y, the d chain) is repeated by every wave from the shared sum; the rows of g = W0^T d_0 (24 row tiles at
+// d0 = 384) are dealt to the waves.  Hands the hidden activations to the backward kernel like ef_fwd_wg_kernel.
+template <int H, int NH>
+__global__ __launch_bounds__(64 * kWW) void ef_fwd_wide_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
+                                                               const float* __restrict__ packed,
+                                                               const float* __restrict__ feat, float* __restrict__ y_tiled,
+                                                               float* __restrict__ g_tiled, float* __restrict__ saved) {
+  constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG, FT = 4, kGT = 3;
+  extern __shared__ float wide_lds[];
+  float* part = wide_lds;
+  float* tot = wide_lds + kWW * RT * 16 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q = lane >> 4;
+  const int64_t tile = blockIdx.x;
+  const int net = blockIdx.y;
+  const int k = mlp.n_nets, D = mlp.dims[0];
+  const int CT = (D + 15) >> 4;
+  const PackLayout L = pack_layout(H, NH, D);
+  const float* pk = packed + (int64_t)net * L.per_net;
+  const int fo = 4 * col;
+  const float* in_lane = feat + tile * (int64_t)D * CVF_TILE + fo;
+  const bool want_g = g_tiled != nullptr;
+  CVF_STAMP(0);
+  // everything the rest of the chain needs is requested before the first layer
+  HConst<H> bias[NH];
+#pragma unroll
+  for (int l = 0; l < NH; ++l) load_hconst<H>(bias[l], theta + mlp.b_off[net][l], q);
+  HFrag<H> hf[NH > 1 ? NH - 1 : 1], tf[NH > 1 ? NH - 1 : 1];
+#pragma unroll
+  for (int l = 1; l < NH; ++l) load_hfrag<H>(hf[l - 1], pk + L.fh(l), lane);
+  float wl[RT][4];
+  load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
+  const float bL = theta[mlp.b_off[net][NH]];
+  const float* pT0 = pk + L.t0();
+  float t0f[kGT][NG];   // W0^T fragments of this wave's first kGT row tiles of g
+  if (want_g) {
+#pragma unroll
+    for (int l = 1; l < NH; ++l) load_hfrag<H>(tf[l - 1], pk + L.th(l), lane);
+#pragma unroll
+    for (int i = 0; i < kGT; ++i) {
+      const int rt = wave + kWW * i < CT ? wave + kWW * i : CT - 1;
+#pragma unroll
+      for (int s = 0; s < NG; ++s) t0f[i][s] = pT0[(rt * NG + s) * 64 + lane];
+    }
+  }
+  CVF_STAMP(1);
+  Vec<H, FT> h[NH];
+  set_const<H, FT>(h[0], bias[0]);
+  wide_layer0<H>(h[0], pk + L.f0(), D, in_lane, lane, wave, part, tot);
+  CVF_STAMP(2);
+  tanh_inplace<H, FT>(h[0], mlp.act[0]);
+#pragma unroll
+  for (int l = 1; l < NH; ++l) {
+    set_const<H, FT>(h[l], bias[l]);
+    hidden_mul<H, FT>(h[l], hf[l - 1], h[l - 1]);
+    tanh_inplace<H, FT>(h[l], mlp.act[0]);
+  }
+  CVF_STAMP(3);
+  if (wave == 0) {
+    float yv[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      float p = 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p = fmaf(wl[rt][r], h[NH - 1].v[rt][ft][r], p);
+      yv[ft] = sum_over_q(p) + bL;
+    }
+    if (q == 0) store_frames<FT>(y_tiled + (tile * k + net) * CVF_TILE + fo, yv);
+  }
+  if (saved != nullptr) {
+    float* sv = saved + (tile * k + net) * (int64_t)(NH * saved_per_vec<H>());
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+      if (wave == 1 + l % (kWW - 1)) save_vec<H>(sv + l * saved_per_vec<H>(), h[l], lane);
+  }
+  CVF_STAMP(4);
+  if (!want_g) return;
+  Vec<H, FT> d;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = h[NH - 1].v[rt][ft][r];
+        d.v[rt][ft][r] = wl[rt][r] * act_d1(mlp.act[0], hv);
+      }
+#pragma unroll
+  for (int l = NH - 1; l >= 1; --l) {
+    Vec<H, FT> e;
+    init_bias<H, FT>(e, nullptr, q);
+    hidden_mul<H, FT>(e, tf[l - 1], d);
+    tangent_of<H, FT>(d, h[l - 1], e, mlp.act[0]);
+  }
+  CVF_STAMP(5);
+  float* gout = g_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + fo;
+  auto g_tile = [&](int rt, const float (&af)[NG]) {
+    f32x4 acc[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) acc[ft] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < NG; ++s)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) acc[ft] = mfma4(af[s], d.v[s >> 2][ft][s & 3], acc[ft]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * rt + 4 * q + r;
+      if (i < D) {
+        float gv[FT];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) gv[ft] = acc[ft][r];
+        store_frames<FT>(gout + (int64_t)i * CVF_TILE, gv);
+      }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < kGT; ++i)
+    if (wave + kWW * i < CT) g_tile(wave + kWW * i, t0f[i]);   // (wave-uniform)
+  for (int rt = wave + kWW * kGT; rt < CT; rt += kWW) {   // wider still: the remaining row tiles just in time
+    float af[NG];
+#pragma unroll
+    for (int s = 0; s < NG; ++s) af[s] = pT0[(rt * NG + s) * 64 + lane];
+    g_tile(rt, af);
+  }
+  CVF_STAMP(6);
+  CVF_STAMP(7);
+}
+
+// Generator mode: the tangent chain's first product t0 = W0 q (K = d0) for one (tile, net), ahead of the backward kernel -
+// there it was a just-in-time double-buffered loop (40 k cycles at d0 = 384, and the kernel has no registers left for more
+// operands in flight), repeated by every block that shares the (tile, net).  Output: one vector in the hand-off layout, behind
+// the activations (see cvf_ef_saved_floats).
+template <int H>
+__global__ __launch_bounds__(64 * kWW) void ef_t0_kernel(cvf_mlp_desc mlp, const float* __restrict__ packed,
+                                                         const float* __restrict__ q_tiled, float* __restrict__ t0_out) {
+  extern __shared__ float wide_lds[];
+  constexpr int RT = Hid<H>::RT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q = lane >> 4;
+  const int64_t tile = blockIdx.x;
+  const int net = blockIdx.y;
   const int k = mlp.n_nets, D = mlp.dims[0];
   const PackLayout L = pack_layout(H, mlp.n_layers - 1, D);
   const float* pk = packed + (int64_t)net * L.per_net;
-  const float* in_lane = q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + 4 * col + 2 * w;
-  Vec<H, FT> t;
-  init_bias<H, FT>(t, nullptr, q);
-  layer0_apply_deep<H, FT, 6, 3>(t, pk + L.f0(), D, in_lane, lane);
-  save_vec_half<H>(t0_out + (tile * k + net) * (int64_t)saved_per_vec<H>(), t, w, lane);
+  const float* in_lane = q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + 4 * col;
+  Vec<H, 4> t;
+  init_bias<H, 4>(t, nullptr, q);
+  wide_layer0<H>(t, pk + L.f0(), D, in_lane, lane, wave, wide_lds, wide_lds + kWW * RT * 16 * 64);
+  if (wave == 0) save_vec<H>(t0_out + (tile * k + net) * (int64_t)saved_per_vec<H>(), t, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -825,7 +1007,8 @@ struct EfBwdArgs {
   int64_t B;
   int64_t T;
   int64_t n_tiles;
-  int zs;             // blocks that share a (tile, net): block z takes the first layer's column tiles ct = z (mod zs)
+  int zs;             // blocks that share a (tile, net): block z takes the first layer's column tiles ct = z (mod zs) and the layers l = z (mod zs)
+  int direct0;        // one tile per block (grid.x == n_tiles): first-layer gradient tiles go straight to the slab row, no LDS image of W0
   const float* t0;    // wide first layers: t0 = W0 q of every (tile, net), computed by ef_t0_kernel (else NULL)
 };
 
@@ -872,9 +1055,13 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
   const bool tangent = args.lag_idx == 0;
   const int gbase = mlp.w_off[net][0];
   const int gspan = mlp.b_off[net][NH] + 1 - gbase;
+  // direct0: the image starts behind the first layer (W0, b0 lead a net's run - checked by the host); GIs is indexed like GI
+  const int gi_off = args.direct0 ? mlp.b_off[net][0] - gbase + H : 0;
+  float* GIs = GI - gi_off;
+  float* out0 = slab + (int64_t)blockIdx.x * mlp.n_params + gbase;   // this block's slab row, this net's run
 
   for (int i = tid; i < kRows * kPitch; i += NT) IMG[i] = 0.0f;
-  for (int i = tid; i < gspan; i += NT) GI[i] = 0.0f;
+  for (int i = tid; i < gspan - gi_off; i += NT) GI[i] = 0.0f;
   __syncthreads();
   if (tid < 64) SB1[H * kPitch + tid] = 1.0f;  // bias column of [h ; 1]  (row H of SB2 stays 0)
 
@@ -907,8 +1094,21 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
     for (int r = 0; r < 4; ++r) {
       const int o = 16 * rt + r0 + r;
       if (o < n_out) {
-        if (i < n_in) GI[wo + o * n_in + i] += acc[r];
-        else if (i == n_in) GI[bo + o] += acc[r];
+        if (i < n_in) GIs[wo + o * n_in + i] += acc[r];
+        else if (i == n_in) GIs[bo + o] += acc[r];
+      }
+    }
+  };
+  // first layer, one tile per block: the finished tile is this block's whole contribution - straight to the slab row
+  auto put_tile0 = [&](int rt, int ct, const f32x4& acc) {
+    const int wo = mlp.w_off[net][0] - gbase, bo = mlp.b_off[net][0] - gbase;
+    const int i = 16 * ct + row16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 16 * rt + r0 + r;
+      if (o < H) {
+        if (i < D) out0[wo + o * D + i] = acc[r];
+        else if (i == D) out0[bo + o] = acc[r];
       }
     }
   };
@@ -1042,7 +1242,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
     CVF_STAMP(11);
     // ---- last layer (1 x H):  W_L += sum alpha h_{NH-1} + tdot_{NH-1} ; b_L += sum alpha
     {
-      if (z == 0) {
+      const bool mine = z == NH % zs;   // the block that owns the last layer's gradient
+      if (mine) {
         if (q == 0) {
 #pragma unroll
           for (int ft = 0; ft < FT; ++ft) {
@@ -1058,13 +1259,13 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
         }
       }
       __syncthreads();
-      for (int ct = wave; ct < CTH && z == 0; ct += WPB) {
+      for (int ct = wave; ct < CTH && mine; ct += WPB) {
         const f32x4 acc = outer_tile(SA1, SB1, SA2, SB2, 0, ct, tangent, lane);
         if (q == 0) {  // output row 0 lives in register 0 of lanes 0..15
           const int wo = mlp.w_off[net][NH] - gbase, bo = mlp.b_off[net][NH] - gbase;
           const int i = 16 * ct + row16;
-          if (i < H) GI[wo + i] += acc[0];
-          else if (i == H) GI[bo] += acc[0];
+          if (i < H) GIs[wo + i] += acc[0];
+          else if (i == H) GIs[bo] += acc[0];
         }
       }
       __syncthreads();
@@ -1111,7 +1312,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
               zbar.v[rt][ft][r] = zb;
             }
           }
-      if (l == 0 || z == 0) {
+      const bool mine = z == l % zs;   // the block that owns layer l's gradient (l >= 1; the first layer is shared by column tile)
+      if (l == 0 || mine) {
         store_image<H, FT, false>(SA1, zbar, one, lane, fo);
         if (tangent) {
           if (l == 0) store_image<H, FT, true>(SA2, dl, gamma, lane, fo);
@@ -1119,7 +1321,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
         }
       }
       if (l > 0) {
-        if (z == 0) {
+        if (mine) {
           store_image<H, FT, false>(SB1, h[l - 1], one, lane, fo);
           if (tangent) {
             Vec<H, FT> td;
@@ -1128,7 +1330,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
           }
         }
         __syncthreads();
-        for (int pr = wave; pr < RTO * CTH && z == 0; pr += WPB) {
+        for (int pr = wave; pr < RTO * CTH && mine; pr += WPB) {
           const int rt = pr / CTH, ct = pr - rt * CTH;
           add_tile(l, H, H, rt, ct, outer_tile(SA1, SB1, SA2, SB2, rt, ct, tangent, lane));
         }
@@ -1212,7 +1414,10 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
           }
 #pragma unroll
           for (int rt = 0; rt < RTO; ++rt)
-            if (rt >= rt0 && (rt - rt0) % rstep == 0) add_tile(0, H, D, rt, ct, acc[rt]);
+            if (rt >= rt0 && (rt - rt0) % rstep == 0) {
+              if (args.direct0) put_tile0(rt, ct, acc[rt]);
+              else add_tile(0, H, D, rt, ct, acc[rt]);
+            }
         };
         if constexpr (WPB == 2) {   // this block's column tiles z, z + zs, ...: whole ones dealt to the waves, an odd last one split by row tile
           const int nz = z < CT1 ? (CT1 - z + zs - 1) / zs : 0;
@@ -1230,19 +1435,24 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : WPB) void ef_bwd_mfma_kern
   CVF_STAMP(17);
   // ---- flush this block's partial gradient of `net` into its slab row
   __syncthreads();
-  float* out = slab + (int64_t)blockIdx.x * mlp.n_params + gbase;
-  if (zs == 1) {
+  float* out = out0;
+  if (zs == 1 && !args.direct0) {
     for (int i = tid; i < gspan; i += NT) out[i] = GI[i];
-  } else {   // the zs blocks of this (row, net) write disjoint parts of the row: layer-0 columns by column tile, the rest block 0
+  } else {   // the zs blocks of this (row, net) write disjoint parts of the row
     const int w0 = mlp.w_off[net][0] - gbase, b0 = mlp.b_off[net][0] - gbase;
-    for (int ct = z; ct < CT1; ct += zs)
-      for (int e = tid; e < 16 * H; e += NT) {
-        const int o = e >> 4, i = 16 * ct + (e & 15);
-        if (i < D) out[w0 + o * D + i] = GI[w0 + o * D + i];
-        else if (i == D) out[b0 + o] = GI[b0 + o];
+    if (!args.direct0)   // first layer by column tile
+      for (int ct = z; ct < CT1; ct += zs)
+        for (int e = tid; e < 16 * H; e += NT) {
+          const int o = e >> 4, i = 16 * ct + (e & 15);
+          if (i < D) out[w0 + o * D + i] = GI[w0 + o * D + i];
+          else if (i == D) out[b0 + o] = GI[b0 + o];
+        }
+    for (int l = 1; l <= NH; ++l)   // the layers this block owns
+      if (z == l % zs) {
+        const int wo = mlp.w_off[net][l] - gbase, bo = mlp.b_off[net][l] - gbase, n_out = l < NH ? H : 1;
+        for (int i = tid; i < n_out * H; i += NT) out[wo + i] = GIs[wo + i];
+        for (int i = tid; i < n_out; i += NT) out[bo + i] = GIs[bo + i];
       }
-    if (z == 0)   // (a net's parameters are W0, b0, W1, ... in this order: everything behind b0)
-      for (int i = b0 + H + tid; i < gspan; i += NT) out[i] = GI[i];
   }
   // one gradient per optimiser step: advance the step counter read by the Adam that follows
   if (step != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && z == 0 && tid == 0) *step += 1;
@@ -1424,7 +1634,12 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
   CVF_REQUIRE(saved == nullptr || cvf_ef_saved_floats(mlp, 1) > 0, "cvf_ef_mlp_fwd: this shape has no activation hand-off (cvf_ef_saved_floats() == 0)");
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    if (wg) {
+    if (mlp->dims[0] > kWideD && getenv("CVF_NO_FWD_WIDE") == nullptr) {
+      (void)hipFuncSetAttribute((const void*)ef_fwd_wide_kernel<kH, kNH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)wide_lds_bytes<kH>());
+      hipLaunchKernelGGL((ef_fwd_wide_kernel<kH, kNH>), dim3((unsigned)n_tiles, mlp->n_nets), dim3(64 * kWW), wide_lds_bytes<kH>(),
+                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled, saved);
+    } else if (wg) {
       if (wlds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)ef_fwd_wg_kernel<kH, kNH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
       hipLaunchKernelGGL((ef_fwd_wg_kernel<kH, kNH>), dim3((unsigned)((n_tiles + 3) / 4), mlp->n_nets), dim3(256), wlds,
@@ -1594,6 +1809,7 @@ static int ef_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, cons
   a.zs = wide ? (int)(want < 1 ? 1 : want > 4 ? 4 : want) : 1;
   if (getenv("CVF_BWD_ZS")) a.zs = atoi(getenv("CVF_BWD_ZS")) > 0 && wide ? atoi(getenv("CVF_BWD_ZS")) : a.zs;   // developer switch
   a.t0 = nullptr;
+  a.direct0 = wide && G == a.n_tiles && getenv("CVF_BWD_NO_DIRECT") == nullptr ? 1 : 0;
   dim3 grid((unsigned)G, cfg->k, a.zs);
   // the LDS gradient image relies on each net's parameters being one contiguous run of the flat buffer
   const int span = mlp->b_off[0][NH] + 1 - mlp->w_off[0][0];
@@ -1607,19 +1823,24 @@ static int ef_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, cons
   }
   CVF_REQUIRE(covered == mlp->n_params, "cvf_ef_backward: flat buffer holds parameters outside the nets");
   // (the shared-out flush assumes the usual order W0, b0, W1, ... inside a net's run)
-  for (int n = 0; n < mlp->n_nets && a.zs > 1; ++n) {
-    if (mlp->b_off[n][0] != mlp->w_off[n][0] + H * mlp->dims[0]) a.zs = 1;
+  for (int n = 0; n < mlp->n_nets && (a.zs > 1 || a.direct0); ++n) {
+    bool usual = mlp->b_off[n][0] == mlp->w_off[n][0] + H * mlp->dims[0];
     for (int l = 1; l <= NH; ++l)
-      if (mlp->w_off[n][l] < mlp->b_off[n][0] + H || mlp->b_off[n][l] < mlp->b_off[n][0] + H) a.zs = 1;
+      usual = usual && mlp->w_off[n][l] >= mlp->b_off[n][0] + H && mlp->b_off[n][l] >= mlp->b_off[n][0] + H;
+    if (!usual) {
+      a.zs = 1;
+      a.direct0 = 0;
+    }
   }
   grid.z = a.zs;
-  const size_t lds_dyn = (size_t)span * sizeof(float);
+  const size_t lds_dyn = (size_t)(span - (a.direct0 ? H * mlp->dims[0] + H : 0)) * sizeof(float);
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
     if (saved != nullptr && wide && cfg->lag_idx == 0 && getenv("CVF_NO_T0") == nullptr) {
       float* t0 = const_cast<float*>(saved) + a.n_tiles * cfg->k * (int64_t)(kNH * saved_per_vec<kH>());   // (behind the activations)
-      hipLaunchKernelGGL((ef_t0_kernel<kH>), dim3((unsigned)(2 * a.T), cfg->k), dim3(64), 0, (hipStream_t)stream, *mlp, packed,
-                         q_tiled, t0);
+      (void)hipFuncSetAttribute((const void*)ef_t0_kernel<kH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes<kH>());
+      hipLaunchKernelGGL((ef_t0_kernel<kH>), dim3((unsigned)a.T, cfg->k), dim3(64 * kWW), wide_lds_bytes<kH>(), (hipStream_t)stream,
+                         *mlp, packed, q_tiled, t0);
       a.t0 = t0;
     }
     if (saved != nullptr)
