@@ -16,6 +16,14 @@
 namespace {
 
 constexpr int kGroup = 8;  // waves = frames per workgroup
+// Workgroups go round the 8 XCDs by blockIdx.  The eight workgroups of a 64-frame tile each write 32 bytes of every row of the tiled
+// outputs ([tile][d_r][64] features, [tile][18][64] rotation rows): on eight different XCDs these stay eight partial lines in eight
+// L2s, on ONE XCD they meet in its L2 and leave as whole lines.  The map keeps consecutive frame groups on one XCD.
+__device__ __forceinline__ int64_t k1_group_of_block(bool same_xcd) {
+  if (!same_xcd) return blockIdx.x;
+  const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7, ix = blockIdx.x >> 3;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ix;
+}
 
 struct Rec {
   int type, a0, a1, a2, a3, out;
@@ -195,14 +203,18 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
     cD[tid][0] = c0; cD[tid][1] = c1; cD[tid][2] = c2;
   } else if (slot_xyz != nullptr && tid >= 64) {
     // meanwhile the other waves write the compact copy of the feature atoms for the derivative kernel (metric_large.hip), which
-    // works with one frame per lane: coordinate rows of the 64-frame tile, [tile][n_slot * 3][64] - this workgroup's kGroup
-    // frames are kGroup consecutive floats (32 bytes) of every row
+    // works with one frame per lane: coordinate rows of this workgroup's kGroup frames, [frame group][n_slot * 3][kGroup] - one
+    // contiguous run per workgroup, written in 16-byte pieces.  (As rows of the 64-frame tile - 32 bytes per row and workgroup -
+    // the partial lines of eight workgroups cost 1406-1733 us per 100 000 frames against 1231-1321 us.)
+    static_assert(kGroup == 8, "two 16-byte pieces per row");
+    typedef float nt4 __attribute__((ext_vector_type(4)));
     const float* img = capL - (size_t)fi * nslot * 3;      // [kGroup][nslot * 3]
     const int ns3 = nslot * 3;
-    float* dst = slot_xyz + (f0 / CVF_TILE) * (int64_t)ns3 * CVF_TILE + (int)(f0 % CVF_TILE);
-    for (int i = tid - 64; i < kGroup * ns3; i += 64 * (kGroup - 1)) {
-      const int fr = i % kGroup, row = i / kGroup;
-      dst[(int64_t)row * CVF_TILE + fr] = img[fr * ns3 + row];
+    nt4* dst = reinterpret_cast<nt4*>(slot_xyz + (f0 / kGroup) * (int64_t)ns3 * kGroup);
+    for (int i = tid - 64; i < 2 * ns3; i += 64 * (kGroup - 1)) {
+      const int row = i >> 1, fr = 4 * (i & 1);
+      const nt4 v = {img[fr * ns3 + row], img[(fr + 1) * ns3 + row], img[(fr + 2) * ns3 + row], img[(fr + 3) * ns3 + row]};
+      __builtin_nontemporal_store(v, dst + i);   // written once, read by a later kernel
     }
   }
   __syncthreads();
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
   const int nc = pp.n_coord, nal = pp.n_align, nslot = pp.n_slot, N = nc / 3;
   float* capL = dyn + (size_t)fi * nslot * 3;
   float* featL = dyn + (size_t)kGroup * nslot * 3;
-  const int64_t f0 = (int64_t)blockIdx.x * kGroup;
+  const int64_t f0 = k1_group_of_block(slot_xyz != nullptr || feat_tiled != nullptr || aux_tiled != nullptr) * kGroup;
   const bool real = f0 + fi < B;
   const int64_t frame = real ? f0 + fi : B - 1;
   const float* __restrict__ xf = x + frame * nc;
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc
   const int nq = N >> 2, nqa = nal >> 2;
   float* featL = dyn + (size_t)kGroup * nslot * 3;
   float* red = featL + w * (4 * kRedPitch);       // wave-private, reused by the feature staging later
-  const int64_t f0 = (int64_t)blockIdx.x * kGroup;
+  const int64_t f0 = k1_group_of_block(slot_xyz != nullptr || feat_tiled != nullptr || aux_tiled != nullptr) * kGroup;
   CVF_STAMP(0);
   // ---- this lane's atoms: reference rows, capture slots (registers for the whole batch)
   const float4* __restrict__ r4 = reinterpret_cast<const float4*>(pp.ref_c);
@@ -497,7 +509,7 @@ static bool capture_ok(const cvf_pp_desc* pp, bool tiled) {
   const size_t ldsc = ((size_t)kGroup * pp->n_slot * 3 + (tiled ? (size_t)pp->d_r * kGroup : 0)) * sizeof(float);
   return ldsc <= 150 * 1024;
 }
-// bytes of the compact feature-atom copy [tiles][n_slot * 3][64] written when `scratch` is given
+// bytes of the compact feature-atom copy [frame groups of 8][n_slot * 3][8] written when `scratch` is given
 size_t cvf_k1_large_scratch_bytes(const cvf_pp_desc* pp, int64_t B) {
   return capture_ok(pp, true) ? (size_t)cvf_ntiles(B) * CVF_TILE * pp->n_slot * 3 * sizeof(float) : 0;
 }

@@ -16,7 +16,7 @@
 //   * one workgroup = F frames (16 when the table below fits the LDS) x ONE net; a lane is (frame f = lane % F, group = lane / F),
 //     the 64/F groups of the 16 waves ("lane groups") share out the RECORDS (phases A, C) and the SLOTS (phase B).  Every table
 //     index is uniform over a group's F lanes, every global access is F consecutive floats of a [row][64 frames] tile
-//     (g, q, aux and - written that way by K1 - the slot coordinates), and sums over records / slots are plain per-lane sums
+//     (g, q, aux; the slot coordinates in K1's groups of eight frames), and sums over records / slots are plain per-lane sums
 //     followed by ONE fixed-order reduction over the lane groups per phase: no cross-lane work inside the loops.
 //   * the scatter J^T g -> slots is a table of contribution rows in LDS, [n_ref][3][F]: atom p of record r owns row
 //     mrec[r].row[p] (nobody else writes it), and the rows of one slot are contiguous (slot_row[t] .. slot_row[t+1]) - phase A
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
   for (int i = 0; i < 3; ++i) c[i] = ax[(9 + i) * CVF_TILE];
 #pragma unroll
   for (int i = 0; i < 6; ++i) Kinv[i] = ax[(12 + i) * CVF_TILE];
-  const float* xs = slot_xyz + tile * (int64_t)ns * 3 * CVF_TILE + l0;     // [ns * 3][64] of this tile
+  const float* xs = slot_xyz + ((f0 + f) >> 3) * (int64_t)ns * 3 * 8 + ((f0 + f) & 7);   // [frame group of 8][ns * 3][8] (K1's copy)
   const float* gt = g_tiled + (tile * k + net) * (int64_t)d_r * CVF_TILE + l0;
   float* qt = q_tiled + (tile * k + net) * (int64_t)d_r * CVF_TILE + l0;
   // per-slot constants [ns][8] = a (3), ref (3, zero off the align set), align flag, rows (start | count << 20), prepared once
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) o.x[3 * p + cc] = xs[(int64_t)(3 * sl[p] + cc) * CVF_TILE];
+      for (int cc = 0; cc < 3; ++cc) o.x[3 * p + cc] = xs[(3 * sl[p] + cc) * 8];
     const int out = ri.to >> 3;
 #pragma unroll
     for (int j = 0; j < 3; ++j) o.g[j] = gt[(int64_t)(out + j < d_r ? out + j : d_r - 1) * CVF_TILE];

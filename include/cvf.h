@@ -159,7 +159,7 @@ const char* cvf_last_error(void);
  * (either may be NULL); aux_tiled [T][18][64] (may be NULL; identity mode ignores it).
  * Frames of thousands of atoms take the streaming path (one wave per frame, 8 frames per workgroup).
  * `scratch` (may be NULL; cvf_align_feature_scratch_bytes() bytes): on the streaming path it receives the compact
- * copy [T][n_slot*3][64] (coordinate rows of 64-frame tiles, like feat_tiled) of the atoms the features use, which
+ * copy [padded frames / 8][n_slot*3][8] (coordinate rows of groups of eight frames) of the atoms the features use, which
  * cvf_metric_apply consumes as `slot_xyz`. */
 int64_t cvf_align_feature_scratch_bytes(const cvf_pp_desc* pp, int64_t B); /* 0 for small molecules */
 int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
