@@ -26,7 +26,7 @@ def ef_widths(n_hidden):
 
 FEAT_ANGLE, FEAT_BOND, FEAT_DIHEDRAL, FEAT_POSITION = 0, 1, 2, 3
 PP_IDENTITY, PP_ALIGN = 0, 1
-PP_ALIGN_CONTIG, PP_PURE_POSITION, PP_SLOT_BATCHED, PP_SLOT_DISJOINT = 1, 2, 4, 8
+PP_ALIGN_CONTIG, PP_PURE_POSITION, PP_SLOT_BATCHED = 1, 2, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcvf_hip.so")

@@ -28,24 +28,17 @@ def _ix(atom_group):
     return np.asarray(atom_group.ix if hasattr(atom_group, "ix") else atom_group, dtype=np.int64)
 
 
-def _batch_records(recs, width=64, disjoint=False):
-    """Greedy packing of slot records ``[type, s0, s1, s2, s3, out]`` into batches of ``width`` such that, inside a
-    batch, no (atom position, slot) pair occurs twice - ``disjoint``: no slot occurs twice at all (CVF_PP_SLOT_DISJOINT);
-    short batches are padded with ``type = -1`` entries."""
-    natoms = {_hip.FEAT_POSITION: 1, _hip.FEAT_BOND: 2, _hip.FEAT_ANGLE: 3, _hip.FEAT_DIHEDRAL: 4}
-    batches = []   # [records, set of (position, slot)]
-    for r in recs:
-        keys = {((0 if disjoint else j), r[1 + j]) for j in range(natoms[r[0]])}
-        for b in batches:
-            if len(b[0]) < width and b[2] == r[0] and not (keys & b[1]):
-                b[0].append(r)
-                b[1] |= keys
-                break
-        else:
-            batches.append([[r], set(keys), r[0]])
-    out = []
-    for b in batches:
-        out += b[0] + [[-1, 0, 0, 0, 0, 0]] * (width - len(b[0]))
+def _batch_records(recs, width=64):
+    """Slot records ``[type, s0, s1, s2, s3, out]``, sorted by type, in batches of ``width`` of ONE type (the streaming
+    alignment kernel hands a batch to the lanes of a wave: one code path per wave); short batches are padded with
+    ``type = -1`` entries (CVF_PP_SLOT_BATCHED)."""
+    out, i = [], 0
+    while i < len(recs):
+        j = i
+        while j < len(recs) and recs[j][0] == recs[i][0] and j - i < width:
+            j += 1
+        out += [list(r) for r in recs[i:j]] + [[-1, 0, 0, 0, 0, 0]] * (width - (j - i))
+        i = j
     return out
 
 
@@ -137,18 +130,13 @@ class AlignFeatureLayer(torch.nn.Module):
         for r in rec:
             na = 1 if r[0] == _hip.FEAT_POSITION else _TYPE_NATOMS[{v: k_ for k_, v in _TYPE_ID.items()}[r[0]]]
             rec_slot.append([r[0]] + [int(atom_slot[a]) for a in r[1:1 + na]] + [0] * (4 - na) + [r[5]])
-        # the streaming kernels hand one record to each lane, 64 at a time: records of one type side by side keep a
-        # wave's lanes on one code path, and a batch in which no two records name the same slot in the same atom
-        # position lets the derivative kernel scatter without atomics (CVF_PP_SLOT_BATCHED; the output offset travels
-        # with the record, so the order is free; type -1 entries are padding)
+        # the streaming kernel hands one record to each lane, 64 at a time: records of one type side by side keep a
+        # wave's lanes on one code path (CVF_PP_SLOT_BATCHED; the output offset travels with the record, so the order is
+        # free; type -1 entries are padding)
         by_type = sorted(rec_slot, key=lambda r: r[0])
         rec_slot = _batch_records(by_type)
-        strict = _batch_records(by_type, disjoint=True)   # batches whose records share no atom at all, when that costs no extra batch
         if w_hat is None:
             self._flags |= _hip.PP_SLOT_BATCHED
-            if len(strict) <= len(rec_slot):
-                rec_slot = strict
-                self._flags |= _hip.PP_SLOT_DISJOINT
         self._n_rec_slot = len(rec_slot)
         self._n_slot = len(used)
         # the derivative kernel of large molecules (csrc/metric_large.hip) scatters J^T g through a table of rows: one row per
@@ -166,8 +154,10 @@ class AlignFeatureLayer(torch.nn.Module):
             rows = [row_of[(i, j)] for j in range(na)] + [0] * (4 - na)
             ur = [int(slot_row[r[1 + j]]) for j in range(na)] + [0] * (4 - na)
             sl = list(r[1:5])
-            mrec.append([(r[0] + 1) | (r[5] << 3), sl[0] | (sl[1] << 16), sl[2] | (sl[3] << 16), rows[0] | (rows[1] << 16),
-                         rows[2] | (rows[3] << 16), ur[0] | (ur[1] << 16), ur[2] | (ur[3] << 16), 0])
+            off = [rows[j] - ur[j] if j < na else 0 for j in range(4)]     # position of this record among its atom's rows
+            self._row_off_max = max(getattr(self, "_row_off_max", 0), max(off))
+            mrec.append([(r[0] + 1) | (r[5] << 3), sl[0] | (sl[1] << 16), sl[2] | (sl[3] << 16), ur[0] | (ur[1] << 16),
+                         ur[2] | (ur[3] << 16), off[0] | (off[1] << 8) | (off[2] << 16) | (off[3] << 24), 0, 0])
         self._n_ref = len(pairs)
         self.register_buffer("mrec", torch.tensor(np.asarray(mrec, dtype=np.int64).astype(np.uint32).view(np.int32)
                                                   if mrec else np.zeros((0, 8), np.int32)).reshape(-1, 8))
@@ -197,7 +187,7 @@ class AlignFeatureLayer(torch.nn.Module):
         d.atom_align, d.atom_slot, d.rec_slot = self.atom_align.data_ptr(), self.atom_slot.data_ptr(), self.rec_slot.data_ptr()
         d.slot_atom, d.n_slot, d.n_rec_slot = self.slot_atom.data_ptr(), self._n_slot, self._n_rec_slot
         d.align_w = self.align_w.data_ptr() if self.align_w is not None else None
-        if self._n_ref < 65536 and self._n_slot < 65536:
+        if self._n_ref < 65536 and self._n_slot < 65536 and getattr(self, "_row_off_max", 0) < 256:   # (else: cvf_metric_apply names what is missing)
             d.mrec, d.slot_row, d.n_mrec, d.n_ref = self.mrec.data_ptr(), self.slot_row.data_ptr(), self.mrec.shape[0], self._n_ref
         return d
 

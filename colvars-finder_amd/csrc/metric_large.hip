@@ -29,13 +29,14 @@
 namespace {
 
 constexpr int kNRed = 13;        // values per block reduction (phase A: 12, phase B: 13)
-constexpr int kMrecInts = 8;     // mrec entry (include/cvf.h): (type + 1) | out << 3, slots (2 x 16 bits) x 2, rows x 2, u rows x 2, 0
+constexpr int kMrecInts = 8;     // mrec entry (include/cvf.h): (type + 1) | out << 3, slots (2 x 16 bits) x 2, u rows x 2, row offsets (4 x 8 bits), 0, 0
 
 // Everything about a feature record that does not depend on the net: output offset, the u rows of its atoms and the gradient
 // vectors of the feature with respect to its atoms (for a position record: the centred coordinates).
 struct Geo {
   int to;              // (type + 1) | out << 3   (type -1 = no record)
-  int u01, u23;        // u rows of the atoms, 16 bits each (n_ref < 65536)
+  int u01, u23;        // u rows of the atoms (= first rows of their slots), 16 bits each (n_ref < 65536)
+  int off;             // contribution row of atom p = its u row + byte p of off
   V3 v0, v1;           // position: v0 = x - c;  bond: v0 = ga (gb = -ga);  angle: ga, gc (gb = -(ga+gc));  dihedral: g1, g4
   float p, q;          // dihedral: g2 = (-1 - p) g1 + q g4,  g3 = p g1 + (-1 - q) g4
   float cs, sn;        // angle: cs (and sn = -1/sqrt(1-cs^2) for angle-value mode);  dihedral: cos, sin
@@ -76,14 +77,15 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red, float* fin
   for (int i = 0; i < NV; ++i) v[i] = fin[i * F + f];
 }
 
-// F frames per workgroup, kMWaves waves, kGeoPre records per lane group held in registers (the rest is evaluated twice)
-template <int F, int kMWaves, int kGeoPre>
+// F frames per workgroup, kMWaves waves, kGeoPre records per lane group held in registers (the rest is evaluated twice per net);
+// kMulti: the workgroup walks npb nets (else one: the loop below folds away)
+template <int F, int kMWaves, int kGeoPre, bool kMulti>
 __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc pp, int64_t B, const float* __restrict__ aux_tiled,
                                                                    const float* __restrict__ a, int k,
                                                                    const float* __restrict__ slot_xyz,
                                                                    const double* __restrict__ dense,
                                                                    const float* __restrict__ g_tiled,
-                                                                   float* __restrict__ q_tiled, float* __restrict__ e_tiled) {
+                                                                   float* __restrict__ q_tiled, float* __restrict__ e_tiled, int npb) {
   extern __shared__ float dyn[];
   constexpr int G = 64 / F, LG = kMWaves * G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,14 +93,23 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
   CVF_STAMP(20);
   const int ns = pp.n_slot, d_r = pp.d_r, nal = pp.n_align, nref = pp.n_ref, nrec = pp.n_mrec;
   float* rows = dyn;                                   // [nref * 3][F]
-  float* red = rows + (size_t)nref * 3 * F;           // [kNRed][kMWaves][F]
+  // [8][ns]: a (3), ref (3, zero off the align set), align flag, rows (start | count << 20) of every slot, copied from the table
+  // cvf_metric_dense_tensors prepared behind the 42 moments.  One dword per read: the F lanes of a group read the SAME address,
+  // which the LDS serves as a broadcast for 32-bit reads - as [ns][8] read by two ds_read_b128 the 16 equal addresses were
+  // serialised (3.5 k cycles per three slots instead of 1.6 k; straight from global memory with the next iteration's constants
+  // requested one iteration ahead it is 1.6 k as well, for 24 more registers)
+  float* slotC = rows + (size_t)nref * 3 * F;
+  float* red = slotC + (size_t)ns * 8;                 // [kNRed][kMWaves][F]
   float* fin = red + kNRed * kMWaves * F;              // [kNRed][F]
   // blockIdx -> (frame group, net) such that the k nets of a frame group follow each other on ONE XCD (workgroups go round
   // the 8 XCDs by blockIdx): they read the same slot coordinates and aux rows, which then come from that XCD's L2
   const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7, ix = blockIdx.x >> 3;
   const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ix;
-  const int net = work % k;
-  const int64_t f0 = (int64_t)(work / k) * F;
+  // npb nets per workgroup, one after the other (k % npb == 0): the records' geometry is evaluated once and kept in registers
+  // across them - a third of the kernel's instructions otherwise repeated per net; taken when the batch fills the chip anyway
+  if (!kMulti) npb = 1;
+  const int kb = k / npb, net0 = (work % kb) * npb;
+  const int64_t f0 = (int64_t)(work / kb) * F;
   const int64_t tile = f0 / CVF_TILE;
   const int l0 = (int)(f0 % CVF_TILE) + f;             // this lane's frame inside its tile
   // per-frame constants
@@ -111,14 +122,10 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
 #pragma unroll
   for (int i = 0; i < 6; ++i) Kinv[i] = ax[(12 + i) * CVF_TILE];
   const float* xs = slot_xyz + ((f0 + f) >> 3) * (int64_t)ns * 3 * 8 + ((f0 + f) & 7);   // [frame group of 8][ns * 3][8] (K1's copy)
-  const float* gt = g_tiled + (tile * k + net) * (int64_t)d_r * CVF_TILE + l0;
-  float* qt = q_tiled + (tile * k + net) * (int64_t)d_r * CVF_TILE + l0;
-  // per-slot constants [ns][8] = a (3), ref (3, zero off the align set), align flag, rows (start | count << 20), prepared once
-  // by cvf_metric_dense_tensors behind the 42 moments.  Read from global memory: the F lanes of a group name the same address,
-  // which a vector memory load serves as one request - from LDS the two 16-byte reads per slot were serialised over the 16
-  // equal addresses (3.5 k cycles per three slots), and as eight 4-byte broadcast reads they were 24 of the loop's 39 LDS
-  // instructions
-  const float4* slotG = reinterpret_cast<const float4*>(dense + 42);
+  {
+    const float* slotG = reinterpret_cast<const float*>(dense + 42);   // [ns][8]
+    for (int i = tid; i < ns * 8; i += 64 * kMWaves) slotC[(i & 7) * ns + (i >> 3)] = slotG[i];
+  }
   // dense moments: 42 uniform numbers, kept in LDS and read by broadcast where the closed forms need them
   __shared__ float dn[42];
   if (tid < 42) dn[tid] = (float)dense[tid];
@@ -137,12 +144,12 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
   // its (up to) three g values, unused positions naming slot 0 / a clamped row; geometry - so that the loads of SEVERAL
   // records are in flight together: as one dependent chain per record (entry -> coordinates -> g) phase A was 21 memory
   // round trips long for the 7 records of a lane group, 22 k of the workgroup's 61 k cycles.
-  struct RecI { int to, s01, s23, r01, r23, u01, u23; };
-  struct RecX { float x[12], g[3]; };
+  struct RecI { int to, s01, s23, u01, u23, off; };
+  struct RecX { float x[12]; };
   auto load_rec = [&](int r) {
     const int4* p = reinterpret_cast<const int4*>(pp.mrec + kMrecInts * (r < nrec ? r : nrec - 1));
     const int4 lo = p[0], hi = p[1];
-    return RecI{r < nrec ? lo.x : 0, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z};
+    return RecI{r < nrec ? lo.x : 0, lo.y, lo.z, lo.w, hi.x, hi.y};
   };
   auto load_x = [&](const RecI& ri) {
     RecX o;
@@ -151,7 +158,12 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
     for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc) o.x[3 * p + cc] = xs[(3 * sl[p] + cc) * 8];
-    const int out = ri.to >> 3;
+    return o;
+  };
+  struct RecG { float g[3]; };
+  auto load_g = [&](const float* gt, int to) {   // the (up to) three g rows of a record's outputs, clamped
+    RecG o;
+    const int out = to >> 3;
 #pragma unroll
     for (int j = 0; j < 3; ++j) o.g[j] = gt[(int64_t)(out + j < d_r ? out + j : d_r - 1) * CVF_TILE];
     return o;
@@ -160,6 +172,7 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
     Geo ge;
     ge.to = ri.to;
     ge.u01 = ri.u01; ge.u23 = ri.u23;
+    ge.off = kMulti ? ri.off : 0;   // (one net: only the first pass needs it, straight from the table entry)
     ge.v0 = ge.v1 = v3(0, 0, 0);
     ge.p = ge.q = ge.cs = ge.sn = 0.0f;
     const int ty = geo_type(ge);
@@ -184,12 +197,11 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
   };
   // ---- phase A: contribution rows of J^T g (record r, atom p -> its own row), position sums
   float sa[kNRed];
-#pragma unroll
-  for (int i = 0; i < kNRed; ++i) sa[i] = 0.0f;   // sump (3), M (9), -
-  auto vjp = [&](const Geo& ge, const RecI& ri, const RecX& rx) {
+  auto vjp = [&](const Geo& ge, int off, const RecG& rx) {
     const int ty = geo_type(ge);
     if (ty < 0) return;
-    const int r0 = ri.r01 & 0xffff, r1 = (unsigned)ri.r01 >> 16, r2 = ri.r23 & 0xffff, r3 = (unsigned)ri.r23 >> 16;
+    const int r0 = (ge.u01 & 0xffff) + (off & 255), r1 = (int)((unsigned)ge.u01 >> 16) + ((off >> 8) & 255);
+    const int r2 = (ge.u23 & 0xffff) + ((off >> 16) & 255), r3 = (int)((unsigned)ge.u23 >> 16) + (int)((unsigned)off >> 24);
     if (ty == CVF_FEAT_POSITION) {
       const V3 g = v3(rx.g[0], rx.g[1], rx.g[2]);
       const V3 pv = mat_times(R, g);
@@ -221,7 +233,13 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
   };
   Geo pre[kGeoPre];
   constexpr int kChunk = 4;   // records whose coordinates are requested together
-  {
+  for (int nn = 0; nn < npb; ++nn) {
+  const int net = net0 + nn;
+  const float* gt = g_tiled + (tile * k + net) * (int64_t)d_r * CVF_TILE + l0;
+  float* qt = q_tiled + (tile * k + net) * (int64_t)d_r * CVF_TILE + l0;
+#pragma unroll
+  for (int i = 0; i < kNRed; ++i) sa[i] = 0.0f;   // sump (3), M (9), -
+  if (nn == 0) {   // first net: table entries, coordinates, geometry (kept in `pre` for the other nets)
     RecI ri[kGeoPre];
 #pragma unroll
     for (int it = 0; it < kGeoPre; ++it) ri[it] = load_rec(lg + LG * it);
@@ -229,21 +247,31 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
 #pragma unroll
     for (int c0 = 0; c0 < kGeoPre; c0 += kChunk) {
       RecX rx[kChunk];
+      RecG rg[kChunk];
 #pragma unroll
       for (int j = 0; j < kChunk; ++j)
-        if (c0 + j < kGeoPre) rx[j] = load_x(ri[c0 + j]);
+        if (c0 + j < kGeoPre) {
+          rx[j] = load_x(ri[c0 + j]);
+          rg[j] = load_g(gt, ri[c0 + j].to);
+        }
 #pragma unroll
       for (int j = 0; j < kChunk; ++j)
         if (c0 + j < kGeoPre) {
           pre[c0 + j] = eval(ri[c0 + j], rx[j]);
-          vjp(pre[c0 + j], ri[c0 + j], rx[j]);
+          vjp(pre[c0 + j], ri[c0 + j].off, rg[j]);
         }
     }
+  } else {
+    RecG rg[kGeoPre];
+#pragma unroll
+    for (int it = 0; it < kGeoPre; ++it) rg[it] = load_g(gt, pre[it].to);
+#pragma unroll
+    for (int it = 0; it < kGeoPre; ++it) vjp(pre[it], pre[it].off, rg[it]);
   }
   for (int r = lg + LG * kGeoPre; r < nrec; r += LG) {
     const RecI ri = load_rec(r);
     const RecX rx = load_x(ri);
-    vjp(eval(ri, rx), ri, rx);
+    vjp(eval(ri, rx), ri.off, load_g(gt, ri.to));
   }
   CVF_STAMP(22);
   block_sum<F, kMWaves, kNRed>(sa, red, fin, wave, f, grp);     // (its barriers also publish the rows and slotC)
@@ -294,23 +322,13 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
 #ifdef CVF_STAMPS
   int itb = 0;
 #endif
-  float4 n0[kSlots], n1[kSlots];   // the next iteration's constants, requested one iteration ahead
-#pragma unroll
-  for (int j = 0; j < kSlots; ++j) {
-    const int sl = lg + LG * j < ns ? lg + LG * j : ns - 1;
-    n0[j] = slotG[2 * sl];
-    n1[j] = slotG[2 * sl + 1];
-  }
   for (int sl0 = lg; sl0 < ns; sl0 += LG * kSlots) {
     float4 c0[kSlots], c1[kSlots];
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) {
-      c0[j] = n0[j];
-      c1[j] = n1[j];
-      const int nx = sl0 + LG * (kSlots + j);
-      const int sl = nx < ns ? nx : ns - 1;
-      n0[j] = slotG[2 * sl];
-      n1[j] = slotG[2 * sl + 1];
+      const float* sc = slotC + (sl0 + LG * j < ns ? sl0 + LG * j : ns - 1);
+      c0[j] = float4{sc[0], sc[ns], sc[2 * ns], sc[3 * ns]};
+      c1[j] = float4{sc[4 * ns], sc[5 * ns], sc[6 * ns], sc[7 * ns]};
     }
     V3 st[kSlots];
     int r0[kSlots], cnt[kSlots], mx = 1;
@@ -423,6 +441,8 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
     jvp(eval(ri, load_x(ri)));
   }
   CVF_STAMP(26);
+  if (nn + 1 < npb) __syncthreads();   // the u rows are read; the next net writes its contributions over them
+  }
 }
 
 // dense[42] = T0[3], T1[3][3], T2[3][3][3], R1[3] in fp64; one block
@@ -481,7 +501,7 @@ __global__ void metric_dense_kernel(cvf_pp_desc pp, const float* __restrict__ a,
 }  // namespace
 
 static size_t metric_rows_lds(const cvf_pp_desc* pp, int F, int waves) {
-  return ((size_t)pp->n_ref * 3 * F + (size_t)kNRed * waves * F + (size_t)kNRed * F) * sizeof(float);
+  return ((size_t)pp->n_ref * 3 * F + (size_t)8 * pp->n_slot + (size_t)kNRed * waves * F + (size_t)kNRed * F) * sizeof(float);
 }
 size_t cvf_metric_large_lds(const cvf_pp_desc* pp) { return metric_rows_lds(pp, 4, 8); }   // the smallest layout
 
@@ -498,19 +518,28 @@ int cvf_metric_large_launch(const cvf_pp_desc* pp, int64_t B, const float* aux_t
   CVF_REQUIRE(lds <= kBudget, "cvf_metric_apply: %d feature-atom references need %zu B of LDS (> 158 KiB)", pp->n_ref, lds);
   const int64_t groups = cvf_ntiles(B) * (CVF_TILE / F) * k;
   CVF_REQUIRE(groups < (int64_t)1 << 31, "cvf_metric_apply: batch too large");
+  // all k nets of a frame group in one workgroup once that still leaves every CU two workgroups and more (see the kernel)
+  int npb = groups / k >= 512 ? k : 1;
+  if (getenv("CVF_METRIC_NPB") && k % atoi(getenv("CVF_METRIC_NPB")) == 0 && atoi(getenv("CVF_METRIC_NPB")) > 0) npb = atoi(getenv("CVF_METRIC_NPB"));   // developer switch
   auto go = [&](auto kernel) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)groups), dim3(64 * W), lds, s, *pp, B, aux_tiled, a, k, slot_xyz, dense,
-                       g_tiled, q_tiled, e_tiled);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(groups / npb)), dim3(64 * W), lds, s, *pp, B, aux_tiled, a, k, slot_xyz, dense,
+                       g_tiled, q_tiled, e_tiled, npb);
   };
+  static const int pre_multi = getenv("CVF_METRIC_PRE") ? atoi(getenv("CVF_METRIC_PRE")) : 7;   // developer switch: 5 (no spills) | 7 (17 spilled registers, but 363 against 416 us at 16 000 frames x 6 nets)
   if (W == 16) {
-    if (F == 16) go(metric_rows_kernel<16, 16, 2>);
-    else if (F == 8) go(metric_rows_kernel<8, 16, 2>);
-    else go(metric_rows_kernel<4, 16, 2>);
+    if (F == 16) go(metric_rows_kernel<16, 16, 2, true>);
+    else if (F == 8) go(metric_rows_kernel<8, 16, 2, true>);
+    else go(metric_rows_kernel<4, 16, 2, true>);
+  } else if (npb > 1) {
+    if (F == 16 && pre_multi == 7) go(metric_rows_kernel<16, 8, 7, true>);
+    else if (F == 16) go(metric_rows_kernel<16, 8, 5, true>);
+    else if (F == 8) go(metric_rows_kernel<8, 8, 4, true>);
+    else go(metric_rows_kernel<4, 8, 2, true>);
   } else {
-    if (F == 16) go(metric_rows_kernel<16, 8, 7>);
-    else if (F == 8) go(metric_rows_kernel<8, 8, 4>);
-    else go(metric_rows_kernel<4, 8, 2>);
+    if (F == 16) go(metric_rows_kernel<16, 8, 7, false>);
+    else if (F == 8) go(metric_rows_kernel<8, 8, 4, false>);
+    else go(metric_rows_kernel<4, 8, 2, false>);
   }
   return cvf_check_launch("metric_rows_kernel");
 }

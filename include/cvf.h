@@ -53,11 +53,8 @@ enum {
 enum {
   CVF_PP_ALIGN_CONTIG = 1,   /* align_idx[b] == b for all b (the align atoms are the first n_align frame atoms) */
   CVF_PP_PURE_POSITION = 2,  /* record r is {POSITION, atom r, out 3r}: n_rec atoms emit their aligned positions in order */
-  CVF_PP_SLOT_DISJOINT = 8,  /* (with CVF_PP_SLOT_BATCHED) within a batch no slot occurs twice at all: a record's accumulators can be
-                              * read together and written together - one LDS round trip per record instead of one per component */
-  CVF_PP_SLOT_BATCHED = 4    /* rec_slot holds n_rec_slot entries in batches of 64 (one per lane of a wave): within a batch no two
-                              * records name the same slot in the same atom position, entries of type -1 are padding.  Lets the
-                              * derivative kernel scatter with plain read-modify-write instead of LDS float atomics. */
+  CVF_PP_SLOT_BATCHED = 4    /* rec_slot holds n_rec_slot entries in batches of 64 of ONE feature type (one entry per lane of a wave),
+                              * entries of type -1 are padding */
 };
 
 /* The preprocessing layer r(x): torch.nn.Identity (examples/2d/2d.ipynb:485) or the
@@ -92,10 +89,10 @@ typedef struct cvf_pp_desc {
   /* large molecules, derivative kernel (cvf_metric_apply; csrc/metric_large.hip): the scatter J^T g -> feature atoms as a table
    * of rows.  Every (record, atom position) pair owns one row; the rows of one slot are contiguous:
    *   slot_row[t] .. slot_row[t+1]-1 (slot_row[n_slot] = n_ref = total number of pairs, < 65536).
-   * mrec[r] = { (type + 1) | out_offset << 3, slot[0] | slot[1] << 16, slot[2] | slot[3] << 16, row[0] | row[1] << 16,
-   *             row[2] | row[3] << 16, urow[0] | urow[1] << 16, urow[2] | urow[3] << 16, 0 }   (16-byte aligned)
-   * with urow[p] = slot_row[slot[p]] (unused positions 0; n_slot, n_ref < 65536); records of one type side by side keep a
-   * wave on one code path. */
+   * mrec[r] = { (type + 1) | out_offset << 3, slot[0] | slot[1] << 16, slot[2] | slot[3] << 16, urow[0] | urow[1] << 16,
+   *             urow[2] | urow[3] << 16, off[0] | off[1] << 8 | off[2] << 16 | off[3] << 24, 0, 0 }   (16-byte aligned)
+   * with urow[p] = slot_row[slot[p]] and urow[p] + off[p] = the row of atom p of record r (off < 256; unused positions 0;
+   * n_slot, n_ref < 65536); records of one type side by side keep a wave on one code path. */
   const int32_t* mrec;       /* [n_mrec*8] */
   const int32_t* slot_row;   /* [n_slot+1] */
   int32_t n_mrec;

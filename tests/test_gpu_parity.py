@@ -529,6 +529,17 @@ def test_large_molecule_generator_step_vs_oracle(dev, n_atoms, B, contig, k):
     want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
     got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+    # the derivative kernel with all k nets of a frame group in one workgroup (what large batches take; forced here): the same
+    # sums in the same order per net - identical loss and eigenvalues
+    os.environ["CVF_METRIC_NPB"] = str(k)
+    try:
+        loss2, eig2, npl2, pen2, cvec2 = task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    finally:
+        del os.environ["CVF_METRIC_NPB"]
+    # (this call answers in the fp64 default dtype set above for the oracle, the first one in fp32: equal up to that rounding)
+    np.testing.assert_allclose(float(loss2), float(loss), rtol=2e-7)
+    np.testing.assert_allclose(eig2.numpy(), eig.numpy(), rtol=2e-7)
+    assert list(cvec2) == list(cvec)
 
 
 def test_config5_shape_generator_step_vs_oracle(dev):

@@ -259,16 +259,17 @@ def test_utils_match_reference_files(tmp_path):
         utils.integrate_md_langevin()
 
 
-def test_slot_record_batches_are_conflict_free():
-    """pp._batch_records: every record appears once, batches are 64 wide and of one type, padding entries have type -1,
-    and inside a batch no (atom position, slot) pair repeats - what CVF_PP_SLOT_BATCHED promises the derivative kernel."""
+def test_slot_record_batches_and_row_tables():
+    """pp._batch_records: every record appears once, batches are 64 wide and of one type, padding entries have type -1
+    (CVF_PP_SLOT_BATCHED).  The derivative kernel's tables (include/cvf.h: mrec, slot_row): every (record, atom position)
+    pair owns exactly one row, the rows of a slot are contiguous and in record order, urow = the slot's first row."""
     from colvarsfinder import _hip, pp
     rs = np.random.RandomState(5)
     natoms = {_hip.FEAT_POSITION: 1, _hip.FEAT_BOND: 2, _hip.FEAT_ANGLE: 3, _hip.FEAT_DIHEDRAL: 4}
     recs, out = [], 0
     for t, n in ((_hip.FEAT_POSITION, 40), (_hip.FEAT_BOND, 150), (_hip.FEAT_ANGLE, 70), (_hip.FEAT_DIHEDRAL, 130)):
         for _ in range(n):
-            atoms = [int(a) for a in rs.choice(30, natoms[t], replace=False)]    # few slots: plenty of collisions
+            atoms = [int(a) for a in rs.choice(30, natoms[t], replace=False)]    # few slots: plenty of shared atoms
             recs.append([t] + atoms + [0] * (4 - len(atoms)) + [out])
             out += 3 if t == _hip.FEAT_POSITION else 1
     batched = pp._batch_records(sorted(recs, key=lambda r: r[0]))
@@ -276,27 +277,32 @@ def test_slot_record_batches_are_conflict_free():
     real = [r for r in batched if r[0] >= 0]
     assert sorted(map(tuple, real)) == sorted(map(tuple, recs))
     for b in range(0, len(batched), 64):
-        batch = [r for r in batched[b:b + 64] if r[0] >= 0]
-        assert len({r[0] for r in batch}) <= 1
-        for j in range(4):
-            slots = [r[1 + j] for r in batch if j < natoms[r[0]]]
-            assert len(slots) == len(set(slots))
-    # disjoint batches (CVF_PP_SLOT_DISJOINT): no slot twice in a batch, whatever its position in the record
-    strict = pp._batch_records(sorted(recs, key=lambda r: r[0]), disjoint=True)
-    assert sorted(map(tuple, [r for r in strict if r[0] >= 0])) == sorted(map(tuple, recs)) and len(strict) >= len(batched)
-    for b in range(0, len(strict), 64):
-        batch = [r for r in strict[b:b + 64] if r[0] >= 0]
-        assert len({r[0] for r in batch}) <= 1
-        slots = [r[1 + j] for r in batch for j in range(natoms[r[0]])]
-        assert len(slots) == len(set(slots))
-    # the layer takes the disjoint batches only when they cost no extra batch
+        assert len({r[0] for r in batched[b:b + 64] if r[0] >= 0}) <= 1
     n_at = 400
-    feats = [("dihedral", tuple(int(a) for a in rs.choice(n_at, 4, replace=False))) for _ in range(40)] + [("bond", (1, 2)), ("bond", (2, 3))]
-    lay = pp.AlignFeatureLayer(n_at, list(range(n_at)), rs.normal(size=(n_at, 3)), feats)
-    assert lay._flags & _hip.PP_SLOT_BATCHED
+    names = {_hip.FEAT_POSITION: "position", _hip.FEAT_BOND: "bond", _hip.FEAT_ANGLE: "angle", _hip.FEAT_DIHEDRAL: "dihedral"}
     chain = [("dihedral", (i, i + 1, i + 2, i + 3)) for i in range(0, 300)]       # a backbone: neighbours share atoms
-    lay2 = pp.AlignFeatureLayer(n_at, list(range(n_at)), rs.normal(size=(n_at, 3)), chain)
-    assert lay2._flags & _hip.PP_SLOT_BATCHED and lay2._n_rec_slot % 64 == 0
+    mixed = [(names[r[0]], tuple(r[1:1 + natoms[r[0]]])) for r in recs]
+    for feats in (chain, mixed):
+        lay = pp.AlignFeatureLayer(n_at, list(range(n_at)), rs.normal(size=(n_at, 3)), feats)
+        assert lay._flags & _hip.PP_SLOT_BATCHED and lay._n_rec_slot % 64 == 0
+        mrec, slot_row = lay.mrec.numpy().view(np.uint32), lay.slot_row.numpy()
+        n_ref = lay._n_ref
+        assert slot_row[0] == 0 and slot_row[-1] == n_ref and np.all(np.diff(slot_row) >= 1) and len(slot_row) == lay._n_slot + 1
+        seen = np.zeros(n_ref, dtype=int)
+        last_rec_of_row = {}
+        for i, m in enumerate(mrec):
+            ty = int(m[0] & 7) - 1
+            sl = [m[1] & 0xffff, m[1] >> 16, m[2] & 0xffff, m[2] >> 16]
+            ur = [m[3] & 0xffff, m[3] >> 16, m[4] & 0xffff, m[4] >> 16]
+            rw = [int(ur[j]) + int((m[5] >> (8 * j)) & 255) for j in range(4)]
+            for j in range(natoms[ty]):
+                seen[rw[j]] += 1
+                assert slot_row[sl[j]] <= rw[j] < slot_row[sl[j] + 1] and ur[j] == slot_row[sl[j]]
+                last_rec_of_row[int(rw[j])] = i
+        assert np.all(seen == 1)
+        for t in range(lay._n_slot):      # rows of a slot in record order (a fixed summation order)
+            owners = [last_rec_of_row[r] for r in range(slot_row[t], slot_row[t + 1])]
+            assert owners == sorted(owners)
 
 
 @pytest.mark.parametrize("angle_value,weighted", [(False, False), (True, False), (False, True)])

@@ -76,8 +76,8 @@ int main(int argc, char** argv) {
       int sl[4] = {0, 0, 0, 0}, rw[4] = {0, 0, 0, 0}, ur[4] = {0, 0, 0, 0};
       for (int j = 0; j < na; ++j) { sl[j] = atom_slot[recs[i][1 + j]]; rw[j] = rowof[i * 4 + j]; ur[j] = slot_row[sl[j]]; }
       m[0] = (recs[i][0] + 1) | (recs[i][5] << 3);
-      m[1] = sl[0] | (sl[1] << 16); m[2] = sl[2] | (sl[3] << 16); m[3] = rw[0] | (rw[1] << 16); m[4] = rw[2] | (rw[3] << 16);
-      m[5] = ur[0] | (ur[1] << 16); m[6] = ur[2] | (ur[3] << 16);
+      m[1] = sl[0] | (sl[1] << 16); m[2] = sl[2] | (sl[3] << 16); m[3] = ur[0] | (ur[1] << 16); m[4] = ur[2] | (ur[3] << 16);
+      m[5] = (rw[0] - ur[0]) | ((rw[1] - ur[1]) << 8) | ((rw[2] - ur[2]) << 16) | ((rw[3] - ur[3]) << 24);
     }
     pp.mrec = (const int32_t*)up(mrec.data(), mrec.size() * 4); pp.slot_row = (const int32_t*)up(slot_row.data(), slot_row.size() * 4);
     pp.n_mrec = (int)recs.size(); pp.n_ref = (int)pairs.size();
