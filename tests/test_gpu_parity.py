@@ -1264,6 +1264,56 @@ def test_eigenfunction_activations_generator_step_vs_oracle(dev, name, module, f
     np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("d_in,dims_h,k,B,lag", [(150, [12], 2, 70, 0), (200, [16, 16], 3, 200, 0), (384, [20, 20, 20], 2, 130, 0),
+                                                 (150, [16, 16], 2, 70, 2), (260, [20, 20, 20], 3, 129, 3)])
+def test_wide_first_layer_steps_vs_oracle(dev, d_in, dims_h, k, B, lag):
+    """First layers wider than 128 inputs (csrc/ef_mfma.hip: ef_fwd_wide_kernel with the first layer's k-steps shared out over
+    eight waves, t0 = W0 q ahead of the backward kernel, the first layer's gradient tiles shared out over the blocks of a tile
+    and written straight to the slab row), on the identity layer so that the input width is free: ragged batches, 1-3 hidden
+    layers, generator and transfer-operator mode - loss, eigenvalues, ordering, every parameter gradient against the fp64 oracle."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    from tests.synth import make_weights
+    rs = np.random.RandomState(1000 + d_in + B)
+    n = B + lag
+    drift = np.cumsum(0.05 * rs.normal(size=(n, 1)), axis=0)
+    traj = (0.4 * rs.normal(size=(n, d_in)) + drift * rs.normal(size=(1, d_in))).astype(np.float64)
+    w = make_weights(rs, n)
+    a = torch.tensor(rs.uniform(0.3, 1.5, size=d_in), dtype=torch.float32)
+    dims = [d_in] + dims_h + [1]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(31))
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    eig_w = [1.0, 0.7, 0.4][:k]
+    layer, olayer = torch.nn.Identity(), torch.nn.Identity()
+    kw = dict(k=k, device=dev, verbose=False, save_model_every_step=0)
+    if lag == 0:
+        task = core.EigenFunctionTask(Traj(traj, w, 1.0), layer, model, "/tmp/cvf_test", 12.0, eig_w, diag_coeff=a, beta=1.2, lag_tau=0, **kw)
+        loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj), torch.tensor(w), None, None)
+    else:
+        task = core.EigenFunctionTask(Traj(traj, w, 0.5), layer, model, "/tmp/cvf_test", 12.0, eig_w, beta=1.0, lag_tau=lag * 0.5, **kw)
+        X, Xl, wt, wl = torch.tensor(traj[:B]), torch.tensor(traj[lag:lag + B]), torch.tensor(w[:B]), torch.tensor(w[lag:lag + B])
+        loss, eig, npl, pen, cvec = task.loss_func(X, wt, Xl, wl)
+    assert not task._use_ef16()
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n_: p.double().requires_grad_(True) for n_, p in sd0.items()}
+    if lag == 0:
+        Xo = torch.tensor(traj, dtype=torch.float64, requires_grad=True)
+        lo, eo, no, po, co = losses.ef_loss(sd, k, olayer, Xo, torch.tensor(w), alpha=12.0, eig_w=eig_w, diag_coeff=a.double(), beta=1.2)
+    else:
+        lo, eo, no, po, co = losses.ef_loss(sd, k, olayer, X.double(), wt.double(), Xl.double(), wl.double(), alpha=12.0, eig_w=eig_w,
+                                            lag_idx=lag, dt=0.5)
+    lo.backward()
+    torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=RTOL64)
+    assert list(cvec) == list(co)
+    want = torch.cat([sd[n_].grad.reshape(-1) for n_, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+
+
 @pytest.mark.parametrize("name,module,fn", [ACTIVATIONS[0], ACTIVATIONS[2], ACTIVATIONS[4]], ids=["sigmoid", "elu", "softplus"])
 def test_eigenfunction_activations_transfer_training_vs_oracle(dev, name, module, fn):
     """... and a short transfer-operator training run (loss of every step) against the oracle's trainer."""
