@@ -730,7 +730,9 @@ int cvf_ef_stats_finish(const cvf_ef_cfg* cfg, int n_rows, const double* partial
                         hipStream_t s);
 int cvf_metric_large_launch(const cvf_pp_desc* pp, int64_t B, const float* aux_tiled, const float* a, int k,
                             const float* slot_xyz, const double* dense, const float* g_tiled, float* q_tiled, float* e_tiled,
-                            hipStream_t s);
+                            const MetricFuse* fuse, int* fused_rows, hipStream_t s);
+int cvf_ef_stats_finish_impl(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
+                             double* loss_vec, double* coef, hipStream_t s);
 
 // frames larger than this use the streaming workgroup-per-frame kernel (k1_large.hip)
 static constexpr int kLanePerFrameMaxCoord = 192;
@@ -840,8 +842,9 @@ extern "C" int cvf_align_feature_fwd(const cvf_pp_desc* pp, const float* x, int6
 
 static int metric_apply_impl(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled, const float* a,
                              int k, const float* g_tiled, float* q_tiled, float* e_tiled, const float* slot_xyz,
-                             const double* dense, const MetricFuse& fuse, bool* fused, void* stream) {
+                             const double* dense, const MetricFuse& fuse, bool* fused, void* stream, int* major_rows = nullptr) {
   if (fused) *fused = false;
+  if (major_rows) *major_rows = 0;   // > 0: the launch left that many rows of [statistic][row] partial sums (large molecules)
   CVF_REQUIRE(pp && a && g_tiled && q_tiled && e_tiled && B > 0 && k >= 1 && k <= CVF_MAX_NETS,
               "cvf_metric_apply: bad argument (B=%lld k=%d)", (long long)B, k);
   const int64_t T = cvf_ntiles(B);
@@ -859,7 +862,7 @@ static int metric_apply_impl(const cvf_pp_desc* pp, const float* x, int64_t B, c
     CVF_REQUIRE(slot_xyz && dense && pp->rec_slot && pp->slot_atom && pp->atom_align && pp->n_slot > 0,
                 "cvf_metric_apply: large molecules need the slot tables, slot_xyz (cvf_align_feature_fwd scratch) and "
                 "dense (cvf_metric_dense_tensors)");
-    return cvf_metric_large_launch(pp, B, aux_tiled, a, k, slot_xyz, dense, g_tiled, q_tiled, e_tiled, s);
+    return cvf_metric_large_launch(pp, B, aux_tiled, a, k, slot_xyz, dense, g_tiled, q_tiled, e_tiled, &fuse, major_rows, s);
   }
   CVF_REQUIRE(x, "cvf_metric_apply: align mode needs x");
   const size_t lds = ((size_t)CVF_TILE * (x_tile_stride(pp->n_coord) + pp->n_coord) + tables_dwords(*pp) + pp->n_coord) * sizeof(float);
@@ -901,7 +904,9 @@ extern "C" int cvf_metric_apply(const cvf_pp_desc* pp, const float* x, int64_t B
 }
 
 extern "C" int64_t cvf_metric_stats_scratch_doubles(int64_t B, int k) {
-  return 2 * cvf_ntiles(B) * (int64_t)cvf_ef_nstats(k, 0) + cvf_ef_stats_scratch_doubles(k, 0);   // (up to two rows per tile)
+  // (up to two rows per tile; the large-molecule derivative kernel: one row per group of 4..16 frames, while those are few)
+  const int64_t T = cvf_ntiles(B), per_group = 16 * T < kFuseMaxTiles ? 16 * T : kFuseMaxTiles;
+  return (2 * T > per_group ? 2 * T : per_group) * (int64_t)cvf_ef_nstats(k, 0) + cvf_ef_stats_scratch_doubles(k, 0);
 }
 
 extern "C" int cvf_metric_apply_stats(const cvf_pp_desc* pp, const float* x, int64_t B, const float* aux_tiled,
@@ -921,8 +926,10 @@ extern "C" int cvf_metric_apply_stats(const cvf_pp_desc* pp, const float* x, int
   f.y_tiled = y_tiled;
   f.partial = scratch;
   bool fused = false;
-  const int rc = metric_apply_impl(pp, x, B, aux_tiled, a, k, g_tiled, q_tiled, e_tiled, slot_xyz, dense, f, &fused, stream);
+  int major_rows = 0;
+  const int rc = metric_apply_impl(pp, x, B, aux_tiled, a, k, g_tiled, q_tiled, e_tiled, slot_xyz, dense, f, &fused, stream, &major_rows);
   if (rc) return rc;
+  if (major_rows > 0) return cvf_ef_stats_finish_impl(cfg, major_rows, 1, scratch, stats, loss_vec, coef, (hipStream_t)stream);
   if (fused) return cvf_ef_stats_finish(cfg, (int)T, scratch, stats, loss_vec, coef, (hipStream_t)stream);
   // shapes without the fused first stage: the two-stage reduction on the rest of the scratch
   return cvf_ef_stats(cfg, B, w, y_tiled, e_tiled, nullptr, nullptr, scratch + T * ns, stats, loss_vec, coef, stream);

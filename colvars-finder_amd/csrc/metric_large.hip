@@ -85,7 +85,8 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
                                                                    const float* __restrict__ slot_xyz,
                                                                    const double* __restrict__ dense,
                                                                    const float* __restrict__ g_tiled,
-                                                                   float* __restrict__ q_tiled, float* __restrict__ e_tiled, int npb) {
+                                                                   float* __restrict__ q_tiled, float* __restrict__ e_tiled, int npb,
+                                                                   MetricFuse fuse) {
   extern __shared__ float dyn[];
   constexpr int G = 64 / F, LG = kMWaves * G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -384,6 +385,29 @@ __global__ __launch_bounds__(64 * kMWaves) void metric_rows_kernel(cvf_pp_desc p
 #pragma unroll
   for (int i = 0; i < 9; ++i) dH[i] += sb[4 + i];
   if (lg == 0) e_tiled[(tile * k + net) * CVF_TILE + l0] = E;
+  if (fuse.on && wave == 0) {
+    // first stage of the batch sums of EigenFunctionTask.loss_func (K5; cvf_metric.hpp: MetricFuse): this workgroup's F frames of the
+    // slots its net owns, one row per frame group, [statistic][row]; cvf_ef_stats_finish adds the rows.  fp64, fixed order
+    // (row_shr steps inside the 16-lane row that holds group 0's frames; the other groups add zeros).
+    const int64_t frame = f0 + f;
+    const bool valid = frame < B && grp == 0;
+    const double wb = valid ? (double)fuse.w[frame < B ? frame : B - 1] : 0.0;
+    const float* yb = fuse.y_tiled + tile * k * CVF_TILE + l0;
+    const double yn = valid ? (double)yb[net * CVF_TILE] : 0.0;
+    const int64_t n_rows = (int64_t)(gridDim.x / kb), row = work / kb;
+    auto put = [&](int slot, double v) {
+      v += dpp_movd<0x111, 0xf>(v);
+      v += dpp_movd<0x112, 0xf>(v);
+      v += dpp_movd<0x114, 0xf>(v);
+      v += dpp_movd<0x118, 0xf>(v);   // lane 15 holds the sum of lanes 0..15
+      if (lane == 15) fuse.partial[slot * n_rows + row] = v;
+    };
+    if (net == 0) put(0, wb);
+    put(1 + net, wb * yn);
+    const int s2o = 1 + k + net * k - (net * (net - 1)) / 2 - net;   // + j : slot of S2[net][j], j >= net
+    for (int j = net; j < k; ++j) put(s2o + j, wb * yn * (valid ? (double)yb[j * CVF_TILE] : 0.0));
+    put(1 + k + CVF_NPAIR(k) + net, wb * (double)E);
+  }
   const float ub[3] = {inv_nal * (usd[0] + sb[1]), inv_nal * (usd[1] + sb[2]), inv_nal * (usd[2] + sb[3])};
 #pragma unroll
   for (int cc = 0; cc < 3; ++cc)
@@ -505,9 +529,11 @@ static size_t metric_rows_lds(const cvf_pp_desc* pp, int F, int waves) {
 }
 size_t cvf_metric_large_lds(const cvf_pp_desc* pp) { return metric_rows_lds(pp, 4, 8); }   // the smallest layout
 
+// fuse / fused_rows: see MetricFuse (cvf_metric.hpp); *fused_rows = rows of [statistic][row] partial sums written (0: none)
 int cvf_metric_large_launch(const cvf_pp_desc* pp, int64_t B, const float* aux_tiled, const float* a, int k,
                             const float* slot_xyz, const double* dense, const float* g_tiled, float* q_tiled, float* e_tiled,
-                            hipStream_t s) {
+                            const MetricFuse* fuse, int* fused_rows, hipStream_t s) {
+  if (fused_rows) *fused_rows = 0;
   CVF_REQUIRE(pp->mrec && pp->slot_row && pp->n_mrec > 0 && pp->n_ref >= pp->n_slot && pp->n_ref < 65536,
               "cvf_metric_apply: large molecules need the record / row tables (mrec, slot_row, n_mrec, n_ref) of cvf_pp_desc");
   constexpr size_t kBudget = 158 * 1024;
@@ -521,10 +547,15 @@ int cvf_metric_large_launch(const cvf_pp_desc* pp, int64_t B, const float* aux_t
   // all k nets of a frame group in one workgroup once that still leaves every CU two workgroups and more (see the kernel)
   int npb = groups / k >= 512 ? k : 1;
   if (getenv("CVF_METRIC_NPB") && k % atoi(getenv("CVF_METRIC_NPB")) == 0 && atoi(getenv("CVF_METRIC_NPB")) > 0) npb = atoi(getenv("CVF_METRIC_NPB"));   // developer switch
+  MetricFuse mf = {};
+  if (fuse != nullptr && fuse->on && groups / k <= 384) {   // one row per frame group, while the finishing launch reads them in one trip
+    mf = *fuse;
+    if (fused_rows) *fused_rows = (int)(groups / k);
+  }
   auto go = [&](auto kernel) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, dim3((unsigned)(groups / npb)), dim3(64 * W), lds, s, *pp, B, aux_tiled, a, k, slot_xyz, dense,
-                       g_tiled, q_tiled, e_tiled, npb);
+                       g_tiled, q_tiled, e_tiled, npb, mf);
   };
   static const int pre_multi = getenv("CVF_METRIC_PRE") ? atoi(getenv("CVF_METRIC_PRE")) : 7;   // developer switch: 5 (no spills) | 7 (17 spilled registers, but 363 against 416 us at 16 000 frames x 6 nets)
   if (W == 16) {

@@ -111,26 +111,45 @@ __global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, i
   //  statistic; with eight it was three dependent ones, 9 us for this launch)
   // stat_major: partial is [statistic][row] - a wave's 64 lanes read 512 consecutive bytes per load instead of one 8-byte
   // word in each of 64 rows (64 cache lines per instruction: with 1250 rows that access pattern alone was 8 us)
-  constexpr int kRows = 24;
   const int64_t rs = stat_major ? 1 : ns, is = stat_major ? n_rows : 1;
-  for (int i = wave; i < ns; i += nw) {
-    double acc = 0.0;
-    for (int g0 = lane; g0 < n_rows; g0 += CVF_WAVE * kRows) {
-      double v[kRows];
+  // kSt statistics per wave at a time, kR row loads in flight for each.  More statistics than waves (k >= 4: 19..53) used to be
+  // ceil(ns / 16) passes of one statistic per wave - as many DEPENDENT memory round trips (11 us at k = 6, the rows just written
+  // by other CUs); four statistics share a pass now.
+  auto pass = [&](auto kst_, auto kr_) {
+    constexpr int kSt = decltype(kst_)::value, kR = decltype(kr_)::value;
+    for (int i0 = wave; i0 < ns; i0 += nw * kSt) {
+      double acc[kSt];
 #pragma unroll
-      for (int b = 0; b < kRows; ++b) {
-        const int g = g0 + CVF_WAVE * b;
-        v[b] = partial[(int64_t)(g < n_rows ? g : n_rows - 1) * rs + i * is];
+      for (int j = 0; j < kSt; ++j) acc[j] = 0.0;
+      for (int g0 = lane; g0 < n_rows; g0 += CVF_WAVE * kR) {
+        double v[kSt][kR];
+#pragma unroll
+        for (int j = 0; j < kSt; ++j) {
+          const int i = i0 + nw * j < ns ? i0 + nw * j : ns - 1;
+#pragma unroll
+          for (int b = 0; b < kR; ++b) {
+            const int g = g0 + CVF_WAVE * b;
+            v[j][b] = partial[(int64_t)(g < n_rows ? g : n_rows - 1) * rs + i * is];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kSt; ++j)
+#pragma unroll
+          for (int b = 0; b < kR; ++b) acc[j] += (g0 + CVF_WAVE * b < n_rows) ? v[j][b] : 0.0;
       }
 #pragma unroll
-      for (int b = 0; b < kRows; ++b) acc += (g0 + CVF_WAVE * b < n_rows) ? v[b] : 0.0;
+      for (int j = 0; j < kSt; ++j) {
+        const double sum = wave_sum(acc[j]);
+        const int i = i0 + nw * j;
+        if (lane == 0 && i < ns) {
+          fin[i] = sum;
+          stats[i] = sum;
+        }
+      }
     }
-    const double sum = wave_sum(acc);
-    if (lane == 0) {
-      fin[i] = sum;
-      stats[i] = sum;
-    }
-  }
+  };
+  if (ns <= nw) pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 24>{});
+  else pass(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
   if (loss_vec == nullptr) return;
   __syncthreads();
   if (wave == 0) ef_loss_tail_wave(cfg, fin, loss_vec, coef);

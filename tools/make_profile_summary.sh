@@ -5,6 +5,7 @@ cd "$(dirname "$0")/.."
 TAG="${CVF_PROFILE_TAG:-r3}"
 cp gpurun_out/$TAG/kt/bench_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
 [ -f gpurun_out/$TAG/kt_k1/k1_kernel_stats.csv ] && cp gpurun_out/$TAG/kt_k1/k1_kernel_stats.csv profiles/${TAG}_k1_roofline_kernel_stats.csv
+for b in 2000 16000; do [ -f gpurun_out/$TAG/kt_c5_$b/c5_kernel_stats.csv ] && cp gpurun_out/$TAG/kt_c5_$b/c5_kernel_stats.csv profiles/${TAG}_c5_batch${b}_kernel_stats.csv; done
 (cd gpurun_out/$TAG && {
   echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --cpu-seconds 0   (avg us per launch, first 30 launches skipped)"
   python3 ../../tools/kstats.py kt/bench_kernel_trace.csv 30; echo
@@ -16,6 +17,12 @@ cp gpurun_out/$TAG/kt/bench_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.
   python3 ../../tools/pmc_summary.py pmc_sq/bench_counter_collection.csv; echo
   echo "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_k1.py  (align+feature kernel alone, whole-shard launches)"
   python3 ../../tools/kstats.py kt_k1/k1_kernel_trace.csv 3; grep '^{"case"' bench_k1.log; echo
+  for b in 2000 16000; do
+    if [ -f kt_c5_$b/c5_kernel_trace.csv ]; then
+      echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload c5 --batch $b --cpu-seconds 0   (config-5 shape: 5000 atoms, d_r 384, k 6; avg us per launch, first 10 launches skipped)"
+      python3 ../../tools/kstats.py kt_c5_$b/c5_kernel_trace.csv 10; echo
+    fi
+  done
   echo "# python bench.py (full line incl. cpu_baseline)"; tail -1 bench_full.log
 } > ../../profiles/${TAG}_bench_summary.txt)
 CVF_TAG=$TAG python3 - <<'PY'

@@ -108,10 +108,10 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(dg, g.data(), g.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(da, av.data(), nc * 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(metric_dense_kernel, dim3(1), dim3(256), 0, 0, pp, da, ddense);
-    for (int it = 0; it < 2; ++it) cvf_metric_large_launch(&pp, B, daux, da, k, dslot, ddense, dg, dq, de, nullptr);
+    for (int it = 0; it < 2; ++it) cvf_metric_large_launch(&pp, B, daux, da, k, dslot, ddense, dg, dq, de, nullptr, nullptr, nullptr);
     (void)hipEventRecord(e0, nullptr);
     for (int it = 0; it < reps; ++it) {
-      int rc = cvf_metric_large_launch(&pp, B, daux, da, k, dslot, ddense, dg, dq, de, nullptr);
+      int rc = cvf_metric_large_launch(&pp, B, daux, da, k, dslot, ddense, dg, dq, de, nullptr, nullptr, nullptr);
       if (rc) { printf("failed: %s\n", cvf_last_error()); return 1; }
     }
     (void)hipEventRecord(e1, nullptr);

@@ -14,6 +14,7 @@ run kt rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o bench 
 run pmc_fetch rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -o bench -- python3 "$R/bench.py" --steps 20 --warmup 5 --cpu-seconds 0 --no-extras
 run pmc_write rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -o bench -- python3 "$R/bench.py" --steps 20 --warmup 5 --cpu-seconds 0 --no-extras
 run pmc_sq rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d "$O/pmc_sq" -o bench -- python3 "$R/bench.py" --steps 20 --warmup 5 --cpu-seconds 0 --no-extras
+for b in 2000 16000; do rm -rf "$O/kt_c5_$b"; run kt_c5_$b rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_c5_$b" -o c5 -- python3 "$R/bench.py" --workload c5 --batch $b --cpu-seconds 0; done
 echo "== kt_k1"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_k1" -o k1 -- python3 "$R/tools/bench_k1_c5.py" > "$O/bench_k1.log" 2>&1 || { echo "bench_k1_c5 pass failed"; tail -5 "$O/bench_k1.log"; exit 1; }
 for c in FETCH_SIZE WRITE_SIZE; do echo "== pmc_k1_$c"; timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_k1_$c" -o k1 -- python3 "$R/tools/bench_k1_c5.py" 20000 > "$O/bench_k1_$c.log" 2>&1 || { echo "pmc k1 pass failed"; exit 1; }; done
 cd "$R"
