@@ -1805,7 +1805,10 @@ static int ef_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, cons
   // d0 = 384, 100 k of one SIMD's cycles per (tile, net) - is shared out over up to four blocks per (tile, net) when the grid
   // would otherwise leave most of the chip idle; with the activation hand-off they also get t0 = W0 q from a launch of its own
   const bool wide = mlp->dims[0] > kWideD;
-  const int64_t want = (768 + G * cfg->k - 1) / (G * cfg->k);
+  // (measured at the config-5 shape, backward us for zs = 1 / 2 / 3 / 4: 2000 frames 65 / 50 / 48 / 42, 4000 frames 81 / 62 / 83 / 79,
+  //  6000 frames 89 / 107 / 94 / 110, 16 000 frames 197 / 203 / 220 / 231 - every block repeats the chains, so sharing pays only
+  //  while the blocks are few: as many as keep the grid at or under 768 blocks)
+  const int64_t want = 768 / (G * cfg->k);
   a.zs = wide ? (int)(want < 1 ? 1 : want > 4 ? 4 : want) : 1;
   if (getenv("CVF_BWD_ZS")) a.zs = atoi(getenv("CVF_BWD_ZS")) > 0 && wide ? atoi(getenv("CVF_BWD_ZS")) : a.zs;   // developer switch
   a.t0 = nullptr;
