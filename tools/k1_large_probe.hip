@@ -70,10 +70,10 @@ int main(int argc, char** argv) {
   {
     const size_t ldsc = ((size_t)kGroup * pp.n_slot * 3 + (size_t)pp.d_r * kGroup) * sizeof(float);
     int nb = -1;
-    (void)hipFuncSetAttribute((const void*)k1_large_slice_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k1_large_slice_kernel<3>, 64 * kGroup, ldsc);
+    (void)hipFuncSetAttribute((const void*)k1_large_slice_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k1_large_slice_kernel<3, false>, 64 * kGroup, ldsc);
     hipFuncAttributes fa;
-    (void)hipFuncGetAttributes(&fa, (const void*)k1_large_slice_kernel<3>);
+    (void)hipFuncGetAttributes(&fa, (const void*)k1_large_slice_kernel<3, false>);
     printf("occupancy query: %d blocks/CU (err %d), dynamic LDS %zu B, static %zu B, regs %d\n", nb, (int)e, ldsc, fa.sharedSizeBytes, fa.numRegs);
   }
   hipEvent_t e0, e1;
