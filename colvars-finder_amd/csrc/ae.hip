@@ -110,12 +110,13 @@ struct AeMLayout {
   int img_off[CVF_MAX_LAYERS + 1];   // dword offset of image a_l, l = 1..L-1 (rows d_l + 1, the last one all ones)
   int zb_off, ab_off, w_off, tail_off, total;
   int zb_rows, ab_rows;
+  int skip0;   // > 0: the first layer's weights (theta[0 .. skip0), read once per tile by the forward pass) stay in global memory
 };
 // Operand tiles read up to 15 rows past an image / past zbar: those rows belong to the next region (next image, zbar, the
 // second zbar buffer, the weights), which always holds finite numbers (everything is zeroed once, then activations and
 // weights), and they meet A values forced to 0 or land in output rows that are discarded - no padding rows needed.
 // The forward-only pass (test loop, RegAutoEncoderTask's statistics pass) has no second zbar buffer.
-__host__ __device__ inline AeMLayout ae_mlayout(const cvf_mlp_desc& m, bool with_grad) {
+__host__ __device__ inline AeMLayout ae_mlayout_of(const cvf_mlp_desc& m, bool with_grad, bool tight) {
   AeMLayout lay;
   int rows = 0, dh = 1, dall = 1;
   for (int l = 1; l < m.n_layers; ++l) {
@@ -124,16 +125,28 @@ __host__ __device__ inline AeMLayout ae_mlayout(const cvf_mlp_desc& m, bool with
     dh = m.dims[l] > dh ? m.dims[l] : dh;
   }
   for (int l = 1; l <= m.n_layers; ++l) dall = m.dims[l] > dall ? m.dims[l] : dall;
-  lay.zb_rows = up16(dall);
-  lay.ab_rows = with_grad ? up16(dh) : 0;
+  // tight: zbar buffers of exactly the rows written (what is read past them lies in the next region, see above), and the
+  // first layer's weights left in global memory
+  lay.zb_rows = tight ? dall : up16(dall);
+  lay.ab_rows = with_grad ? (tight ? dh : up16(dh)) : 0;
+  lay.skip0 = tight && m.w_off[0][0] == 0 ? m.dims[0] * m.dims[1] : 0;
   lay.zb_off = rows * AP;
   lay.ab_off = lay.zb_off + lay.zb_rows * AP;
   lay.w_off = lay.ab_off + lay.ab_rows * AP;
   // batches of k-steps read up to 31 rows past zbar: when theta is shorter than that, a zeroed tail keeps them finite
-  const int np4 = (m.n_params + 3) & ~3;
+  const int np4 = (m.n_params - lay.skip0 + 3) & ~3;
   lay.tail_off = lay.w_off + np4;
   lay.total = lay.tail_off + (np4 < 32 * AP ? 32 * AP - np4 : 0);
   return lay;
+}
+// The roomy layout unless only the tight one lets TWO workgroups share a CU's 160 KB (RegAutoEncoderTask's chain with gradient:
+// 86.7 KB roomy - one workgroup per CU, 626 tiles in three rounds, 147 us - against 77.6 KB tight).
+__host__ __device__ inline AeMLayout ae_mlayout(const cvf_mlp_desc& m, bool with_grad) {
+  constexpr int kHalf = 80 * 1024 - 1024;   // (less the kernel's static tables)
+  const AeMLayout roomy = ae_mlayout_of(m, with_grad, false);
+  if (roomy.total * (int)sizeof(float) <= kHalf) return roomy;
+  const AeMLayout tight = ae_mlayout_of(m, with_grad, true);
+  return tight.total * (int)sizeof(float) <= kHalf ? tight : roomy;
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
   const int d0 = s_dims[0], dL = s_dims[L];
   float* ZB = lds + lay.zb_off;
   float* AB = lds + lay.ab_off;
-  float* WL = lds + lay.w_off;
+  float* WL = lds + lay.w_off - lay.skip0;   // indexed like theta (entries below skip0 are not in LDS)
   // zero everything (operand tiles read rows past an image: they must be finite), ones rows, weights
   {
     float4* l4 = reinterpret_cast<float4*>(lds);
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
     for (int i = tid; i < lay.w_off / 4; i += 256) l4[i] = z4;   // (every region is a multiple of AP = 68 dwords)
     for (int i = lay.tail_off / 4 + tid; i < lay.total / 4; i += 256) l4[i] = z4;
 #pragma unroll 4
-    for (int i = tid; i < mlp.n_params; i += 256) WL[i] = theta[i];
+    for (int i = lay.skip0 + tid; i < mlp.n_params; i += 256) WL[i] = theta[i];
   }
   __syncthreads();
   for (int l = 1; l < L; ++l)
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
     // ---- forward
     for (int l = 0; l < L; ++l) {
       const int din = s_dims[l], dout = s_dims[l + 1];
-      const float* Wl = WL + s_woff[l];
+      const float* Wl = (l == 0 && lay.skip0 > 0 ? theta : WL) + s_woff[l];
       const float* bl = WL + s_boff[l];
       const float* in = l > 0 ? lds + s_img[l] : nullptr;
       float* dst = l + 1 < L ? lds + s_img[l + 1] : ZB;
