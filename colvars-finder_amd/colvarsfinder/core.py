@@ -1650,8 +1650,9 @@ class RegAutoEncoderTask(TrainingTask):
         use_enc = self._use_enc
         eta1 = float(self.eta[1]) if self.eta[1] > self._eps else 0.0
         eta2 = float(self.eta[2]) if self.eta[2] > self._eps else 0.0
-        self._call("cvf_regae_forward", lib.cvf_regae_forward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
-                   lag_reg if use_reg else 0, K, P(w), P(ws["scratch"]), P(ws["y"]), self._n_enc_layers,
+        # (with a gradient to follow, the statistics pass leaves its activations in the scratch buffer for the gradient pass)
+        self._call("cvf_regae_forward", lib.cvf_regae_forward_keep if with_grad else lib.cvf_regae_forward, fl.desc, P(fl.theta),
+                   P(feat), P(idx), B, lag_ae, lag_reg if use_reg else 0, K, P(w), P(ws["scratch"]), P(ws["y"]), self._n_enc_layers,
                    P(ws["enc"]) if use_enc else None, P(ws["out2"]), _hip.stream())
         if dp:
             self._allreduce("allreduce_batch_sums", ws["out2"])     # [sum w err, sum w, (ratio: recomputed by cvf_regae_loss_row)]
@@ -1686,7 +1687,7 @@ class RegAutoEncoderTask(TrainingTask):
                     _dist.allreduce_sum_(wsum_t)
                 wsum = float(wsum_t)
             adam = self.optimizer.fused_args() if advance and eg is None and gen is None and not dp else None   # (their gradients are added before the update)
-            self._call("cvf_regae_backward", lib.cvf_regae_backward, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
+            self._call("cvf_regae_backward", lib.cvf_regae_backward_reuse, fl.desc, P(fl.theta), P(feat), P(idx), B, lag_ae,
                        lag_reg if use_reg else 0, K, P(w), P(w_lag) if use_reg else None, alpha / wsum,
                        float(self.gamma[0]) if use_reg else 0.0, P(ws["y"]) if use_reg else None,
                        P(ws["coef"]) if use_reg else None, self._n_enc_layers, P(ws["ecoef"]) if use_enc else None,

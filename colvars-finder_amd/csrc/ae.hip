@@ -173,6 +173,10 @@ struct AeReg {
   int k_enc;             // its width
   float* enc_tiled;      // forward pass: [T][k_enc][64] latent values (NULL: not wanted)
   const double* enc_coef;   // backward pass: [gS1(k), gS2(k*k)] of eta_1 norm + eta_2 orth penalties (NULL: off)
+  // activation hand-off between the statistics pass and the gradient pass of one step (cvf_regae_forward_keep /
+  // cvf_regae_backward_reuse): every tile's images and last-layer outputs, [n_tiles][image rows + d_L][64]
+  float* hand;           // NULL: none
+  int hand_mode;         // 1: the forward pass stores them, 2: the gradient pass loads them instead of running the chain forward
 };
 
 template <bool TANH>
@@ -242,8 +246,14 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
     const float* __restrict__ frow = feat_rows + (frame + in_shift) * d0;
     const float* __restrict__ frow_t = feat_rows + (frame + reg.lag_t) * d0;
     CVF_STAMP(20);
+    const int n_img = lay.zb_off / AP;   // rows of the images (activations of layers 1..L-1, each with its row of ones)
+    float* hand = reg.hand != nullptr ? reg.hand + tile * (int64_t)(n_img + dL) * CVF_TILE + fcol : nullptr;
+    if (hand != nullptr && reg.hand_mode == 2) {
+      // the statistics pass of this step left the activations of this tile: this wave's 16 frame columns of every row
+      for (int r = kq; r < n_img + dL; r += 4) (r < n_img ? lds + r * AP : ZB + (r - n_img) * AP)[fcol] = hand[(int64_t)r * CVF_TILE];
+    }
     // ---- forward
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < (hand != nullptr && reg.hand_mode == 2 ? 0 : L); ++l) {
       const int din = s_dims[l], dout = s_dims[l + 1];
       const float* Wl = (l == 0 && lay.skip0 > 0 ? theta : WL) + s_woff[l];
       const float* bl = WL + s_boff[l];
@@ -305,6 +315,9 @@ __global__ __launch_bounds__(256, 2) void ae_mfma_kernel(cvf_mlp_desc mlp, const
       if (l == 0) layer(std::integral_constant<int, 20>{});   // 80 inputs per global round trip
       else layer(std::integral_constant<int, 8>{});
       CVF_STAMP(41 + l);
+    }
+    if (hand != nullptr && reg.hand_mode == 1) {
+      for (int r = kq; r < n_img + dL; r += 4) hand[(int64_t)r * CVF_TILE] = (r < n_img ? lds + r * AP : ZB + (r - n_img) * AP)[fcol];
     }
     CVF_STAMP(21);
     if (reg.enc_tiled != nullptr && reg.write_y && !lagged) {   // the latent vector of this wave's frames
@@ -1159,14 +1172,22 @@ extern "C" int cvf_ae_step(const cvf_mlp_desc* mlp, const float* theta, const fl
 // ---- RegAutoEncoderTask (time-lagged autoencoder + transfer-operator regulariser heads)
 static int regae_grid(int64_t n_tiles) { return (int)(n_tiles < kAeMaxBlocks ? n_tiles : kAeMaxBlocks); }
 
-extern "C" int64_t cvf_regae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B) {
+static int64_t regae_hand_rows(const cvf_mlp_desc* mlp) {   // image rows + last-layer outputs (see AeReg.hand)
+  int64_t rows = mlp->dims[mlp->n_layers];
+  for (int l = 1; l < mlp->n_layers; ++l) rows += mlp->dims[l] + 1;
+  return rows;
+}
+static int64_t regae_hand_offset(const cvf_mlp_desc* mlp, int64_t B) {   // floats of the slab and the loss partials in front of it
   const int64_t G = regae_grid(2 * cvf_ntiles(B));
-  return G * mlp->n_params + 4 * G + 4;
+  return (G * mlp->n_params + 4 * G + 4 + 3) & ~(int64_t)3;
+}
+extern "C" int64_t cvf_regae_scratch_floats(const cvf_mlp_desc* mlp, int64_t B) {
+  return regae_hand_offset(mlp, B) + 2 * cvf_ntiles(B) * regae_hand_rows(mlp) * CVF_TILE;
 }
 
 static int regae_launch(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx, int64_t B,
                         const float* w, double mse_scale, bool with_grad, float* scratch, int32_t* step_count, AeReg reg,
-                        int* grid_out, hipStream_t s) {
+                        int* grid_out, hipStream_t s, bool handoff = false) {
   CVF_REQUIRE(mlp->n_nets == 1 && mlp->n_layers >= 2 && mlp->n_layers <= CVF_MAX_LAYERS, "cvf_regae: one chain expected");
   CVF_REQUIRE(reg.K >= 0 && reg.K <= CVF_MAX_NETS && mlp->dims[mlp->n_layers] == mlp->dims[0] + reg.K,
               "cvf_regae: the chain must end in d_0 = %d reconstruction rows + K = %d heads (it has %d outputs)", mlp->dims[0],
@@ -1186,6 +1207,10 @@ static int regae_launch(const cvf_mlp_desc* mlp, const float* theta, const float
   reg.n_tiles = (reg.K > 0 && reg.lag_in > 0) ? 2 * reg.T : reg.T;
   const int G = regae_grid(reg.n_tiles);
   *grid_out = G;
+  if (handoff) {
+    reg.hand = scratch + regae_hand_offset(mlp, B);
+    reg.hand_mode = with_grad ? 2 : 1;
+  }
   float* slab = scratch;
   double* partial = reinterpret_cast<double*>(scratch + (((int64_t)G * mlp->n_params + 1) & ~(int64_t)1));
   auto kernel = chain_is_tanh(mlp) ? ae_mfma_kernel<true> : ae_mfma_kernel<false>;
@@ -1195,9 +1220,9 @@ static int regae_launch(const cvf_mlp_desc* mlp, const float* theta, const float
   return cvf_check_launch("ae_mfma_kernel");
 }
 
-extern "C" int cvf_regae_forward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
-                                 int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, float* scratch,
-                                 float* y_tiled, int n_enc_layers, float* enc_tiled, double* out2, void* stream) {
+static int regae_forward_impl(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
+                              int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, float* scratch,
+                              float* y_tiled, int n_enc_layers, float* enc_tiled, double* out2, void* stream, bool keep) {
   CVF_REQUIRE(mlp && theta && feat_rows && w && scratch && out2 && B > 0 && (K == 0 || y_tiled), "cvf_regae_forward: bad argument");
   AeReg reg = {};
   reg.K = K;
@@ -1209,18 +1234,30 @@ extern "C" int cvf_regae_forward(const cvf_mlp_desc* mlp, const float* theta, co
   reg.enc_tiled = enc_tiled;
   int G = 0;
   hipStream_t s = (hipStream_t)stream;
-  int rc = regae_launch(mlp, theta, feat_rows, idx, B, w, 0.0, false, scratch, nullptr, reg, &G, s);
+  int rc = regae_launch(mlp, theta, feat_rows, idx, B, w, 0.0, false, scratch, nullptr, reg, &G, s, keep);
   if (rc) return rc;
   double* partial = reinterpret_cast<double*>(scratch + (((int64_t)G * mlp->n_params + 1) & ~(int64_t)1));
   hipLaunchKernelGGL(ae_loss_sum_kernel, dim3(1), dim3(64), 0, s, partial, G, out2);
   return cvf_check_launch("ae_loss_sum_kernel");
 }
+extern "C" int cvf_regae_forward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
+                                 int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, float* scratch,
+                                 float* y_tiled, int n_enc_layers, float* enc_tiled, double* out2, void* stream) {
+  return regae_forward_impl(mlp, theta, feat_rows, idx, B, lag_target, lag_input, K, w, scratch, y_tiled, n_enc_layers, enc_tiled,
+                            out2, stream, false);
+}
+extern "C" int cvf_regae_forward_keep(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
+                                      int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, float* scratch,
+                                      float* y_tiled, int n_enc_layers, float* enc_tiled, double* out2, void* stream) {
+  return regae_forward_impl(mlp, theta, feat_rows, idx, B, lag_target, lag_input, K, w, scratch, y_tiled, n_enc_layers, enc_tiled,
+                            out2, stream, true);
+}
 
-extern "C" int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
-                                  int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, const float* w_lag,
-                                  double mse_scale, double head_scale, const float* y_tiled, const double* coef,
-                                  int n_enc_layers, const double* enc_coef, float* scratch, float* grad, const float* mask,
-                                  int32_t* step_count, const cvf_adam_args* adam, void* stream) {
+static int regae_backward_impl(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
+                               int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, const float* w_lag,
+                               double mse_scale, double head_scale, const float* y_tiled, const double* coef,
+                               int n_enc_layers, const double* enc_coef, float* scratch, float* grad, const float* mask,
+                               int32_t* step_count, const cvf_adam_args* adam, void* stream, bool reuse) {
   CVF_REQUIRE(mlp && theta && feat_rows && w && scratch && grad && B > 0, "cvf_regae_backward: bad argument");
   CVF_REQUIRE(coef == nullptr || (K > 0 && w_lag && y_tiled), "cvf_regae_backward: the regulariser needs heads, w_lag and y_tiled");
   CVF_REQUIRE(adam == nullptr || (adam->theta && adam->m && adam->v && adam->step_count), "cvf_regae_backward: incomplete adam arguments");
@@ -1235,7 +1272,7 @@ extern "C" int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, c
   reg.enc_layer = n_enc_layers;
   reg.enc_coef = enc_coef;
   int G = 0;
-  int rc = regae_launch(mlp, theta, feat_rows, idx, B, w, mse_scale, true, scratch, step_count, reg, &G, (hipStream_t)stream);
+  int rc = regae_launch(mlp, theta, feat_rows, idx, B, w, mse_scale, true, scratch, step_count, reg, &G, (hipStream_t)stream, reuse);
   if (rc) return rc;
   cvf_adam_args ad;
   if (adam != nullptr) {
@@ -1244,6 +1281,22 @@ extern "C" int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, c
     ad.packed = nullptr;
   }
   return cvf_slab_reduce_impl(scratch, G, mlp->n_params, grad, mask, adam != nullptr ? &ad : nullptr, stream);
+}
+extern "C" int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
+                                  int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, const float* w_lag,
+                                  double mse_scale, double head_scale, const float* y_tiled, const double* coef,
+                                  int n_enc_layers, const double* enc_coef, float* scratch, float* grad, const float* mask,
+                                  int32_t* step_count, const cvf_adam_args* adam, void* stream) {
+  return regae_backward_impl(mlp, theta, feat_rows, idx, B, lag_target, lag_input, K, w, w_lag, mse_scale, head_scale, y_tiled, coef,
+                             n_enc_layers, enc_coef, scratch, grad, mask, step_count, adam, stream, false);
+}
+extern "C" int cvf_regae_backward_reuse(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx,
+                                        int64_t B, int64_t lag_target, int64_t lag_input, int K, const float* w, const float* w_lag,
+                                        double mse_scale, double head_scale, const float* y_tiled, const double* coef,
+                                        int n_enc_layers, const double* enc_coef, float* scratch, float* grad, const float* mask,
+                                        int32_t* step_count, const cvf_adam_args* adam, void* stream) {
+  return regae_backward_impl(mlp, theta, feat_rows, idx, B, lag_target, lag_input, K, w, w_lag, mse_scale, head_scale, y_tiled, coef,
+                             n_enc_layers, enc_coef, scratch, grad, mask, step_count, adam, stream, true);
 }
 
 // row of RegAutoEncoderTask's loss list (core.py:1112-1124): [loss, ae, npl, pen, eig_1..K, enc_grad (0), enc_norm, enc_orth]

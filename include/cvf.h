@@ -337,6 +337,16 @@ int cvf_regae_backward(const cvf_mlp_desc* mlp, const float* theta, const float*
                        double head_scale, const float* y_tiled, const double* coef, int n_enc_layers, const double* enc_coef,
                        float* scratch, float* grad, const float* mask, int32_t* step_count, const cvf_adam_args* adam,
                        void* stream);
+/* The two passes of ONE step on the same (theta, rows, lags): _keep leaves every tile's activations in `scratch`, _reuse reads
+ * them instead of running the chain forward again (same arguments as the plain calls). */
+int cvf_regae_forward_keep(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx, int64_t B,
+                      int64_t lag_target, int64_t lag_input, int K, const float* w, float* scratch, float* y_tiled,
+                      int n_enc_layers, float* enc_tiled, double* out2, void* stream);
+int cvf_regae_backward_reuse(const cvf_mlp_desc* mlp, const float* theta, const float* feat_rows, const int64_t* idx, int64_t B,
+                       int64_t lag_target, int64_t lag_input, int K, const float* w, const float* w_lag, double mse_scale,
+                       double head_scale, const float* y_tiled, const double* coef, int n_enc_layers, const double* enc_coef,
+                       float* scratch, float* grad, const float* mask, int32_t* step_count, const cvf_adam_args* adam,
+                       void* stream);
 /* latent penalties from the latent vector's batch sums (cvf_ef_stats layout [W, S1(k), S2(i<=j), ..]):
  * terms = {sum_j (var_j - 1)^2, sum_{i<j} cov_ij^2} (core.py:934, 966); enc_coef [k + k*k] for cvf_regae_backward */
 int cvf_regae_enc_loss(const double* stats, int k, double eta1, double eta2, double* terms, double* enc_coef, void* stream);
