@@ -468,7 +468,7 @@ def other_configs():
     every frame twice, 2 (12 N + 4) + O(k) = 120 008 B per frame-step at N = 5000.  Extra measurements, not `value`."""
     import subprocess
     res = {}
-    for wl, extra in (("c2", []), ("transfer", []), ("c5", ["--batch", "2000"]), ("c5", ["--batch", "16000"])):
+    for wl, extra in (("c2", []), ("transfer", []), ("regae", []), ("c5", ["--batch", "2000"]), ("c5", ["--batch", "16000"])):
         key = wl if not extra else f"{wl}_batch{extra[1]}"
         note(f"other configurations: {key}")
         try:
