@@ -802,11 +802,11 @@ __global__ __launch_bounds__(256) void ef_fwd_wg_kernel(cvf_mlp_desc mlp, const 
 // (12 k-steps = 36 loads at d0 = 384) are requested in one go, the partial sums meet in LDS and are added in wave order.
 // One wave per (half) tile walked the 96 k-steps of d0 = 384 behind a two-chunk operand ring - 16 dependent memory round
 // trips, 45 k of the forward kernel's 79 k cycles; a wave cannot keep more than 63 loads in flight, so a deeper ring does
-// not help, more waves do.  On return every wave holds the sum.
+// not help, more waves do.  On return tot[((rt * 4 + ft) * 4 + r) * 64 + lane] holds element (rt, ft, r) of the sum (all 64 frames).
 constexpr int kWW = 8;
 template <int H>
-__device__ __forceinline__ void wide_layer0(Vec<H, 4>& X, const float* __restrict__ pk0, int D,
-                                            const float* __restrict__ in_lane, int lane, int wave, float* part, float* tot) {
+__device__ __forceinline__ void wide_layer0(const float* __restrict__ pk0, int D, const float* __restrict__ in_lane, int lane, int wave,
+                                            float* part, float* tot) {
   constexpr int RT = Hid<H>::RT, CH = 12, NV = RT * 16;
   const int S = (D + 3) >> 2;
   const int per = (S + kWW - 1) / kWW;
@@ -836,19 +836,15 @@ __device__ __forceinline__ void wide_layer0(Vec<H, 4>& X, const float* __restric
     tot[i * 64 + lane] = acc;
   }
   __syncthreads();
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) X.v[rt][ft][r] += tot[((rt * 4 + ft) * 4 + r) * 64 + lane];
 }
 template <int H>
 constexpr size_t wide_lds_bytes() { return (size_t)(kWW + 1) * Hid<H>::RT * 16 * 64 * sizeof(float); }
 
-// K4a for wide first layers: one block of kWW waves per (tile, net).  First layer by wide_layer0; the short rest of the chain
-// (hidden layers, y, the d chain) is repeated by every wave from the shared sum; the rows of g = W0^T d_0 (24 row tiles at
-// d0 = 384) are dealt to the waves.  Hands the hidden activations to the backward kernel like ef_fwd_wg_kernel.
+// K4a for wide first layers: one block of kWW waves per (tile, net).  First layer by wide_layer0 (all waves); the short rest of the
+// chain (hidden layers, y, the d chain) runs ONCE, waves 0..3 each on one 16-frame group of the tile (as eight copies on all 64
+// frames it was 13 k of the block's 31 k cycles and 96 registers of activations per wave); d_0 goes through LDS to all waves, which
+// share out the rows of g = W0^T d_0 (24 row tiles at d0 = 384).  Hands the hidden activations to the backward kernel like
+// ef_fwd_wg_kernel.
 template <int H, int NH>
 __global__ __launch_bounds__(64 * kWW) void ef_fwd_wide_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                                const float* __restrict__ packed,
@@ -868,22 +864,28 @@ __global__ __launch_bounds__(64 * kWW) void ef_fwd_wide_kernel(cvf_mlp_desc mlp,
   const int fo = 4 * col;
   const float* in_lane = feat + tile * (int64_t)D * CVF_TILE + fo;
   const bool want_g = g_tiled != nullptr;
+  const bool chain = wave < 4;   // (uniform per wave) this wave runs the chain for frame group ft = wave: frames 4 col + ft
   CVF_STAMP(0);
   // everything the rest of the chain needs is requested before the first layer
   HConst<H> bias[NH];
-#pragma unroll
-  for (int l = 0; l < NH; ++l) load_hconst<H>(bias[l], theta + mlp.b_off[net][l], q);
   HFrag<H> hf[NH > 1 ? NH - 1 : 1], tf[NH > 1 ? NH - 1 : 1];
-#pragma unroll
-  for (int l = 1; l < NH; ++l) load_hfrag<H>(hf[l - 1], pk + L.fh(l), lane);
   float wl[RT][4];
-  load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
-  const float bL = theta[mlp.b_off[net][NH]];
+  float bL = 0.0f;
+  if (chain) {
+#pragma unroll
+    for (int l = 0; l < NH; ++l) load_hconst<H>(bias[l], theta + mlp.b_off[net][l], q);
+#pragma unroll
+    for (int l = 1; l < NH; ++l) load_hfrag<H>(hf[l - 1], pk + L.fh(l), lane);
+    load_hid_const<H>(theta + mlp.w_off[net][NH], q, wl);
+    bL = theta[mlp.b_off[net][NH]];
+    if (want_g) {
+#pragma unroll
+      for (int l = 1; l < NH; ++l) load_hfrag<H>(tf[l - 1], pk + L.th(l), lane);
+    }
+  }
   const float* pT0 = pk + L.t0();
   float t0f[kGT][NG];   // W0^T fragments of this wave's first kGT row tiles of g
   if (want_g) {
-#pragma unroll
-    for (int l = 1; l < NH; ++l) load_hfrag<H>(tf[l - 1], pk + L.th(l), lane);
 #pragma unroll
     for (int i = 0; i < kGT; ++i) {
       const int rt = wave + kWW * i < CT ? wave + kWW * i : CT - 1;
@@ -892,57 +894,73 @@ __global__ __launch_bounds__(64 * kWW) void ef_fwd_wide_kernel(cvf_mlp_desc mlp,
     }
   }
   CVF_STAMP(1);
-  Vec<H, FT> h[NH];
-  set_const<H, FT>(h[0], bias[0]);
-  wide_layer0<H>(h[0], pk + L.f0(), D, in_lane, lane, wave, part, tot);
+  wide_layer0<H>(pk + L.f0(), D, in_lane, lane, wave, part, tot);
   CVF_STAMP(2);
-  tanh_inplace<H, FT>(h[0], mlp.act[0]);
+  if (chain) {
+    const int ft = wave;
+    Vec<H, 1> h[NH];
+    set_const<H, 1>(h[0], bias[0]);
 #pragma unroll
-  for (int l = 1; l < NH; ++l) {
-    set_const<H, FT>(h[l], bias[l]);
-    hidden_mul<H, FT>(h[l], hf[l - 1], h[l - 1]);
-    tanh_inplace<H, FT>(h[l], mlp.act[0]);
-  }
-  CVF_STAMP(3);
-  if (wave == 0) {
-    float yv[FT];
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) {
+      for (int r = 0; r < 4; ++r) h[0].v[rt][0][r] += tot[((rt * 4 + ft) * 4 + r) * 64 + lane];
+    tanh_inplace<H, 1>(h[0], mlp.act[0]);
+#pragma unroll
+    for (int l = 1; l < NH; ++l) {
+      set_const<H, 1>(h[l], bias[l]);
+      hidden_mul<H, 1>(h[l], hf[l - 1], h[l - 1]);
+      tanh_inplace<H, 1>(h[l], mlp.act[0]);
+    }
+    CVF_STAMP(3);
+    {
       float p = 0.0f;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p = fmaf(wl[rt][r], h[NH - 1].v[rt][ft][r], p);
-      yv[ft] = sum_over_q(p) + bL;
+        for (int r = 0; r < 4; ++r) p = fmaf(wl[rt][r], h[NH - 1].v[rt][0][r], p);
+      const float yv = sum_over_q(p) + bL;
+      if (q == 0) y_tiled[(tile * k + net) * CVF_TILE + fo + ft] = yv;
     }
-    if (q == 0) store_frames<FT>(y_tiled + (tile * k + net) * CVF_TILE + fo, yv);
-  }
-  if (saved != nullptr) {
-    float* sv = saved + (tile * k + net) * (int64_t)(NH * saved_per_vec<H>());
+    if (saved != nullptr) {   // the layout of save_vec (ef_frag.hpp), this wave's frame group
+      float* sv = saved + (tile * k + net) * (int64_t)(NH * saved_per_vec<H>());
 #pragma unroll
-    for (int l = 0; l < NH; ++l)
-      if (wave == 1 + l % (kWW - 1)) save_vec<H>(sv + l * saved_per_vec<H>(), h[l], lane);
+      for (int l = 0; l < NH; ++l)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) sv[l * saved_per_vec<H>() + (g * 2 + (ft >> 1)) * 128 + 2 * lane + (ft & 1)] = h[l].v[g >> 2][0][g & 3];
+    }
+    CVF_STAMP(4);
+    if (want_g) {
+      Vec<H, 1> d;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float hv = h[NH - 1].v[rt][0][r];
+          d.v[rt][0][r] = wl[rt][r] * act_d1(mlp.act[0], hv);
+        }
+#pragma unroll
+      for (int l = NH - 1; l >= 1; --l) {
+        Vec<H, 1> e;
+        init_bias<H, 1>(e, nullptr, q);
+        hidden_mul<H, 1>(e, tf[l - 1], d);
+        tangent_of<H, 1>(d, h[l - 1], e, mlp.act[0]);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[((rt * 4 + ft) * 4 + r) * 64 + lane] = d.v[rt][0][r];   // (part: free since wide_layer0's sums)
+    }
   }
-  CVF_STAMP(4);
   if (!want_g) return;
+  __syncthreads();
+  CVF_STAMP(5);
   Vec<H, FT> d;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float hv = h[NH - 1].v[rt][ft][r];
-        d.v[rt][ft][r] = wl[rt][r] * act_d1(mlp.act[0], hv);
-      }
-#pragma unroll
-  for (int l = NH - 1; l >= 1; --l) {
-    Vec<H, FT> e;
-    init_bias<H, FT>(e, nullptr, q);
-    hidden_mul<H, FT>(e, tf[l - 1], d);
-    tangent_of<H, FT>(d, h[l - 1], e, mlp.act[0]);
-  }
-  CVF_STAMP(5);
+      for (int r = 0; r < 4; ++r) d.v[rt][ft][r] = part[((rt * 4 + ft) * 4 + r) * 64 + lane];
   float* gout = g_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + fo;
   auto g_tile = [&](int rt, const float (&af)[NG]) {
     f32x4 acc[FT];
@@ -992,10 +1010,18 @@ __global__ __launch_bounds__(64 * kWW) void ef_t0_kernel(cvf_mlp_desc mlp, const
   const PackLayout L = pack_layout(H, mlp.n_layers - 1, D);
   const float* pk = packed + (int64_t)net * L.per_net;
   const float* in_lane = q_tiled + (tile * k + net) * (int64_t)D * CVF_TILE + 4 * col;
-  Vec<H, 4> t;
-  init_bias<H, 4>(t, nullptr, q);
-  wide_layer0<H>(t, pk + L.f0(), D, in_lane, lane, wave, wide_lds, wide_lds + kWW * RT * 16 * 64);
-  if (wave == 0) save_vec<H>(t0_out + (tile * k + net) * (int64_t)saved_per_vec<H>(), t, lane);
+  float* tot = wide_lds + kWW * RT * 16 * 64;
+  wide_layer0<H>(pk + L.f0(), D, in_lane, lane, wave, wide_lds, tot);
+  if (wave == 0) {
+    Vec<H, 4> t;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.v[rt][ft][r] = tot[((rt * 4 + ft) * 4 + r) * 64 + lane];
+    save_vec<H>(t0_out + (tile * k + net) * (int64_t)saved_per_vec<H>(), t, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
