@@ -199,7 +199,9 @@ int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const float* pac
                    int64_t n_tiles, float* y_tiled, float* g_tiled, float* saved, void* stream);
 /* `saved` (may be NULL): cvf_ef_saved_floats() floats in which the forward kernel leaves the hidden activations (and
  * the back-propagated output sensitivities) of every (tile, net) for cvf_ef_backward, which then skips recomputing
- * them.  Opaque layout; 0 floats = this shape has no hand-off, pass NULL to both calls. */
+ * them; for first layers wider than 128 inputs the buffer also has room for the tangent chain's first product, which
+ * cvf_ef_backward computes with a launch of its own ahead of its main kernel).  Opaque layout; 0 floats = this shape has no
+ * hand-off, pass NULL to both calls. */
 int64_t cvf_ef_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles);
 
 /* --- K4a + K2/K3 + K5 in one go for the fast layout (pure position features on a contiguous align set, d_r <= 72):
