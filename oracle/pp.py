@@ -70,8 +70,63 @@ def kabsch_rotation(x, align_idx, ref_c, w=None):
     return R, c
 
 
-def features_of(xal, features, use_angle_value=False):
-    """xal [B,N,3] -> [B,d_r]; list order, molann conventions (see module docstring)."""
+def _features_grouped(xal, features, use_angle_value):
+    """features_of with the features of one type evaluated together (same formulas on [B, n_type, 3] operands), the columns
+    put back into list order at the end; the atoms the features read are gathered once."""
+    used = sorted({int(i) for _, atoms in features for i in atoms})
+    slot = {a: s_ for s_, a in enumerate(used)}
+    xs = xal[:, used, :]
+    B = xal.shape[0]
+    cols, blocks, start = {}, [], 0      # cols[feature number] = its column indices in the concatenated blocks
+    by_type = {}
+    for n_, (ftype, atoms) in enumerate(features):
+        by_type.setdefault(ftype, []).append((n_, [slot[int(i)] for i in atoms]))
+
+    def pick(rows, j):
+        return xs[:, [r[1][j] for r in rows], :]
+
+    for ftype, rows in by_type.items():
+        if ftype == "position":
+            for n_, sl in rows:
+                blocks.append(xs[:, sl, :].reshape(B, -1))
+                cols[n_] = list(range(start, start + 3 * len(sl)))
+                start += 3 * len(sl)
+            continue
+        if ftype == "bond":
+            val = torch.linalg.norm(pick(rows, 1) - pick(rows, 0), dim=2)
+            width = 1
+        elif ftype == "angle":
+            r21, r23 = pick(rows, 0) - pick(rows, 1), pick(rows, 2) - pick(rows, 1)
+            cs = (r21 * r23).sum(2) / (torch.linalg.norm(r21, dim=2) * torch.linalg.norm(r23, dim=2))
+            val = torch.acos(cs) if use_angle_value else cs
+            width = 1
+        elif ftype == "dihedral":
+            r12, r23, r34 = pick(rows, 1) - pick(rows, 0), pick(rows, 2) - pick(rows, 1), pick(rows, 3) - pick(rows, 2)
+            n1, n2 = torch.linalg.cross(r12, r23, dim=2), torch.linalg.cross(r23, r34, dim=2)
+            inv = 1.0 / (torch.linalg.norm(n1, dim=2) * torch.linalg.norm(n2, dim=2))
+            cs = (n1 * n2).sum(2) * inv
+            sn = (n1 * r34).sum(2) * torch.linalg.norm(r23, dim=2) * inv
+            if use_angle_value:
+                val, width = torch.atan2(sn, cs), 1
+            else:
+                val, width = torch.stack([cs, sn], dim=2).reshape(B, -1), 2
+        else:
+            raise ValueError(ftype)
+        blocks.append(val)
+        for j, (n_, _) in enumerate(rows):
+            cols[n_] = list(range(start + width * j, start + width * (j + 1)))
+        start += width * len(rows)
+    order = [c for n_ in range(len(features)) for c in cols[n_]]
+    return torch.cat(blocks, dim=1)[:, order]
+
+
+def features_of(xal, features, use_angle_value=False, compact=False):
+    """xal [B,N,3] -> [B,d_r]; list order, molann conventions (see module docstring).
+    ``compact``: the same formulas evaluated per feature TYPE on stacked operands, the atoms gathered once - the autograd graph
+    of a 5000-atom frame with ~200 features is then a few dozen nodes instead of thousands (oracle/chunked.py); equal to the
+    per-feature evaluation to rounding (tests/test_oracle_pp.py)."""
+    if compact:
+        return _features_grouped(xal, features, use_angle_value)
     out = []
     for ftype, atoms in features:
         if ftype == "position":
@@ -117,8 +172,9 @@ class AlignFeature(torch.nn.Module):
     uniform weights): weighted centroids, weighted covariance.
     """
 
-    def __init__(self, align_idx, ref_pos, features, use_angle_value=False, align_weights=None):
+    def __init__(self, align_idx, ref_pos, features, use_angle_value=False, align_weights=None, compact=False):
         super().__init__()
+        self.compact = bool(compact)
         ref = torch.as_tensor(np.asarray(ref_pos), dtype=torch.get_default_dtype())
         self.register_buffer("align_idx", torch.as_tensor(np.asarray(align_idx), dtype=torch.long))
         if align_weights is None:
@@ -136,7 +192,7 @@ class AlignFeature(torch.nn.Module):
         return torch.matmul(x - c, R)
 
     def forward(self, x):
-        return features_of(self.align(x), self.features, self.use_angle_value)
+        return features_of(self.align(x), self.features, self.use_angle_value, self.compact)
 
 
 # --------------------------------------------------------------------------------------

@@ -51,3 +51,29 @@ def pp_spec(g):
         return None
     return dict(align_idx=[int(i) for i in g["align_idx"]], ref_pos=np.array(g["ref_pos"]),
                 features=features_list(g), use_angle_value=bool(g["use_angle_value"]))
+
+
+# Bench-sized fixtures (tools/gen_golden.py run_big_cases: BASELINE configs 2 / 3 at 100 000 frames, batches of 20 000): the
+# file holds the arguments of tests.synth.make_molecule_traj instead of the frames ("seed + outputs only").
+BIG_EF_CASES = ["big_gen_c3", "big_tr_c3"]
+BIG_AE_CASES = ["big_ae_c2"]
+
+
+class Synth:
+    """An npz fixture whose ``traj`` / ``w`` entries are regenerated from ``traj_gen`` = (atoms, frames, seed)."""
+
+    def __init__(self, g):
+        from tests.synth import make_molecule_traj
+        self._g = g
+        n_atoms, n_frames, seed = (int(v) for v in g["traj_gen"])
+        traj, w, ref = make_molecule_traj(n_atoms, n_frames, seed)
+        assert np.array_equal(ref, np.array(g["ref_pos"])), "make_molecule_traj no longer reproduces the fixture's reference structure"
+        self._extra = {"traj": traj, "w": w}
+        self.files = list(g.files) + ["traj", "w"]
+
+    def __getitem__(self, key):
+        return self._extra[key] if key in self._extra else self._g[key]
+
+
+def load_big(name, tag):
+    return Synth(load(name, tag))

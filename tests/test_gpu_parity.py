@@ -13,7 +13,7 @@ the suite red, not sit inside a 50x margin):
   per-step LOSS of the training traces             1.5e-6                      1e-5     5.1e-6                        3e-5
   the other columns (npl, pen, eig) of the traces  1.9e-6                      1e-5     4.1e-5 (idem)                 1.5e-4
   final parameters, |d| / (|p| + 1)                1.4e-6                      1e-5     4.4e-5 (idem)                 1.5e-4
-  learned CVs / largest |CV|                       4.4e-6                      1.5e-5   1.7e-5 (= the reference's     5e-5
+  learned CVs / largest |CV|                       4.4e-6                      1e-5     1.7e-5 (= the reference's     5e-5
                                                                                          own fp32 vs fp64 distance)
 The fp32 fixtures carry the reference's own fp32 rounding (its fp32 and fp64 runs differ by exactly these amounts), which no
 implementation can undercut; against the exact (fp64) answer every figure is inside the north star's 1e-5.
@@ -33,7 +33,9 @@ pytestmark = pytest.mark.gpu
 RTOL64, RTOL32 = 2e-5, 2e-4          # oracle-vs-kernel tests on random nets / shapes without a recorded error table
 # fixture tests (table in the module docstring): {tag: (loss, npl_and_eig, grad_over_gmax)} and the trace bars
 KAT_TOL = {"f64": (1e-6, 1e-6, 1e-5), "f32": (1e-5, 1e-4, 5e-4)}
-TRACE_TOL = {"f64": dict(loss=1e-5, rows=1e-5, params=1e-5, cv=1.5e-5), "f32": dict(loss=3e-5, rows=1.5e-4, params=1.5e-4, cv=5e-5)}
+TRACE_TOL = {"f64": dict(loss=1e-5, rows=1e-5, params=1e-5, cv=1e-5), "f32": dict(loss=3e-5, rows=1.5e-4, params=1.5e-4, cv=5e-5)}
+REGAE_PARAM_TOL = {"f64": 1.5e-5, "f32": 1e-4}   # RegAutoEncoderTask: final encoder / decoder parameters, learned CVs, regulariser outputs
+REGAE_REG_PARAM_TOL = {"f64": 2.5e-4, "f32": 5e-4}   # ... the regulariser nets' own parameters (see test_regae_train_trace)
 
 
 @pytest.fixture(scope="module")
@@ -216,12 +218,13 @@ def test_stats_are_bitwise_reproducible(dev):
 
 
 # ------------------------------------------------------------------------------------------------ train traces
-def assert_rows(got, want, tol):
+def assert_rows(got, want, tol, noise=0.0):
     """Loss rows [loss, npl, pen, eig..]: the loss column to `tol['loss']` relative, every column to `tol['rows']` in
-    |got - want| / (|want| + 1) (entries near zero: the penalty late in training)."""
+    |got - want| / (|want| + 1) (entries near zero: the penalty late in training).  `noise`: absolute allowance per entry."""
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
-    np.testing.assert_allclose(got[..., 0], want[..., 0], rtol=tol["loss"])
-    assert float(np.max(np.abs(got - want) / (np.abs(want) + 1.0))) <= tol["rows"]
+    noise = np.broadcast_to(np.asarray(noise, dtype=np.float64), want.shape)
+    assert np.all(np.abs(got[..., 0] - want[..., 0]) <= tol["loss"] * np.abs(want[..., 0]) + noise[..., 0])
+    assert float(np.max((np.abs(got - want) - noise) / (np.abs(want) + 1.0))) <= tol["rows"]
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
@@ -252,6 +255,99 @@ def test_ef_train_trace(dev, name, tag):
     ref_cv = np.array(g["colvar_probe"])
     ref_c = ref_cv - ref_cv.mean(0)
     np.testing.assert_allclose(cv - cv.mean(0), ref_c, rtol=0, atol=tol["cv"] * np.abs(ref_c).max())
+
+
+# ------------------------------------------------------------------------------------------------ bench-sized fixtures
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+@pytest.mark.parametrize("name", goldens.BIG_EF_CASES)
+def test_ef_bench_size_vs_reference(dev, name, tag):
+    """the step bench.py times (BASELINE config 3: 22 atoms, k = 3, nets [66,20,20,20,1], batches of 20 000 =
+    1250 sixteen-frame units, 40 groups in the finishing launch, one-round backward; and the same in transfer mode, lag 3)
+    against the REFERENCE run at that size (tools/gen_golden.py run_big_cases: 100 000 seeded frames, the reference's
+    loss_func on the first 20 000 with every parameter gradient, then its train() for two epochs = 8 (6) train + 2 test steps)."""
+    t_loss, t_eig, t_grad = KAT_TOL[tag]
+    tol = TRACE_TOL[tag]
+    g = goldens.load_big(name, tag)
+    task, model = build_task(g, dev)
+    assert task._use_ef16()
+    lag, B = int(g["lag_idx"]), int(g["kat_n"])
+    traj, w = g["traj"], g["w"]
+    X, wt = torch.tensor(traj[:B]), torch.tensor(w[:B])
+    Xl = torch.tensor(traj[lag:lag + B]) if lag else None
+    wl = torch.tensor(w[lag:lag + B]) if lag else None
+    loss, eig, npl, pen, cvec = task.loss_func(X, wt, Xl, wl)
+    np.testing.assert_allclose(float(loss), float(g["kat_loss"]), rtol=t_loss)
+    np.testing.assert_allclose(float(npl), float(g["kat_npl"]), rtol=t_eig)
+    np.testing.assert_allclose(float(pen), float(g["kat_pen"]), rtol=t_loss, atol=t_loss * abs(float(g["kat_loss"])) / float(g["alpha"]))
+    np.testing.assert_allclose(eig.numpy(), g["kat_eig"], rtol=t_eig)
+    assert list(cvec) == list(g["kat_cvec"])
+    task.backward()
+    gmax = max(float(np.abs(g["grad/" + n]).max()) for n, _ in model.named_parameters())
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad/" + n], rtol=0, atol=t_grad * gmax, err_msg=n)
+    np.random.seed(int(g["seed"]))
+    task.train()
+    assert task.batch_size == 20000 and len(task.loss_list) == int(g["num_epochs"])
+    tr = np.stack([e[0].numpy() for e in task.loss_list])
+    te = np.stack([e[1].numpy() for e in task.loss_list])
+    assert tr.shape == np.array(g["train_loss"]).shape and tr.shape[1] == (4 if lag == 0 else 3)
+    # fp32 fixtures: the reference's fp32 run is up to 2.3e-4 from its own fp64 run in single entries at this size (transfer
+    # mode: sum w (y' - y)^2 with y' ~ y in fp32) - that distance, entry by entry, is allowed on top; the fp64 fixture pins
+    # the exact rows at the plain bar
+    g64 = goldens.load(name, "f64")
+    noise_tr = 2.0 * np.abs(np.array(g["train_loss"]) - g64["train_loss"]) if tag == "f32" else 0.0
+    noise_te = 2.0 * np.abs(np.array(g["test_loss"]) - g64["test_loss"]) if tag == "f32" else 0.0
+    assert_rows(tr, g["train_loss"], tol, noise_tr)
+    assert_rows(te, g["test_loss"], tol, noise_te)
+    assert list(task._cvec) == list(g["cvec"])
+    last_bias = f".{len(g['layer_dims']) - 1}.bias"    # (excluded as in test_ef_train_trace)
+    for n, p in model.state_dict().items():
+        if n.endswith(last_bias):
+            continue
+        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=tol["params"], atol=tol["params"], err_msg=n)
+    probe = torch.tensor(traj[:64], device=dev, dtype=torch.float32)
+    cv = task.colvar_model()(probe).detach().cpu().numpy()
+    ref_cv = np.array(g["colvar_probe"])
+    ref_c = ref_cv - ref_cv.mean(0)
+    np.testing.assert_allclose(cv - cv.mean(0), ref_c, rtol=0, atol=tol["cv"] * np.abs(ref_c).max())
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_ae_bench_size_vs_reference(dev, tag):
+    """BASELINE config 2 at its own size against the reference: AutoEncoderTask on 100 000 frames x 22 atoms, [66,20,20,20,2] /
+    [2,10,10,66], batches of 20 000; feature rows, weighted_MSE_loss + gradient of a 20 000-frame batch, two epochs of train()."""
+    from colvarsfinder import core, nn
+    rtol = 2e-6
+    g = goldens.load_big("big_ae_c2", tag)
+    e_dims, d_dims = [int(d) for d in g["e_dims"]], [int(d) for d in g["d_dims"]]
+    model = nn.AutoEncoder(e_dims, d_dims)
+    model.load_state_dict(goldens.state_dict(g, dtype=torch.float32))
+    traj = g["traj"]
+    layer = make_layer(goldens.pp_spec(g), traj.shape[1], dev)
+    task = core.AutoEncoderTask(Traj(traj, g["w"], 0.5), layer, model, "/tmp/cvf_test", learning_rate=float(g["lr"]),
+                                batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]), device=dev, verbose=False,
+                                save_model_every_step=0)
+    F = task._feature_traj
+    rows = torch.cat([F[:256], F[-256:]]).cpu().numpy()
+    np.testing.assert_allclose(rows, g["feature_rows"], rtol=1e-5, atol=5e-6 * np.abs(g["feature_rows"]).max())
+    n0 = int(g["kat_n"])
+    l0 = task.weighted_MSE_loss(F[:n0], task._weights[:n0])
+    task.backward()
+    np.testing.assert_allclose(float(l0), float(g["loss0"]), rtol=rtol)
+    for n, p in model.named_parameters():
+        ref = g["grad/" + n]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * max(1e-3, np.abs(ref).max()), err_msg=n)
+    np.random.seed(int(g["seed"]))
+    task.train()
+    tr = np.stack([e[0].numpy() for e in task.loss_list])
+    assert tr.shape == (2, 4)
+    np.testing.assert_allclose(tr, g["train_loss"], rtol=rtol)
+    np.testing.assert_allclose(np.stack([e[1].numpy() for e in task.loss_list]), g["test_loss"], rtol=rtol)
+    for n, p in model.state_dict().items():
+        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=rtol, atol=rtol, err_msg=n)
+    probe = torch.tensor(traj[:64], device=dev, dtype=torch.float32)
+    cv = task.colvar_model()(probe).detach().cpu().numpy()
+    np.testing.assert_allclose(cv, g["colvar_probe"], rtol=0, atol=rtol * np.abs(g["colvar_probe"]).max())
 
 
 # ------------------------------------------------------------------------------------------------ autoencoder
@@ -436,15 +532,21 @@ def test_regae_train_trace(dev, name, tag, rtol):
         return
     np.testing.assert_allclose(tr, g["train_loss"], rtol=rtol, atol=rtol)
     np.testing.assert_allclose(te, g["test_loss"], rtol=rtol, atol=rtol)
+    # final parameters and learned CVs: achieved 3.7e-6 against the fp64 fixtures (profiles/r4_parity_errors.json; VERDICT r3 item 1c:
+    # the bar was 50 * rtol = 5e-3), 1.9e-5 against the fp32 fixtures that reach this point (the reference's own fp32 noise)
+    ptol = REGAE_PARAM_TOL[tag]
     for n, p in model.state_dict().items():
         if n.startswith("reg.") and n.endswith(reg_last_bias):
             continue   # Adam turns that bias's rounding-noise gradient into +-lr steps; it does not affect the loss
-        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=50 * rtol, atol=50 * rtol, err_msg=n)
+        # the regulariser nets' own weights: entries whose gradient is roundoff-sized take Adam steps of the sign of that
+        # roundoff (g / sqrt(v) ~ +-1): 8e-5 at worst in the generator-mode fixtures, without moving loss or CVs
+        tol_n = REGAE_REG_PARAM_TOL[tag] if n.startswith("reg.") else ptol
+        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=tol_n, atol=tol_n, err_msg=n)
     np.testing.assert_array_equal(np.asarray(task._cvec), g["cvec"])
     probe = torch.tensor(traj[:64], device=dev, dtype=torch.float32)
-    np.testing.assert_allclose(task.colvar_model()(probe).detach().cpu().numpy(), g["colvar_probe"], rtol=50 * rtol, atol=50 * rtol)
+    np.testing.assert_allclose(task.colvar_model()(probe).detach().cpu().numpy(), g["colvar_probe"], rtol=ptol, atol=ptol)
     rp, rp_ref = task.reg_model()(probe).detach().cpu().numpy(), np.array(g["reg_probe"])
-    np.testing.assert_allclose(rp - rp.mean(0), rp_ref - rp_ref.mean(0), rtol=50 * rtol, atol=50 * rtol)   # (up to that bias)
+    np.testing.assert_allclose(rp - rp.mean(0), rp_ref - rp_ref.mean(0), rtol=ptol, atol=ptol)   # (up to that bias)
     assert list(task.train_loss_df.columns)[:4] == ['loss', 'ae_loss', 'eigen_non_penalty', 'eigen_penalty']
 
 
@@ -586,6 +688,96 @@ def test_config5_shape_generator_step_vs_oracle(dev):
     want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
     got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
+
+
+def _config5_task(dev, traj, w, ref):
+    import bench
+    from colvarsfinder import core, nn
+    from oracle import nnref
+    n_atoms, k = traj.shape[1], 6
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=bench.c5_features(n_atoms), use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    dims = [384, 20, 20, 20, 1]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(55))
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    a = torch.tensor(diag_coeff_for(n_atoms, 5), dtype=torch.float32)
+    eig_w = [1.0, 0.9, 0.8, 0.7, 0.6, 0.5]
+    task = core.EigenFunctionTask(Traj(traj[:64], w[:64], 1.0), layer, model, "/tmp/cvf_test", 20.0, eig_w, diag_coeff=a, beta=1.0,
+                                  lag_tau=0, k=k, device=dev, verbose=False, save_model_every_step=0)
+    assert task._dense is not None    # the streaming (large-molecule) path
+    return task, model, spec, sd0, a, eig_w
+
+
+C5_BATCH_TOL = dict(loss=2e-6, eig=5e-6, grad=2e-5)   # achieved: profiles/r4_parity_errors.json ("config5_bench_batches")
+
+
+def config5_bench_batch_errors(dev, B):
+    """One generator-mode step of the config-5 shape on B frames through the HIP path and through the chunked fp64 oracle;
+    returns the relative errors (also recorded by tools/parity_errors.py) and, for B = 16 000, the duplication distances."""
+    from oracle import chunked
+    from oracle.pp import AlignFeature
+    n_atoms, k = 5000, 6
+    # (tests.synth.make_molecule_traj's formula with the rotations applied by a batched matmul: 16 000 x 5000 atoms in seconds)
+    rs = np.random.RandomState(5016)
+    ref = rs.normal(scale=2.0, size=(n_atoms, 3))
+    traj = np.empty((B, n_atoms, 3), dtype=np.float32)
+    for s0 in range(0, B, 2000):
+        nb = min(2000, B - s0)
+        traj[s0:s0 + nb] = np.matmul(ref[None] + rs.normal(scale=0.05, size=(nb, n_atoms, 3)), random_rotations(rs, nb).transpose(0, 2, 1)) \
+            + rs.normal(size=(nb, 1, 3))
+    w = rs.uniform(0.2, 2.0, size=B)
+    w /= w.mean()
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))   # (the GPU box grants a 16-core share)
+    task, model, spec, sd0, a, eig_w = _config5_task(dev, traj, w, ref)
+    torch.set_default_dtype(torch.float64)
+    opp = AlignFeature(spec["align_idx"], ref, spec["features"], compact=True)
+    torch.set_default_dtype(torch.float32)
+
+    def run(Xb, Wb):
+        loss, eig, npl, pen, cvec = task.loss_func(Xb, Wb, None, None)
+        task.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+        return np.asarray([float(loss), float(npl), float(pen)] + [float(e) for e in eig]), g, list(cvec)
+
+    X, W = torch.tensor(traj), torch.tensor(w, dtype=torch.float32)
+    v, g, c = run(X, W)
+    torch.set_default_dtype(torch.float64)
+    try:
+        sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+        (lo, eo, no, po, co), gr = chunked.ef_loss_and_grad(sd, k, opp, X, W.double(), alpha=20.0, eig_w=eig_w, diag_coeff=a.double(),
+                                                            beta=1.0, chunk=125)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    want = np.asarray([float(lo), float(no), float(po)] + [float(e) for e in eo])
+    gw = torch.cat([gr[n].reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    err = dict(loss=float(np.max(np.abs(v[:3] - want[:3]) / np.abs(want[:3]))), eig=float(np.max(np.abs(v[3:] - want[3:]) / np.abs(want[3:]))),
+               grad=float(np.abs(g - gw).max() / np.abs(gw).max()), cvec_equal=bool(c == list(co)))
+    if B == 16000:   # eight copies of its first 2 000 frames = the 2 000-frame batch (oracle-checked by the B = 2 000 call)
+        X2, W2 = X[:2000], W[:2000]
+        v1, g1, c1 = run(X2, W2)
+        v8, g8, c8 = run(torch.cat([X2] * 8), torch.cat([W2] * 8))
+        err.update(dup_values=float(np.max(np.abs(v8 - v1) / np.abs(v1))), dup_grad=float(np.abs(g8 - g1).max() / np.abs(g1).max()),
+                   dup_cvec_equal=bool(c8 == c1))
+    return err
+
+
+@pytest.mark.parametrize("B", [2000, 16000])
+def test_config5_shape_at_the_bench_batches_vs_chunked_oracle(dev, B):
+    """the config-5-shape step at the two batch sizes `bench.py --workload c5` times, on the code paths those
+    sizes take by themselves (no developer switch): 2 000 frames = 125 sixteen-frame groups (<= 384: the first stage of the batch
+    sums inside metric_rows_kernel, one net per workgroup) and 16 000 frames = 1 000 groups (>= 512: the all-nets-per-workgroup
+    `kMulti` instance, ef_stats_partial_kernel for the sums, backward blocks not shared out) - csrc/metric_large.hip
+    cvf_metric_apply_stats dispatch.  Loss, eigenvalues, ordering and every parameter gradient against the fp64 oracle walked in
+    chunks (oracle/chunked.py: two passes over the batch-sum identity, pinned on the CPU against the plain oracle and through it
+    against the reference); then size-independence: eight copies of a 2 000-frame batch (16 000 frames) give the 2 000-frame
+    batch's loss and gradient."""
+    err = config5_bench_batch_errors(dev, B)
+    assert err["cvec_equal"]
+    for key, bar in C5_BATCH_TOL.items():
+        assert err[key] <= bar, (key, err)
+    if B == 16000:
+        assert err["dup_cvec_equal"] and err["dup_values"] <= 2e-6 and err["dup_grad"] <= 2e-6, err
 
 
 @pytest.mark.parametrize("n_atoms,n_pos,B,k", [(22, 22, 1000, 3), (22, 22, 64, 1), (12, 9, 333, 2)])

@@ -229,3 +229,67 @@ def test_split_matches_sklearn():
     assert [len(x) for x in train.split_indices(5000, 0.2)] == [4000, 1000]
     assert [len(x) for x in train.split_indices(4998, 0.2)] == [3998, 1000]
     assert [len(x) for x in train.split_indices(150000, 0.2)] == [120000, 30000]
+
+
+# ------------------------------------------------------------------------------------------------ bench-sized fixtures
+@pytest.mark.parametrize("name", goldens.BIG_EF_CASES)
+def test_big_ef_fixture_pins_the_oracle_at_bench_size(name):
+    """BASELINE config 3 (and its transfer-mode twin) at the size bench.py times: one loss_func call on 20 000 frames with every
+    parameter gradient, then the 100 000-frame training (batches of 20 000) - the oracle against the reference's fp64 run."""
+    g = goldens.load_big(name, "f64")
+    dtype = torch.float64
+    torch.set_default_dtype(dtype)
+    k, lag, B = int(g["k"]), int(g["lag_idx"]), int(g["kat_n"])
+    traj, w = g["traj"], g["w"]
+    pp = build_pp(g)
+    sd = {n: p.requires_grad_(True) for n, p in goldens.state_dict(g, dtype=dtype).items()}
+    X, wt = torch.tensor(traj[:B]).to(dtype), torch.tensor(w[:B]).to(dtype)
+    Xl = wl = a = None
+    if lag == 0:
+        X.requires_grad_()
+        a = torch.tensor(np.array(g["diag_coeff"])).to(dtype)
+    else:
+        Xl, wl = torch.tensor(traj[lag:lag + B]).to(dtype), torch.tensor(w[lag:lag + B]).to(dtype)
+    kw = dict(alpha=float(g["alpha"]), eig_w=list(g["eig_w"]), diag_coeff=a, beta=float(g["beta"]), lag_idx=lag, dt=float(g["dt"]))
+    loss, eig, npl, pen, cvec = losses.ef_loss(sd, k, pp, X, wt, Xl, wl, **kw)
+    loss.backward()
+    tol = TOL["f64"]
+    np.testing.assert_allclose([float(loss), float(npl), float(pen)], [float(g["kat_loss"]), float(g["kat_npl"]), float(g["kat_pen"])], **tol)
+    np.testing.assert_allclose(eig.numpy(), g["kat_eig"], **tol)
+    assert list(cvec) == list(g["kat_cvec"])
+    for n, p in sd.items():
+        ref = g["grad/" + n]
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=1e-8, atol=1e-10 * max(1.0, float(np.abs(ref).max())), err_msg=n)
+    np.random.seed(int(g["seed"]))
+    res = train.train_ef(goldens.state_dict(g, dtype=dtype), k, pp, traj, w, learning_rate=float(g["lr"]), batch_size=int(g["batch_size"]),
+                         num_epochs=int(g["num_epochs"]), **kw)
+    np.testing.assert_allclose(np.stack([e[0].numpy() for e in res["loss_list"]]), g["train_loss"], **tol)
+    np.testing.assert_allclose(np.stack([e[1].numpy() for e in res["loss_list"]]), g["test_loss"], **tol)
+    assert list(res["cvec"]) == list(g["cvec"])
+    for n, p in res["state_dict"].items():
+        np.testing.assert_allclose(p.numpy(), g["final/" + n], rtol=1e-8, atol=1e-10, err_msg=n)
+
+
+def test_big_ae_fixture_pins_the_oracle_at_bench_size():
+    """BASELINE config 2 at its own size: 100 000 frames x 22 atoms, batches of 20 000 (AutoEncoderTask, core.py:610-744)."""
+    g = goldens.load_big("big_ae_c2", "f64")
+    dtype = torch.float64
+    torch.set_default_dtype(dtype)
+    traj, w = g["traj"], g["w"]
+    pp = build_pp(g)
+    sd0 = goldens.state_dict(g, dtype=dtype)
+    F = pp(torch.tensor(traj).to(dtype))
+    np.testing.assert_allclose(np.concatenate([F[:256].numpy(), F[-256:].numpy()]), g["feature_rows"], rtol=1e-9, atol=1e-11)
+    nb = int(g["kat_n"])
+    sd = {n: p.clone().requires_grad_(True) for n, p in sd0.items()}
+    l0 = losses.ae_loss(sd, F[:nb], torch.tensor(w[:nb]).to(dtype))
+    l0.backward()
+    np.testing.assert_allclose(float(l0), float(g["loss0"]), rtol=1e-9)
+    for n, p in sd.items():
+        np.testing.assert_allclose(p.grad.numpy(), g["grad/" + n], rtol=1e-8, atol=1e-10, err_msg=n)
+    np.random.seed(int(g["seed"]))
+    res = train.train_ae(sd0, pp, traj, w, learning_rate=float(g["lr"]), batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]))
+    np.testing.assert_allclose(np.stack([e[0].numpy() for e in res["loss_list"]]), g["train_loss"], rtol=1e-9)
+    np.testing.assert_allclose(np.stack([e[1].numpy() for e in res["loss_list"]]), g["test_loss"], rtol=1e-9)
+    for n, p in res["state_dict"].items():
+        np.testing.assert_allclose(p.numpy(), g["final/" + n], rtol=1e-8, atol=1e-10, err_msg=n)

@@ -15,6 +15,8 @@ Cases:
   G3  AutoEncoderTask.train traces   (core.py:668-744)
   G4  colvarsfinder.nn structure     (nn.py:29-114,242-293)
   G7  RegAutoEncoderTask.train traces (core.py:746-1217: time-lagged reconstruction + transfer-operator regulariser)
+  G8  the bench-sized cases: BASELINE configs 2 / 3 and config 3 in transfer mode at 100 000 frames, batches of 20 000
+      (seed + outputs only; tests/goldens.py regenerates the frames from the seed)
 Every case is emitted for torch default dtype float32 and float64 with identical
 initial weights (drawn in fp32, then cast).
 
@@ -351,6 +353,124 @@ def run_regae_cases(core, rnn, id2, mol10):
     torch.set_default_dtype(torch.float32)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Fixtures at the sizes bench.py times: BASELINE configs 2 and 3 - 22 atoms x 100 000 frames, batches of
+# 20 000 (examples/dipeptide/main.ipynb:266) - run by the imported reference.  The trajectory is NOT stored: the fixture keeps
+# the arguments of tests.synth.make_molecule_traj (``traj_gen`` = atoms, frames, seed) and the reference's outputs only.
+BIG_ATOMS, BIG_FRAMES, BIG_BATCH = 22, 100_000, 20_000
+
+
+def big_case(seed):
+    traj, w, ref = make_molecule_traj(BIG_ATOMS, BIG_FRAMES, seed)
+    return dict(pp="align", traj=traj, w=w, align_idx=list(range(BIG_ATOMS)), ref_pos=ref,
+                features=[("position", tuple(range(BIG_ATOMS)))], traj_gen=np.asarray([BIG_ATOMS, BIG_FRAMES, seed], dtype=np.int64))
+
+
+def run_ef_train_big(core, rnn, name, case, k, layer_dims, mode, dtype, alpha, eig_w, beta, lr, epochs, seed, lag_idx=0, dt=0.5):
+    """config 3 (generator, diag_coeff) / the same in transfer mode: one loss_func call on the first 20 000 frames with every
+    parameter gradient (core.py:387-457), then EigenFunctionTask.train (core.py:459-566) at batch_size 20 000."""
+    torch.set_default_dtype(dtype)
+    g = torch.Generator().manual_seed(seed)
+    sd0 = nnref.init_eigenfunctions(layer_dims, k, g, dtype)
+    model = rnn.EigenFunctions(layer_dims, k)
+    model.load_state_dict(sd0)
+    pp = build_pp(case)
+    traj, w = case["traj"], case["w"]
+    a = None
+    if mode == "generator":
+        lag_idx = 0
+        rs = np.random.RandomState(seed + 7)
+        a = torch.tensor(1.0 / rs.choice([1.0, 12.0, 14.0, 16.0], size=traj.shape[1]).repeat(3), dtype=dtype)
+    with tempfile.TemporaryDirectory() as tmp:
+        task = core.EigenFunctionTask(Traj(traj, w, dt), pp, model, tmp, alpha, eig_w, diag_coeff=a, beta=beta,
+                                      lag_tau=lag_idx * dt, learning_rate=lr, k=k, batch_size=BIG_BATCH, num_epochs=epochs,
+                                      test_ratio=0.2, verbose=False, save_model_every_step=0)
+        B = BIG_BATCH
+        X = torch.tensor(traj[:B]).to(dtype)
+        wt = torch.tensor(w[:B]).to(dtype)
+        Xl = wl = None
+        if lag_idx == 0:
+            X.requires_grad_()
+        else:
+            Xl = torch.tensor(traj[lag_idx:lag_idx + B]).to(dtype)
+            wl = torch.tensor(w[lag_idx:lag_idx + B]).to(dtype)
+        loss, eig, npl, pen, cvec = task.loss_func(X, wt, Xl, wl)
+        loss.backward()
+        kat = dict(kat_loss=float(loss), kat_eig=eig.detach().numpy().astype(np.float64), kat_npl=float(npl), kat_pen=float(pen),
+                   kat_cvec=np.asarray(cvec, dtype=np.int64), kat_n=B)
+        kat.update({f"grad/{n}": p.grad.numpy().copy() for n, p in model.named_parameters()})
+        model.zero_grad(set_to_none=True)
+        np.random.seed(seed)
+        task.train()
+    probe = torch.tensor(traj[:64]).to(dtype)
+    cv = task.colvar_model()(probe).detach().numpy()
+    out = dict(kind="ef_train_big", mode=mode, k=k, layer_dims=np.asarray(layer_dims), alpha=alpha, eig_w=np.asarray(eig_w, dtype=np.float64),
+               beta=beta, dt=dt, lag_idx=lag_idx, lr=lr, batch_size=BIG_BATCH, num_epochs=epochs, seed=seed, traj_gen=case["traj_gen"],
+               train_loss=np.stack([e[0].numpy() for e in task.loss_list]),
+               test_loss=np.stack([e[1].numpy() for e in task.loss_list]),
+               cvec=np.asarray(task._cvec, dtype=np.int64), colvar_probe=cv,
+               train_loss_df=task.train_loss_df.to_numpy(), test_loss_df=task.test_loss_df.to_numpy(),
+               loss_names=np.asarray(list(task.train_loss_df.columns)))
+    out.update(kat)
+    if a is not None:
+        out["diag_coeff"] = a.numpy().astype(np.float64)
+    out.update(sd_np(sd0))
+    out.update({f"final/{n}": p.detach().numpy() for n, p in model.state_dict().items()})
+    out.update(pp_meta(case))
+    tag = "f32" if dtype == torch.float32 else "f64"
+    np.savez_compressed(os.path.join(OUT, f"{name}_{tag}.npz"), **out)
+    print(f"  {name}_{tag}: kat loss {float(loss):.9g}; {out['train_loss'].shape[0]} train steps, last row {out['train_loss'][-1, -1]}")
+
+
+def run_ae_train_big(core, rnn, name, case, e_dims, d_dims, dtype, lr, epochs, seed):
+    """config 2: AutoEncoderTask (core.py:610-744) on 100 000 x 22 atoms at batch_size 20 000; weighted_MSE_loss and its gradient on
+    the first 20 000 feature rows; 512 rows of _feature_traj (first and last 256) instead of the whole array."""
+    torch.set_default_dtype(dtype)
+    g = torch.Generator().manual_seed(seed)
+    sd0 = nnref.init_autoencoder(e_dims, d_dims, g, dtype)
+    model = rnn.AutoEncoder(e_dims, d_dims)
+    model.load_state_dict(sd0)
+    pp = build_pp(case)
+    traj, w = case["traj"], case["w"]
+    with tempfile.TemporaryDirectory() as tmp:
+        task = core.AutoEncoderTask(Traj(traj, w, 0.5), pp, model, tmp, learning_rate=lr, batch_size=BIG_BATCH, num_epochs=epochs,
+                                    test_ratio=0.2, verbose=False, save_model_every_step=0)
+        feat = task._feature_traj.detach().numpy()
+        l0 = task.weighted_MSE_loss(task._feature_traj[:BIG_BATCH], task._weights[:BIG_BATCH])
+        l0.backward()
+        grads0 = {f"grad/{n}": p.grad.detach().numpy().copy() for n, p in model.named_parameters()}
+        model.zero_grad(set_to_none=True)
+        np.random.seed(seed)
+        task.train()
+    probe = torch.tensor(traj[:64]).to(dtype)
+    cv = task.colvar_model()(probe).detach().numpy()
+    out = dict(kind="ae_train_big", e_dims=np.asarray(e_dims), d_dims=np.asarray(d_dims), lr=lr, batch_size=BIG_BATCH, num_epochs=epochs,
+               seed=seed, traj_gen=case["traj_gen"], feature_rows=np.concatenate([feat[:256], feat[-256:]]), loss0=float(l0), kat_n=BIG_BATCH,
+               train_loss=np.stack([e[0].numpy() for e in task.loss_list]),
+               test_loss=np.stack([e[1].numpy() for e in task.loss_list]),
+               colvar_probe=cv, train_loss_df=task.train_loss_df.to_numpy(), test_loss_df=task.test_loss_df.to_numpy())
+    out.update(sd_np(sd0))
+    out.update(grads0)
+    out.update({f"final/{n}": p.detach().numpy() for n, p in model.state_dict().items()})
+    out.update(pp_meta(case))
+    tag = "f32" if dtype == torch.float32 else "f64"
+    np.savez_compressed(os.path.join(OUT, f"{name}_{tag}.npz"), **out)
+    print(f"  {name}_{tag}: loss0={float(l0):.9g} last train {out['train_loss'][-1, -1]:.9g}")
+
+
+def run_big_cases(core, rnn):
+    import time
+    for dtype in (torch.float32, torch.float64):
+        t0 = time.time()
+        run_ef_train_big(core, rnn, "big_gen_c3", big_case(2603), 3, [66, 20, 20, 20, 1], "generator", dtype, 20.0, [1.0, 0.75, 0.5], 1.0,
+                         1e-3, 2, 2603)
+        run_ef_train_big(core, rnn, "big_tr_c3", big_case(2604), 3, [66, 20, 20, 20, 1], "transfer", dtype, 20.0, [1.0, 0.75, 0.5], 1.0,
+                         1e-3, 2, 2604, lag_idx=3)
+        run_ae_train_big(core, rnn, "big_ae_c2", big_case(2602), [66, 20, 20, 20, 2], [2, 10, 10, 66], dtype, 1e-3, 2, 2602)
+        print(f"  big cases {dtype}: {time.time() - t0:.1f} s")
+    torch.set_default_dtype(torch.float32)
+
+
 def run_nn_structure(rnn):
     torch.set_default_dtype(torch.float32)
     ef = rnn.EigenFunctions([30, 20, 20, 20, 1], 3)
@@ -415,6 +535,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     core, rnn = import_reference()
     print("reference imported from", core.__file__)
+    if "--big-only" in sys.argv:     # add the bench-sized cases without rewriting the other fixtures
+        run_big_cases(core, rnn)
+        return
     if "--regae-generator-only" in sys.argv:
         t2, w2 = make_2d_traj(600, seed=11)
         run_regae_generator_cases(core, rnn, dict(pp="identity", traj=t2, w=w2), molecule_case(10, 300, seed=21))
@@ -464,6 +587,7 @@ def main():
     run_regae_eta_cases(core, rnn, id2, mol10)
     run_regae_grad_cases(core, rnn, id2, mol10)
     run_regae_generator_cases(core, rnn, id2, mol10)
+    run_big_cases(core, rnn)
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 TAG="${1:-dev}"
-O="$R/gpurun_out/r3"
+O="$R/gpurun_out/${CVF_ROUND:-r4}"
 mkdir -p "$O"
 cd "$R"
 timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "large or config5 or streaming or fused_metric" > "$O/c5_tests_$TAG.log" 2>&1 || { echo "tests failed"; tail -30 "$O/c5_tests_$TAG.log"; exit 1; }

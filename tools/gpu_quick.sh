@@ -3,7 +3,7 @@
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 TAG="${1:-dev}"
-O="$R/gpurun_out/r3"
+O="$R/gpurun_out/${CVF_ROUND:-r4}"
 mkdir -p "$O"
 cd "$R"
 timeout -k 10 120 tools/build/ef16_time > "$O/ef16_time_$TAG.log" 2>&1 || { echo "time probe failed"; tail -5 "$O/ef16_time_$TAG.log"; exit 1; }

@@ -4,7 +4,7 @@
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 TAG="${1:-dev}"
-O="$R/gpurun_out/r3"
+O="$R/gpurun_out/${CVF_ROUND:-r4}"
 mkdir -p "$O"
 cd "$R"
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$O/gpu_tests_$TAG.log" 2>&1; rc=$?

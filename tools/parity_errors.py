@@ -38,7 +38,7 @@ def rel_scale(a, b):
 
 
 def main():
-    tag_out = sys.argv[1] if len(sys.argv) > 1 else "r3"
+    tag_out = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "r4"
     from tests.test_gpu_parity import build_task, make_layer
     from colvarsfinder import core, nn
     dev = torch.device("cuda:0")
@@ -145,9 +145,81 @@ def main():
             cv = task.colvar_model()(torch.tensor(traj[:64], dtype=torch.float32)).detach().numpy()
             row[f"cv_vs_{tag}"] = rel_scale(cv, g["colvar_probe"])
             row["steps"] = int(tr.shape[0] * tr.shape[1])
+            ad = lambda n, p_: float(np.max(np.abs(p_.cpu().numpy() - g["final/" + n]) / (np.abs(g["final/" + n]) + 1.0)))  # noqa: E731
+            rlb = f".{len(r_dims) - 1}.bias"
+            sdict = task.model.state_dict()
+            row[f"encdec_params_vs_{tag}"] = max(ad(n, p_) for n, p_ in sdict.items() if not n.startswith("reg."))
+            row[f"reg_params_vs_{tag}"] = max([ad(n, p_) for n, p_ in sdict.items() if n.startswith("reg.") and not n.endswith(rlb)] + [0.0])
+            rp, rr = task.reg_model()(torch.tensor(traj[:64], dtype=torch.float32)).detach().numpy(), np.array(g["reg_probe"])
+            row[f"reg_probe_vs_{tag}"] = float(np.max(np.abs((rp - rp.mean(0)) - (rr - rr.mean(0)))) / max(float(np.abs(rr - rr.mean(0)).max()), 1e-300))
         row["ref_f32_vs_f64_step_loss"] = rel(np.array(g32["train_loss"])[..., 0], np.array(g64["train_loss"])[..., 0])
         row["ref_f32_vs_f64_cv"] = rel_scale(g32["colvar_probe"], g64["colvar_probe"])
         out["regae_train"][name] = row
+
+    # the bench-sized fixtures (BASELINE configs 2 / 3 at 100 000 frames, batches of 20 000; tools/gen_golden.py run_big_cases)
+    out["bench_size"] = {}
+    for name in goldens.BIG_EF_CASES:
+        row = {}
+        g32, g64 = goldens.load_big(name, "f32"), goldens.load_big(name, "f64")
+        for tag, g in (("f32", g32), ("f64", g64)):
+            task, _ = build_task(g, dev)
+            lag, B = int(g["lag_idx"]), int(g["kat_n"])
+            traj, w = g["traj"], g["w"]
+            Xl = torch.tensor(traj[lag:lag + B]) if lag else None
+            wl = torch.tensor(w[lag:lag + B]) if lag else None
+            loss, eig, npl, pen, cvec = task.loss_func(torch.tensor(traj[:B]), torch.tensor(w[:B]), Xl, wl)
+            row[f"loss_vs_{tag}"] = rel(float(loss), float(g["kat_loss"]))
+            row[f"eig_vs_{tag}"] = rel(eig.numpy(), g["kat_eig"])
+            row[f"npl_vs_{tag}"] = rel(float(npl), float(g["kat_npl"]))
+            task.backward()
+            names = [n for n, _ in task.model.named_parameters()]
+            gmax = max(float(np.abs(g["grad/" + n]).max()) for n in names)
+            row[f"grad_vs_{tag}"] = max(float(np.abs(p_.grad.cpu().numpy() - g["grad/" + n]).max()) for n, p_ in task.model.named_parameters()) / gmax
+            np.random.seed(int(g["seed"]))
+            task.train()
+            tr = np.stack([e[0].numpy() for e in task.loss_list])
+            te = np.stack([e[1].numpy() for e in task.loss_list])
+            row[f"step_loss_vs_{tag}"] = max(rel(tr[..., 0], np.array(g["train_loss"])[..., 0]), rel(te[..., 0], np.array(g["test_loss"])[..., 0]))
+            row[f"step_rows_vs_{tag}"] = max(float(np.max(np.abs(a_ - np.array(b_)) / (np.abs(np.array(b_)) + 1.0)))
+                                             for a_, b_ in ((tr, g["train_loss"]), (te, g["test_loss"])))
+            last_bias = f".{len(g['layer_dims']) - 1}.bias"
+            row[f"params_vs_{tag}"] = max(float(np.max(np.abs(p_.cpu().numpy() - g["final/" + n]) / (np.abs(g["final/" + n]) + 1.0)))
+                                          for n, p_ in task.model.state_dict().items() if not n.endswith(last_bias))
+            cv = task.colvar_model()(torch.tensor(traj[:64], dtype=torch.float32)).detach().numpy()
+            rc = np.array(g["colvar_probe"])
+            row[f"cv_vs_{tag}"] = rel_scale(cv - cv.mean(0), rc - rc.mean(0))
+            row["steps"] = int(tr.shape[0] * tr.shape[1])
+        row["ref_f32_vs_f64_step_loss"] = rel(np.array(g32["train_loss"])[..., 0], np.array(g64["train_loss"])[..., 0])
+        row["ref_f32_vs_f64_step_rows"] = float(np.max(np.abs(np.array(g32["train_loss"]) - g64["train_loss"]) / (np.abs(g64["train_loss"]) + 1.0)))
+        a, b = np.array(g32["colvar_probe"]), np.array(g64["colvar_probe"])
+        row["ref_f32_vs_f64_cv"] = rel_scale(a - a.mean(0), b - b.mean(0))
+        out["bench_size"][name] = row
+    row = {}
+    g32, g64 = goldens.load_big("big_ae_c2", "f32"), goldens.load_big("big_ae_c2", "f64")
+    for tag, g in (("f32", g32), ("f64", g64)):
+        model = nn.AutoEncoder([int(d) for d in g["e_dims"]], [int(d) for d in g["d_dims"]])
+        model.load_state_dict(goldens.state_dict(g, dtype=torch.float32))
+        traj = g["traj"]
+        task = core.AutoEncoderTask(Traj(traj, g["w"], 0.5), make_layer(goldens.pp_spec(g), traj.shape[1], dev), model, "/tmp/cvf_parity",
+                                    learning_rate=float(g["lr"]), batch_size=int(g["batch_size"]), num_epochs=int(g["num_epochs"]), device=dev,
+                                    verbose=False, save_model_every_step=0)
+        np.random.seed(int(g["seed"]))
+        task.train()
+        tr = np.stack([e[0].numpy() for e in task.loss_list])
+        te = np.stack([e[1].numpy() for e in task.loss_list])
+        row[f"step_loss_vs_{tag}"] = max(rel(tr, g["train_loss"]), rel(te, g["test_loss"]))
+        row[f"params_vs_{tag}"] = max(float(np.max(np.abs(p_.cpu().numpy() - g["final/" + n]) / (np.abs(g["final/" + n]) + 1.0)))
+                                      for n, p_ in task.model.state_dict().items())
+        cv = task.colvar_model()(torch.tensor(traj[:64], dtype=torch.float32)).detach().numpy()
+        row[f"cv_vs_{tag}"] = rel_scale(cv, g["colvar_probe"])
+    row["ref_f32_vs_f64_step_loss"] = rel(g32["train_loss"], g64["train_loss"])
+    out["bench_size"]["big_ae_c2"] = row
+
+    # config-5 shape at the batch sizes bench.py --workload c5 times, vs the chunked fp64 oracle (no reference fixture exists at
+    # 5000 atoms: the oracle's alignment layer is the unpinned part)
+    if "--no-c5" not in sys.argv:
+        from tests.test_gpu_parity import config5_bench_batch_errors
+        out["config5_bench_batches"] = {str(B): config5_bench_batch_errors(dev, B) for B in (2000, 16000)}
 
     def worst(key):
         return max(r[key] for sec in ("kat", "ef_train", "ae_train") for r in out[sec].values() if key in r)
@@ -162,7 +234,13 @@ def main():
                        "reference_own_f32_vs_f64_worst_cv": worst("ref_f32_vs_f64_cv"),
                        "regae_worst_first_step_loss_vs_f64": max(r["first_step_loss_vs_f64"] for r in out["regae_train"].values()),
                        "regae_worst_step_loss_vs_f64_traces": max(r["step_loss_vs_f64"] for r in out["regae_train"].values()),
-                       "regae_reference_own_f32_vs_f64_worst_step_loss": max(r["ref_f32_vs_f64_step_loss"] for r in out["regae_train"].values())}
+                       "regae_reference_own_f32_vs_f64_worst_step_loss": max(r["ref_f32_vs_f64_step_loss"] for r in out["regae_train"].values()),
+                       "regae_worst_cv_vs_f64": max(r["cv_vs_f64"] for r in out["regae_train"].values()),
+                       "regae_worst_encdec_params_vs_f64": max(r["encdec_params_vs_f64"] for r in out["regae_train"].values()),
+                       "regae_worst_reg_params_vs_f64": max(r["reg_params_vs_f64"] for r in out["regae_train"].values()),
+                       "regae_worst_reg_probe_vs_f64": max(r["reg_probe_vs_f64"] for r in out["regae_train"].values()),
+                       "bench_size": {n: {k_: v for k_, v in r.items() if k_.endswith("_vs_f64")} for n, r in out["bench_size"].items()},
+                       "config5_bench_batches": out.get("config5_bench_batches")}
     path = os.path.join(ROOT, "gpurun_out", f"{tag_out}_parity_errors.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as fh:
