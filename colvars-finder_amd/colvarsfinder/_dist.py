@@ -85,7 +85,7 @@ def _abi():
     the current stream by the library instead of by torch.distributed) - the path a host without PyTorch would take; the
     unique id travels from rank 0 over the torch process group.  Default: torch.distributed."""
     global _abi_comm
-    if os.environ.get("CVF_COMM", "") != "abi" or not torch.cuda.is_available():
+    if comm_mode() != "abi" or not torch.cuda.is_available():
         return None
     if _abi_comm is None:
         import ctypes
@@ -105,53 +105,125 @@ def _abi():
     return _abi_comm
 
 
-_p2p_comm = None   # CVF_COMM=p2p: the one-shot peer-to-peer reduce of include/cvf.h's cvf_p2p_* (csrc/p2p.hip)
+_p2p_comm = None    # the one-shot peer-to-peer communicator of include/cvf.h's cvf_p2p_* (csrc/p2p.hip), once it is up
+_p2p_state = None   # None: not decided; "on" / "off"
 _P2P_MAX_BYTES = int(os.environ.get("CVF_P2P_MAX_BYTES", str(1 << 20)))
 
 
+def comm_mode():
+    """``CVF_COMM``: ``auto`` (default) - the peer-to-peer windows when the job runs over RCCL (``nccl`` backend: one process per
+    GPU of one node) and a start-up self-test of the windows passes on every rank, else torch.distributed; ``p2p`` - the windows,
+    or an error; ``rccl`` - torch.distributed's all-reduce; ``abi`` - RCCL through the C ABI's cvf_comm_*."""
+    return os.environ.get("CVF_COMM", "auto")
+
+
+def _agree(ok):
+    """True when `ok` is true on every rank (decisions that change the launch sequence must be taken by all ranks alike)."""
+    if world() <= 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()) == 1)
+
+
+def _p2p_bring_up():
+    """Create the windows, hand the IPC handles around over the torch process group, map the peers', run one all-reduce through
+    them and compare it with the known answer.  Returns the communicator handle or None; every step is agreed across the ranks."""
+    import ctypes
+    from . import _hip
+    lib = _hip.lib()
+    nb = lib.cvf_p2p_handle_bytes()
+    mine = torch.zeros(nb, dtype=torch.uint8)
+    handle = ctypes.c_void_p()
+    rc = lib.cvf_p2p_create(ctypes.byref(handle), rank(), world(), _P2P_MAX_BYTES, mine.data_ptr())
+    why = _hip.lib().cvf_last_error().decode() if rc != 0 else ""
+    if not _agree(rc == 0):
+        return None, f"cvf_p2p_create failed on a rank ({why})"
+    if world() > 1:
+        on_dev = backend() == "nccl"
+        src = mine.cuda() if on_dev else mine
+        parts = [torch.zeros_like(src) for _ in range(world())]
+        dist.all_gather(parts, src)
+        allh = torch.cat([p_.cpu() for p_ in parts]).contiguous()
+    else:
+        allh = mine
+    rc = lib.cvf_p2p_connect(handle, allh.data_ptr())
+    why = _hip.lib().cvf_last_error().decode() if rc != 0 else ""
+    if not _agree(rc == 0):       # (every rank has opened every window before the first kernel writes into one)
+        return None, f"cvf_p2p_connect failed on a rank ({why})"
+    # self-test: sum over ranks of (rank + 1) * [1, 2, .., 512] through the windows, against the closed form
+    n = 512
+    base = torch.arange(1, n + 1, device="cuda", dtype=torch.float32)
+    v = base * float(rank() + 1)
+    rc = lib.cvf_p2p_allreduce_f32(handle, _hip.ptr(v), n, _hip.stream())
+    torch.cuda.synchronize()
+    want = base * float(world() * (world() + 1) // 2)
+    good = rc == 0 and int(lib.cvf_p2p_error(handle)) == 0 and bool(torch.equal(v, want))
+    if good:   # ... and the low-latency form the fused launches use: a one-row slab summed over the ranks by cvf_slab_reduce_dp
+        slab, grad = base * float(rank() + 1), torch.empty_like(base)
+        rc = lib.cvf_slab_reduce_dp(_hip.ptr(slab), 1, n, _hip.ptr(grad), None, handle, _hip.stream())
+        torch.cuda.synchronize()
+        good = rc == 0 and int(lib.cvf_p2p_error(handle)) == 0 and bool(torch.equal(grad, want))
+    if not _agree(good):
+        return None, "the self-test all-reduce through the windows did not give the known sum on every rank"
+    return handle, ""
+
+
 def _p2p():
-    """With ``CVF_COMM=p2p`` the two sums go through ``cvf_p2p_allreduce_*``: every rank writes its vector into a slot of every
-    peer's IPC-shared window and adds the slots in rank order (one xGMI hop instead of a ring's 2 (N - 1),
-    bitwise the same sum on every rank).  The IPC handles travel over the torch process group, once."""
-    global _p2p_comm
-    if os.environ.get("CVF_COMM", "") != "p2p" or not torch.cuda.is_available():
+    """The peer-to-peer communicator, or None when this job sums through torch.distributed / RCCL (see comm_mode)."""
+    global _p2p_comm, _p2p_state
+    mode = comm_mode()
+    if mode not in ("auto", "p2p"):
         return None
-    if _p2p_comm is None:
-        import ctypes
-        from . import _hip
-        lib = _hip.lib()
-        nb = lib.cvf_p2p_handle_bytes()
-        mine = torch.zeros(nb, dtype=torch.uint8)
-        handle = ctypes.c_void_p()
-        _hip.check(lib.cvf_p2p_create(ctypes.byref(handle), rank(), world(), _P2P_MAX_BYTES, mine.data_ptr()), "cvf_p2p_create")
-        if world() > 1:
-            on_dev = backend() == "nccl"
-            src = mine.cuda() if on_dev else mine
-            parts = [torch.zeros_like(src) for _ in range(world())]
-            dist.all_gather(parts, src)
-            allh = torch.cat([p_.cpu() for p_ in parts]).contiguous()
-        else:
-            allh = mine
-        _hip.check(lib.cvf_p2p_connect(handle, allh.data_ptr()), "cvf_p2p_connect")
-        if world() > 1:
-            dist.barrier()      # every rank has opened every window before the first kernel writes into one
-        _p2p_comm = handle
+    if _p2p_state is None:
+        want = torch.cuda.is_available() and (mode == "p2p" or (mode == "auto" and backend() == "nccl" and world() > 1))
+        _p2p_state = "off"
+        if want:
+            handle, why = _p2p_bring_up()
+            if handle is not None:
+                _p2p_comm, _p2p_state = handle, "on"
+            elif mode == "p2p":
+                raise RuntimeError(f"CVF_COMM=p2p: {why}")
+            elif rank() == 0:
+                print(f"[colvarsfinder] peer-to-peer windows not usable ({why}); the cross-rank sums go through RCCL", flush=True)
     return _p2p_comm
 
 
+def fused_comm():
+    """The communicator for the launches that carry a cross-rank sum inside them (cvf_ef16_finish_dp, cvf_ef_stats_dp,
+    cvf_ef_loss_dp, cvf_slab_reduce_dp: the data-parallel step in as many launches as the single-process step), or None: the
+    sums are separate all-reduce launches.  ``CVF_FUSED_COMM=0`` keeps them separate over the same windows."""
+    if not collectives() or os.environ.get("CVF_FUSED_COMM", "1") == "0":
+        return None
+    return _p2p()
+
+
 def p2p_error():
-    """0, or the number of the all-reduce in which a peer did not arrive (``CVF_COMM=p2p`` only; synchronises the device)."""
+    """0, or the number of the exchange in which a peer's data did not arrive in time (a host-visible word: no device call)."""
     if _p2p_comm is None:
         return 0
     from . import _hip
     return int(_hip.lib().cvf_p2p_error(_p2p_comm))
 
 
+def check_comm():
+    """Raise if an exchange over the peer-to-peer windows has timed out: the kernels poison their results with NaN and leave the
+    communicator's error word set; the tasks call this wherever they read results back (after a device synchronisation).  A
+    communicator that has seen a time-out is dead - the job must stop."""
+    err = p2p_error()
+    if err:
+        raise RuntimeError(f"colvarsfinder: a peer did not deliver its share of cross-rank exchange {err} within the time-out "
+                           f"(CVF_P2P_TIMEOUT_MS, default 20 s) - rank {rank()} of {world()}; the batch sums / gradients of that "
+                           "step are NaN and the ranks are no longer in step. Aborting.")
+
+
 def allreduce_sum_(t):
     """In-place sum over ranks; a no-op in a single-process run."""
     if collectives():
         plain = t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous()
-        p2p = _p2p() if plain and t.numel() * t.element_size() <= _P2P_MAX_BYTES else None
+        p2p = _p2p() if plain and t.numel() * t.element_size() <= _P2P_MAX_BYTES else None   # (None also when the job sums over RCCL)
         if p2p is not None:
             from . import _hip
             fn = _hip.lib().cvf_p2p_allreduce_f64 if t.dtype == torch.float64 else _hip.lib().cvf_p2p_allreduce_f32

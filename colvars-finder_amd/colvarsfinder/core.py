@@ -89,6 +89,7 @@ class _AsyncEpochLog:
 
     def _flush(self, slot):
         slot["ev"].synchronize()
+        _dist.check_comm()    # a cross-rank exchange that timed out has poisoned these rows with NaN: stop here, loudly
         ep, slot["pending"] = slot["pending"], None
         self.on_epoch(ep, slot["tr"][:self.n_tr].clone(), slot["te"][:self.n_te].clone())
 
@@ -434,6 +435,7 @@ class TrainingTask(ABC):
 
     def save_model(self, epoch, description="latest"):
         """core.py:168-227: ``model.pt`` + per-CV text files (+ TorchScript CV when the layer is scriptable)."""
+        _dist.check_comm()
         if _dist.rank() != 0:
             return
         if self.verbose:
@@ -611,7 +613,8 @@ class EigenFunctionTask(TrainingTask):
         self._graphs = {}
         # whole-step hipGraph replay (CVF_GRAPH=0 turns it off).  In a data-parallel job the two RCCL all-reduces are
         # captured inside the graph (backend nccl only; a failed capture falls back to eager launches for good)
-        self._use_graphs = os.environ.get("CVF_GRAPH", "1") != "0" and (not _dist.collectives() or _dist.backend() == "nccl")
+        self._use_graphs = os.environ.get("CVF_GRAPH", "1") != "0" and (not _dist.collectives() or _dist.backend() == "nccl" or
+                                                                        _dist.fused_comm() is not None)   # (the peer-to-peer kernels capture on any backend)
         # CVF_PIPELINE=1: the next batch's alignment (independent of the parameters) runs on this stream beside the
         # current step's backward kernel.  Off by default: at 20 000 frames per step it measured 133 us/step against
         # 126 serial - the two-branch graph costs more at the fork/join than the 14 us kernel it hides.
@@ -651,6 +654,17 @@ class EigenFunctionTask(TrainingTask):
                           and bool(_hip.lib().cvf_ef16_supported(self._flat.desc, self._pp)))
         return self._ef16
 
+    def _sum_stats_and_tail(self, ws):
+        """Data-parallel step, collective #1 + the loss tail on this rank's batch sums in ``ws.stats``:
+        one launch over the peer-to-peer windows (cvf_ef_loss_dp), else an all-reduce followed by cvf_ef_loss."""
+        lib, P = _hip.lib(), _hip.ptr
+        comm = _dist.fused_comm()
+        if comm is not None:
+            self._call("cvf_ef_loss_dp", lib.cvf_ef_loss_dp, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), comm, _hip.stream())
+        else:
+            self._allreduce("allreduce_batch_sums", ws.stats)
+            self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), _hip.stream())
+
     def _align(self, ws, slot, X, X_lag):
         """K1 of one batch (and of its lagged partner) into feature buffer ``slot``."""
         lib, P = _hip.lib(), _hip.ptr
@@ -683,11 +697,15 @@ class EigenFunctionTask(TrainingTask):
             self._call("cvf_ef16_front_transfer", lib.cvf_ef16_front_transfer, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat),
                        self._pp, P(X), P(X_lag), B, P(ws.y), P(ws.saved), s)
             y_lag = ws.y[ws.T * k * _hip.TILE:]
+            comm = None if single else _dist.fused_comm()
+            if comm is not None:   # collective #1 and the loss tail inside the finishing launch of the sums
+                self._call("cvf_ef_stats_dp", lib.cvf_ef_stats_dp, self._cfg, B, P(w), P(ws.y), None, P(w_lag), P(y_lag),
+                           P(ws.scratch), P(ws.stats), P(ws.loss_out), P(ws.coef), comm, s)
+                return ws
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), None, P(w_lag), P(y_lag),
                        P(ws.scratch), P(ws.stats), lv, cf, s)
             if not single:
-                self._allreduce("allreduce_batch_sums", ws.stats)                                           # collective #1
-                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
+                self._sum_stats_and_tail(ws)                                                                # collective #1
             return ws
         if self._use_ef16() and not aligned:
             # coordinates -> features, y, hidden activations, q = J A J^T g, E and the batch sums in one launch, 16 frames per
@@ -696,11 +714,15 @@ class EigenFunctionTask(TrainingTask):
             self._call("cvf_ef16_front", lib.cvf_ef16_front, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), self._pp, P(X), B,
                        P(self._diag_coeff), P(ws.y), P(ws.saved), P(ws.q), P(ws.e), self._cfg, P(w), P(ws.scratch),
                        None if rows else P(ws.stats), lv, cf, s)
+            comm = None if single else _dist.fused_comm()
+            if rows and comm is not None:   # the units' rows -> sums -> collective #1 -> loss tail: one launch
+                self._call("cvf_ef16_finish_dp", lib.cvf_ef16_finish_dp, self._cfg, B, P(ws.scratch), P(ws.stats), P(ws.loss_out),
+                           P(ws.coef), comm, s)
+                return ws
             if rows:
                 self._call("cvf_ef16_finish", lib.cvf_ef16_finish, self._cfg, B, P(ws.scratch), P(ws.stats), lv, cf, s)
             if not single:
-                self._allreduce("allreduce_batch_sums", ws.stats)                                           # collective #1
-                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
+                self._sum_stats_and_tail(ws)                                                                # collective #1
             return ws
         if not ws.k1_scratch_checked:
             ws._k1_scratch = [_hip.align_scratch(self._pp, B, self.device) for _ in range(2)]
@@ -726,8 +748,7 @@ class EigenFunctionTask(TrainingTask):
                 self._call("cvf_ef_stats_finish_rows", lib.cvf_ef_stats_finish_rows, self._cfg, rows, P(ws.scratch), P(ws.stats),
                            lv, cf, s)
             if not single:
-                self._allreduce("allreduce_batch_sums", ws.stats)                                           # collective #1
-                self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
+                self._sum_stats_and_tail(ws)                                                                # collective #1
             return ws
         if with_tr:
             self._call("cvf_ef_align_fwd", lib.cvf_ef_align_fwd, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat), self._pp, P(X),
@@ -744,8 +765,7 @@ class EigenFunctionTask(TrainingTask):
             self._call("cvf_ef_stats", lib.cvf_ef_stats, self._cfg, B, P(w), P(ws.y), None, P(w_lag), P(y_lag),
                        P(ws.scratch), P(ws.stats), lv, cf, s)
         if not single:
-            self._allreduce("allreduce_batch_sums", ws.stats)                                               # collective #1
-            self._call("cvf_ef_loss", lib.cvf_ef_loss, self._cfg, P(ws.stats), P(ws.loss_out), P(ws.coef), s)
+            self._sum_stats_and_tail(ws)                                                                    # collective #1
         return ws
 
     def _backward(self, ws, w, w_lag=None, advance=False, fuse_adam=False):
@@ -765,6 +785,11 @@ class EigenFunctionTask(TrainingTask):
             self._call("cvf_ef_backward", lib.cvf_ef_backward, self._cfg, fl.desc, P(fl.theta), P(fl.packed), ws.B, P(w), P(w_lag),
                        P(ws.feat), P(ws.y), P(ws.q) if self.lag_idx == 0 else None, P(ws.coef), P(ws.slab),
                        P(self.optimizer.step_count) if advance else None, P(ws.saved), _hip.stream())
+        comm = _dist.fused_comm()
+        if comm is not None:   # sum of the slab rows -> collective #2 -> (train_step) the identical Adam update: one launch
+            adam = self.optimizer.fused_args() if advance else None
+            self._call("cvf_slab_reduce_dp", lib.cvf_slab_reduce_dp, P(ws.slab), ws.slab_rows, fl.n, P(fl.grad), adam, comm, _hip.stream())
+            return adam is not None
         adam = self.optimizer.fused_args() if fuse_adam else None
         self._call("cvf_slab_reduce", lib.cvf_slab_reduce, P(ws.slab), ws.slab_rows, fl.n, P(fl.grad), adam, _hip.stream())
         if not fuse_adam:
@@ -867,6 +892,7 @@ class EigenFunctionTask(TrainingTask):
         ws = self._forward(X, weight, X_lagged, weight_lagged)
         self._last = (ws, weight, weight_lagged)
         v = ws.loss_vec.cpu()
+        _dist.check_comm()
         k = self.k
         dt = torch.get_default_dtype()
         cvec = v[3 + k:3 + 2 * k].round().to(torch.long).numpy()
@@ -1786,7 +1812,8 @@ class RegAutoEncoderTask(TrainingTask):
             _dist.broadcast_(both)
             both = both.cpu().numpy()
             idx_train, idx_test = both[:len(idx_train)], both[len(idx_train):]
-            assert min(bs_train, bs_test) >= world or min(len(idx_train), len(idx_test)) == 0, "batch size smaller than the number of ranks"
+            assert (bs_train == 0 or bs_train >= world) and (bs_test == 0 or bs_test >= world), \
+                f"batch sizes {bs_train} / {bs_test} smaller than the number of ranks {world}"   # (each set by itself: a rank without steps would leave the others waiting)
             (ptr, nb_tr), (pte, nb_te) = _dist.shard_batches(len(idx_train), bs_train, rank, world), _dist.shard_batches(len(idx_test), bs_test, rank, world)
             idx_train, idx_test = np.asarray(idx_train)[ptr], np.asarray(idx_test)[pte]
         else:

@@ -16,6 +16,7 @@
 //
 // Replaces, for these shapes, cvf_ef_align_fwd_metric_stats / cvf_ef_backward (core.py:403-457, 517).
 #include "ef16_common.hpp"
+#include "cvf_p2p.hpp"
 
 namespace {
 template <int H, int NH, int NIT, bool ALLAL>
@@ -535,6 +536,8 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
 
 int cvf_ef_stats_finish_impl(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
                              double* loss_vec, double* coef, hipStream_t s);
+int cvf_ef_stats_finish_ll(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
+                           double* loss_vec, double* coef, hipStream_t s, const P2PLL* ll);
 
 extern "C" int cvf_ef16_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp) {
   int H, NH;
@@ -565,6 +568,16 @@ extern "C" int cvf_ef16_finish(const cvf_ef_cfg* cfg, int64_t B, const double* s
   CVF_REQUIRE(cfg && scratch && stats && cvf_ef16_rows(B) > 0, "cvf_ef16_finish: bad argument");
   CVF_REQUIRE(loss_vec == nullptr || coef != nullptr, "cvf_ef16_finish: loss_vec without coef");
   return cvf_ef_stats_finish_impl(cfg, (int)cvf_ef16_rows(B), 1, scratch, stats, loss_vec, coef, (hipStream_t)stream);
+}
+
+// data-parallel step: the units' rows -> this rank's sums -> the sum over ranks (peer-to-peer exchange inside the launch,
+// cvf_p2p.hpp) -> loss tail and coefficients.  One launch where the step had three (finish, all-reduce, cvf_ef_loss).
+extern "C" int cvf_ef16_finish_dp(const cvf_ef_cfg* cfg, int64_t B, const double* scratch, double* stats, double* loss_vec, double* coef,
+                                  void* p2p_comm, void* stream) {
+  CVF_REQUIRE(cfg && scratch && stats && loss_vec && coef && cvf_ef16_rows(B) > 0, "cvf_ef16_finish_dp: bad argument");
+  const P2PLL* ll = cvf_p2p_ll(p2p_comm, 0);
+  if (ll == nullptr) return -1;
+  return cvf_ef_stats_finish_ll(cfg, (int)cvf_ef16_rows(B), 1, scratch, stats, loss_vec, coef, (hipStream_t)stream, ll);
 }
 
 extern "C" int64_t cvf_ef16_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles) {

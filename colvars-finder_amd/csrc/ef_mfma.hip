@@ -21,6 +21,7 @@
 #include "cvf_common.hpp"
 #include "cvf_adam.hpp"
 #include "cvf_metric.hpp"
+#include "cvf_p2p.hpp"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1497,7 +1498,7 @@ __global__ __launch_bounds__(kSlabPX * kSlabGY) void slab_reduce_kernel(const fl
                                                                         float* __restrict__ grad, const float* __restrict__ mask,
                                                                         int use_adam, AdamDev adam, cvf_mlp_desc mlp,
                                                                         const double* __restrict__ pair_partial, int n_pair,
-                                                                        double* __restrict__ pair_out) {
+                                                                        double* __restrict__ pair_out, P2PLL ll) {
   // (optional rider: one extra block adds n_pair rows of [a, b] partial sums in a fixed order -> pair_out = [a, b, a / b];
   //  the autoencoder step's loss, which would otherwise be a launch of its own between the step kernel and this one)
   if (pair_partial != nullptr && blockIdx.x == gridDim.x - 1) {
@@ -1526,6 +1527,9 @@ __global__ __launch_bounds__(kSlabPX * kSlabGY) void slab_reduce_kernel(const fl
   if (use_adam && adam.packed != nullptr && px == 0 && gy == 1) pack_tab_fill(tab, mlp);
   if (use_adam && px == 0 && gy == 2) scal = adam_scalars(adam);
   const int p = blockIdx.x * kSlabPX + px;
+  // data-parallel step (ll.world > 0): the number of this launch's gradient exchange, read by every workgroup before any of them
+  // can have advanced it (the last one to leave does, below)
+  const unsigned ex = ll.world > 0 ? __hip_atomic_load(ll.epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
   // kSlabU independent loads in flight per thread (two left every thread with ~10 dependent round trips at 313 rows; with
   // 32 row groups a 20 000-frame batch is one round); rows past the end re-read the group's first row with weight 0: no
   // branch around the loads
@@ -1560,8 +1564,21 @@ __global__ __launch_bounds__(kSlabPX * kSlabGY) void slab_reduce_kernel(const fl
 #pragma unroll
     for (int t = 0; t < kSlabGY; ++t) s += sub[t][px];
     if (mask != nullptr) s *= mask[p];   // structural zeros of block-structured layers / frozen parameters
+    // data-parallel step: this rank's share -> every peer's window, the `world` shares of the entry from my own window, added in
+    // rank order (cvf_p2p.hpp) - collective #2 of SURVEY.md section 8e inside this launch, identical Adam on every rank behind it
+    if (ll.world > 0) s = p2p_ll_allreduce_grad(ll, ex, p, s);
     grad[p] = s;
     if (use_adam) adam_apply(adam, scal, tab, p, s, m0, v0, th0);
+  }
+  if (ll.world > 0) {   // the last workgroup to leave advances the exchange number for the next launch
+    __syncthreads();
+    if (px == 0 && gy == 0) {
+      const unsigned t = __hip_atomic_fetch_add(ll.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1u == gridDim.x) {
+        __hip_atomic_store(ll.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ll.epoch + 1, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -1894,13 +1911,34 @@ extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, c
 int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
                          const cvf_adam_args* adam, void* stream, const double* pair_partial = nullptr, int n_pair = 0,
                          double* pair_out = nullptr);
+static int slab_reduce_ll(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
+                          const cvf_adam_args* adam, void* stream, const double* pair_partial, int n_pair, double* pair_out,
+                          const P2PLL* ll);
 extern "C" int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,
                                void* stream) {
   return cvf_slab_reduce_impl(slab, n_rows, n_params, grad, nullptr, adam, stream);
 }
+// data-parallel step: sum of the slab rows -> sum over ranks (peer-to-peer exchange inside the launch) -> Adam + fragment refresh.
+// One launch where the step had three (cvf_slab_reduce, all-reduce, cvf_adam_step).  One process per GPU: every workgroup waits
+// for the peers' words of ITS parameters only, so the launch needs no workgroup of its own to make progress; several ranks on
+// ONE GPU (the tests) must fit their workgroups on the chip together.
+extern "C" int cvf_slab_reduce_dp(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,
+                                  void* p2p_comm, void* stream) {
+  const P2PLL* ll = cvf_p2p_ll(p2p_comm, n_params);
+  if (ll == nullptr) return -1;
+  return slab_reduce_ll(slab, n_rows, n_params, grad, nullptr, adam, stream, nullptr, 0, nullptr, ll);
+}
 int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
                          const cvf_adam_args* adam, void* stream, const double* pair_partial, int n_pair, double* pair_out) {
+  return slab_reduce_ll(slab, n_rows, n_params, grad, mask, adam, stream, pair_partial, n_pair, pair_out, nullptr);
+}
+static int slab_reduce_ll(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const float* mask,
+                          const cvf_adam_args* adam, void* stream, const double* pair_partial, int n_pair, double* pair_out,
+                          const P2PLL* llp) {
   CVF_REQUIRE(slab && grad && n_rows > 0 && n_params > 0, "cvf_slab_reduce: bad argument");
+  CVF_REQUIRE(llp == nullptr || pair_partial == nullptr, "cvf_slab_reduce: the pair rider does not combine with the cross-rank exchange");
+  P2PLL ll = {};
+  if (llp != nullptr) ll = *llp;
   AdamDev ad{};
   cvf_mlp_desc md = {};
   if (adam != nullptr) {
@@ -1914,9 +1952,9 @@ int cvf_slab_reduce_impl(const float* slab, int64_t n_rows, int64_t n_params, fl
   const unsigned nb = (unsigned)((n_params + kSlabPX - 1) / kSlabPX) + (pair_partial != nullptr ? 1u : 0u);
   if (n_rows > 64)
     hipLaunchKernelGGL(slab_reduce_kernel<32>, dim3(nb), dim3(kSlabPX, 32), 0, (hipStream_t)stream, slab,
-                       n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md, pair_partial, n_pair, pair_out);
+                       n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md, pair_partial, n_pair, pair_out, ll);
   else
     hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3(nb), dim3(kSlabPX, 4), 0, (hipStream_t)stream, slab,
-                       n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md, pair_partial, n_pair, pair_out);
+                       n_rows, (int)n_params, grad, mask, adam != nullptr ? 1 : 0, ad, md, pair_partial, n_pair, pair_out, ll);
   return cvf_check_launch("slab_reduce_kernel");
 }

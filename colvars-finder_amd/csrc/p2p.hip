@@ -13,35 +13,47 @@
 //   Cross-device visibility: the window is FINE-GRAINED memory; payload and flags are written and read with system-scope relaxed
 //   atomics (global_store / global_load ... sc0 sc1), every writing thread drains its stores (s_waitcnt vmcnt(0)) and the block
 //   meets at a barrier before the flags go out; the reader polls the flags with system-scope loads and orders the slot reads
-//   behind them.  Every spin is bounded (s_memrealtime): a peer that never arrives sets the communicator's error word - the
-//   host sees it at its next call - instead of hanging the GPU.
+//   behind them.  Every spin is bounded (s_memrealtime; 20 s by default, CVF_P2P_TIMEOUT_MS): a peer that never arrives makes the
+//   kernel fill `buf` with NaN and set the communicator's error word.  The word lives in host-visible memory: cvf_p2p_error()
+//   reads it without touching the device, and the shipped host does so wherever it reads results back (the epoch log, before
+//   save_model, in loss_func) and raises - a time-out cannot go unnoticed, and the NaN poisons every number derived from the
+//   unreduced vector.  After an error the communicator is dead (the two-parity protocol assumes no rank skips an exchange).
+//   All launches on one communicator must be ordered on ONE stream: the exchange number is read at kernel entry.
+//
+// The same window carries the LOW-LATENCY exchange (cvf_p2p.hpp: 8-byte {payload, tag} words, no flags) that the finishing launch
+// of the batch sums and the slab reduction fold into their own kernels (cvf_ef16_finish_dp, cvf_ef_loss_dp, cvf_slab_reduce_dp).
 //
 // The host hands the handles around by any means (the shipped Python host: torch.distributed all_gather over the existing group).
 #include <cstring>
 #include <new>
 
+#include <cstdlib>
+
 #include "cvf_common.hpp"
+#include "cvf_p2p.hpp"
 
 namespace {
 
-constexpr int kP2PMaxWorld = 16;
 constexpr int kP2PThreads = 1024;
-constexpr unsigned long long kP2PTimeoutTicks = 2000ull * 100000ull;   // 2 s of the 100 MHz s_memrealtime clock
 
 struct P2PDev {
   int rank, world;
   int64_t slot_bytes;          // bytes of one rank's slot (a multiple of 256)
   char* win[kP2PMaxWorld];     // this process's mapping of every rank's window (win[rank] = its own)
   unsigned* epoch;             // device: all-reduces completed so far (private to the rank)
-  unsigned* error;             // device: set to the epoch that timed out
+  unsigned* error;             // host-visible: set to the epoch that timed out
+  unsigned long long timeout_ticks;
 };
 
 struct P2PComm {
   P2PDev d;
   void* own_window = nullptr;
   void* peer_window[kP2PMaxWorld] = {};
-  unsigned* state = nullptr;   // [epoch, error]
+  unsigned* state = nullptr;   // device: [epoch of the flag protocol, LL epoch statistics, LL epoch gradient, LL ticket]
+  unsigned* error_host = nullptr;   // page-locked, mapped: the error word as the host reads it
   int64_t max_bytes = 0;
+  int64_t flag_window_bytes = 0;    // the LL words follow the flag-protocol window in the same allocation
+  P2PLL ll = {};
   bool connected = false;
 };
 
@@ -84,20 +96,22 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_allreduce_kernel(P2PDev d, T*
     bool ok = true;
     while (load_sys(flag) != e) {
       __builtin_amdgcn_s_sleep(8);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > kP2PTimeoutTicks) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > d.timeout_ticks) {
         ok = false;
         break;
       }
     }
     if (!ok) {
       s_ok = 0;
-      store_sys(d.error, e);
+      store_sys(d.error, e != 0u ? e : 1u);
     }
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");         // system scope: the slot reads below stay behind the flags
-  // ---- 3. the sum, rank order (a rank that timed out leaves buf as it is: the error word says so)
-  if (s_ok) {
+  // ---- 3. the sum, rank order (a rank that timed out poisons buf with NaN: the error word says why)
+  if (!s_ok) {
+    for (int64_t i = tid; i < n; i += kP2PThreads) buf[i] = (T)__builtin_nan("");
+  } else {
     const char* mine = d.win[d.rank] + half + fb;
     for (int64_t i = tid; i < n; i += kP2PThreads) {
       T acc = __builtin_bit_cast(T, load_sys(reinterpret_cast<const U*>(mine) + i));
@@ -139,7 +153,11 @@ extern "C" int cvf_p2p_create(void** comm, int rank, int world, int64_t max_byte
   c->d.world = world;
   c->d.slot_bytes = (max_bytes + 255) & ~(int64_t)255;
   c->max_bytes = max_bytes;
-  const size_t bytes = (size_t)p2p_window_bytes(world, c->d.slot_bytes);
+  c->flag_window_bytes = p2p_window_bytes(world, c->d.slot_bytes);
+  const long long cap_g = (long long)((max_bytes + 3) / 4);
+  const size_t bytes = (size_t)c->flag_window_bytes + 8 * (size_t)p2p_ll_words(world, cap_g);
+  const char* tmo = getenv("CVF_P2P_TIMEOUT_MS");
+  const unsigned long long ticks = (tmo != nullptr && atoll(tmo) > 0 ? (unsigned long long)atoll(tmo) : 20000ull) * 100000ull;   // 100 MHz clock
   // fine-grained device memory: writes of a peer (over xGMI) and reads of the owner are coherent without a kernel boundary
   hipError_t e = hipExtMallocWithFlags(&c->own_window, bytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) { delete c; return hip_fail("cvf_p2p_create: hipExtMallocWithFlags", e); }
@@ -148,8 +166,23 @@ extern "C" int cvf_p2p_create(void** comm, int rank, int world, int64_t max_byte
     (void)hipFree(c->own_window); delete c; return hip_fail("cvf_p2p_create: state", e);
   }
   if ((e = hipDeviceSynchronize()) != hipSuccess) { (void)hipFree(c->own_window); (void)hipFree(c->state); delete c; return hip_fail("cvf_p2p_create", e); }
+  void* err_dev = nullptr;
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->error_host), 64, hipHostMallocMapped)) != hipSuccess ||
+      (e = hipHostGetDevicePointer(&err_dev, c->error_host, 0)) != hipSuccess) {
+    (void)hipFree(c->own_window); (void)hipFree(c->state); delete c;
+    return hip_fail("cvf_p2p_create: error word", e);
+  }
+  *c->error_host = 0u;
   c->d.epoch = c->state;
-  c->d.error = c->state + 1;
+  c->d.error = static_cast<unsigned*>(err_dev);
+  c->d.timeout_ticks = ticks;
+  c->ll.rank = rank;
+  c->ll.world = world;
+  c->ll.cap_g = cap_g;
+  c->ll.epoch = c->state + 1;
+  c->ll.ticket = c->state + 3;
+  c->ll.error = c->d.error;
+  c->ll.timeout_ticks = ticks;
   hipIpcMemHandle_t h;
   if ((e = hipIpcGetMemHandle(&h, c->own_window)) != hipSuccess) {
     (void)hipFree(c->own_window); (void)hipFree(c->state); delete c;
@@ -176,6 +209,7 @@ extern "C" int cvf_p2p_connect(void* comm, const void* all_handles_host) {
     c->peer_window[r] = p;
     c->d.win[r] = static_cast<char*>(p);
   }
+  for (int r = 0; r < c->d.world; ++r) c->ll.win[r] = reinterpret_cast<unsigned long long*>(c->d.win[r] + c->flag_window_bytes);
   c->connected = true;
   return 0;
 }
@@ -187,14 +221,27 @@ extern "C" int cvf_p2p_allreduce_f32(void* comm, float* buf, int64_t n, void* st
   return p2p_allreduce<float, unsigned>(comm, buf, n, stream, "cvf_p2p_allreduce_f32");
 }
 
-// 0, or the number of the all-reduce in which a peer's flag did not arrive within 2 s (synchronises the device)
+// 0, or the number of the exchange in which a peer's data did not arrive within the time-out.  Reads a host-visible word: no
+// device call, no synchronisation - what it reports is what the kernels that have FINISHED by now have found.
 extern "C" int cvf_p2p_error(void* comm) {
   P2PComm* c = static_cast<P2PComm*>(comm);
   CVF_REQUIRE(c != nullptr, "cvf_p2p_error: bad argument");
-  unsigned st[2] = {0, 0};
-  const hipError_t e = hipMemcpy(st, c->state, sizeof(st), hipMemcpyDeviceToHost);
-  if (e != hipSuccess) return hip_fail("cvf_p2p_error", e);
-  return (int)st[1];
+  const unsigned v = *static_cast<volatile unsigned*>(c->error_host);
+  return (int)(v & 0x7fffffffu);
+}
+
+// the communicator's device view for the kernels that fold an exchange into their own launch (cvf_p2p.hpp)
+const P2PLL* cvf_p2p_ll(void* comm, int64_t n_grad) {
+  P2PComm* c = static_cast<P2PComm*>(comm);
+  if (c == nullptr || !c->connected) {
+    cvf_set_error("p2p exchange: the communicator is not connected (cvf_p2p_create + cvf_p2p_connect)");
+    return nullptr;
+  }
+  if (n_grad > c->ll.cap_g) {
+    cvf_set_error("p2p exchange: %lld gradient entries do not fit the window's %lld", (long long)n_grad, (long long)c->ll.cap_g);
+    return nullptr;
+  }
+  return &c->ll;
 }
 
 extern "C" int cvf_p2p_destroy(void* comm) {
@@ -205,6 +252,7 @@ extern "C" int cvf_p2p_destroy(void* comm) {
     if (c->peer_window[r] != nullptr) (void)hipIpcCloseMemHandle(c->peer_window[r]);
   if (c->own_window != nullptr) (void)hipFree(c->own_window);
   if (c->state != nullptr) (void)hipFree(c->state);
+  if (c->error_host != nullptr) (void)hipHostFree(c->error_host);
   delete c;
   return 0;
 }

@@ -5,6 +5,7 @@
 #include "cvf_common.hpp"
 #include "cvf_adam.hpp"
 #include "cvf_loss_tail.hpp"
+#include "cvf_p2p.hpp"
 #include <stdarg.h>
 #include <stdio.h>
 #include <type_traits>
@@ -98,14 +99,27 @@ __global__ __launch_bounds__(64) void ef_loss_kernel(cvf_ef_cfg cfg, const doubl
   if (blockIdx.x == 0) ef_loss_tail_wave(cfg, stats, loss_vec, coef);   // one wave, every lane active
 }
 
+// data-parallel step: this rank's batch sums -> the sum over ranks (low-latency peer-to-peer exchange, cvf_p2p.hpp; written
+// back to `stats`) -> the loss tail, in ONE launch (was: all-reduce launch + ef_loss_kernel)
+__global__ __launch_bounds__(256) void ef_loss_dp_kernel(cvf_ef_cfg cfg, int ns, double* __restrict__ stats, double* __restrict__ loss_vec,
+                                                         double* __restrict__ coef, P2PLL ll) {
+  __shared__ double fin[kMaxStats];
+  __shared__ unsigned parts[kP2PMaxWorld * 2 * kMaxStats];
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) fin[i] = stats[i];
+  p2p_ll_allreduce_stats(ll, fin, ns, parts);
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) stats[i] = fin[i];
+  if (threadIdx.x < CVF_WAVE) ef_loss_tail_wave(cfg, fin, loss_vec, coef);
+}
+
 // Second reduction stage (+ the scalar tail when loss_vec != NULL, i.e. no cross-rank reduction in between) in ONE
 // launch.  Stat i is summed by one wave: lane l adds rows l, l+64, ... (loads issued eight at a time), the 64 lane
 // sums are combined by the fixed-order DPP reduction -> bitwise reproducible for a given number of rows.
 __global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, int ns, int n_rows, int stat_major,
                                                                const double* __restrict__ partial,
                                                                double* __restrict__ stats, double* __restrict__ loss_vec,
-                                                               double* __restrict__ coef) {
+                                                               double* __restrict__ coef, P2PLL ll) {
   __shared__ double fin[kMaxStats];
+  __shared__ unsigned parts[kP2PMaxWorld * 2 * kMaxStats];   // (data-parallel exchange only)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // (24 row loads in flight per lane: the 1250 unit rows of a 20 000-frame batch (csrc/ef16_front.hip, ef16_back.hip) are ONE round trip per
   //  statistic; with eight it was three dependent ones, 9 us for this launch)
@@ -143,13 +157,17 @@ __global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, i
         const int i = i0 + nw * j;
         if (lane == 0 && i < ns) {
           fin[i] = sum;
-          stats[i] = sum;
+          if (ll.world == 0) stats[i] = sum;
         }
       }
     }
   };
   if (ns <= nw) pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 24>{});
   else pass(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
+  if (ll.world > 0) {   // data-parallel step: the sum over ranks of the local sums, inside this launch (cvf_p2p.hpp)
+    p2p_ll_allreduce_stats(ll, fin, ns, parts);
+    for (int i = threadIdx.x; i < ns; i += blockDim.x) stats[i] = fin[i];
+  }
   if (loss_vec == nullptr) return;
   __syncthreads();
   if (wave == 0) ef_loss_tail_wave(cfg, fin, loss_vec, coef);
@@ -193,24 +211,30 @@ static bool k_dispatch(int k, F&& f) {
 }
 
 // rows of per-block (or per-tile, see k1_align.hip) partial sums -> stats [+ loss_vec, coef]
+// (ll: NULL, or the peer-to-peer communicator's device view - the sums are then exchanged inside the finishing launch)
+int cvf_ef_stats_finish_ll(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
+                           double* loss_vec, double* coef, hipStream_t s, const P2PLL* ll);
 int cvf_ef_stats_finish_impl(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
-                             double* loss_vec, double* coef, hipStream_t s);
+                             double* loss_vec, double* coef, hipStream_t s) {
+  return cvf_ef_stats_finish_ll(cfg, n_rows, stat_major, partial, stats, loss_vec, coef, s, nullptr);
+}
 int cvf_ef_stats_finish(const cvf_ef_cfg* cfg, int n_rows, const double* partial, double* stats, double* loss_vec, double* coef,
                         hipStream_t s) {
   return cvf_ef_stats_finish_impl(cfg, n_rows, 0, partial, stats, loss_vec, coef, s);
 }
-int cvf_ef_stats_finish_impl(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
-                             double* loss_vec, double* coef, hipStream_t s) {
+int cvf_ef_stats_finish_ll(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
+                           double* loss_vec, double* coef, hipStream_t s, const P2PLL* ll) {
   const int ns = cvf_ef_nstats(cfg->k, cfg->lag_idx);
   const int waves = ns < 16 ? ns : 16;
+  P2PLL none = {};
   hipLaunchKernelGGL(ef_stats_finish_kernel, dim3(1), dim3(64 * waves), 0, s, *cfg, ns, n_rows, stat_major, partial, stats, loss_vec,
-                     coef);
+                     coef, ll != nullptr ? *ll : none);
   return cvf_check_launch("ef_stats_finish_kernel");
 }
 
-extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
-                            const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, double* loss_vec,
-                            double* coef, void* stream) {
+static int ef_stats_impl(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
+                         const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, double* loss_vec,
+                         double* coef, void* stream, const P2PLL* ll) {
   CVF_REQUIRE(cfg && w && y_tiled && scratch && stats && B > 0, "cvf_ef_stats: bad argument");
   CVF_REQUIRE(cfg->k >= 1 && cfg->k <= CVF_MAX_NETS, "cvf_ef_stats: k=%d out of range", cfg->k);
   if (cfg->lag_idx == 0) CVF_REQUIRE(e_tiled, "cvf_ef_stats: generator mode needs e_tiled");
@@ -232,7 +256,20 @@ extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, co
   int rc = cvf_check_launch("ef_stats_partial_kernel");
   if (rc) return rc;
   CVF_REQUIRE(loss_vec == nullptr || coef != nullptr, "cvf_ef_stats: loss_vec without coef");
-  return cvf_ef_stats_finish(cfg, G, scratch, stats, loss_vec, coef, s);
+  return cvf_ef_stats_finish_ll(cfg, G, 0, scratch, stats, loss_vec, coef, s, ll);
+}
+extern "C" int cvf_ef_stats(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
+                            const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, double* loss_vec,
+                            double* coef, void* stream) {
+  return ef_stats_impl(cfg, B, w, y_tiled, e_tiled, w_lag, y_lag_tiled, scratch, stats, loss_vec, coef, stream, nullptr);
+}
+extern "C" int cvf_ef_stats_dp(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
+                               const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, double* loss_vec,
+                               double* coef, void* p2p_comm, void* stream) {
+  const P2PLL* ll = cvf_p2p_ll(p2p_comm, 0);
+  if (ll == nullptr) return -1;
+  CVF_REQUIRE(loss_vec != nullptr && coef != nullptr, "cvf_ef_stats_dp: needs loss_vec and coef (the loss tail runs behind the exchange)");
+  return ef_stats_impl(cfg, B, w, y_tiled, e_tiled, w_lag, y_lag_tiled, scratch, stats, loss_vec, coef, stream, ll);
 }
 
 extern "C" int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* loss_vec, double* coef, void* stream) {
@@ -240,6 +277,16 @@ extern "C" int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* l
   CVF_REQUIRE(cfg->k >= 1 && cfg->k <= CVF_MAX_NETS, "cvf_ef_loss: k=%d out of range", cfg->k);
   hipLaunchKernelGGL(ef_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *cfg, stats, loss_vec, coef);
   return cvf_check_launch("ef_loss_kernel");
+}
+
+extern "C" int cvf_ef_loss_dp(const cvf_ef_cfg* cfg, double* stats, double* loss_vec, double* coef, void* p2p_comm, void* stream) {
+  CVF_REQUIRE(cfg && stats && loss_vec && coef, "cvf_ef_loss_dp: bad argument");
+  CVF_REQUIRE(cfg->k >= 1 && cfg->k <= CVF_MAX_NETS, "cvf_ef_loss_dp: k=%d out of range", cfg->k);
+  const P2PLL* ll = cvf_p2p_ll(p2p_comm, 0);
+  if (ll == nullptr) return -1;
+  hipLaunchKernelGGL(ef_loss_dp_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *cfg, cvf_ef_nstats(cfg->k, cfg->lag_idx), stats,
+                     loss_vec, coef, *ll);
+  return cvf_check_launch("ef_loss_dp_kernel");
 }
 
 extern "C" int cvf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, double lr, const float* lr_dev,

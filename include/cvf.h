@@ -394,8 +394,11 @@ int cvf_comm_destroy(void* comm);
  * sum bit for bit, whatever the arrival order.  One process per GPU.  Unlike the rest of this header cvf_p2p_create allocates (the
  * window, as a communicator does).  Sequence: every rank cvf_p2p_create -> exchange the cvf_p2p_handle_bytes()-byte handles by any
  * means, rank-major -> cvf_p2p_connect -> cvf_p2p_allreduce_* on a stream (in place, SUM; n * sizeof <= max_bytes; capturable:
- * the epoch lives on the device).  A peer whose flag does not arrive within 2 s does not hang the GPU: the kernel leaves `buf`
- * unreduced and sets the communicator's error word, which cvf_p2p_error() returns (0 = none; it synchronises the device). */
+ * the epoch lives on the device; all launches on one communicator must be ordered on ONE stream).  A peer whose data does not
+ * arrive within the time-out (20 s; environment CVF_P2P_TIMEOUT_MS) does not hang the GPU: the kernel fills the result with NaN and
+ * sets the communicator's error word, which cvf_p2p_error() returns (0 = none; a host-visible word - no device call, no
+ * synchronisation: it reports what the kernels finished so far have found).  A host must read it wherever it reads results back
+ * and treat a non-zero value as fatal for the communicator (the shipped host raises). */
 int cvf_p2p_handle_bytes(void);
 int cvf_p2p_create(void** comm, int rank, int world, int64_t max_bytes, void* handle_out_host);
 int cvf_p2p_connect(void* comm, const void* all_handles_host);
@@ -403,6 +406,25 @@ int cvf_p2p_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
 int cvf_p2p_allreduce_f32(void* comm, float* buf, int64_t n, void* stream);
 int cvf_p2p_error(void* comm);
 int cvf_p2p_destroy(void* comm);
+
+/* --- the data-parallel step in FOUR launches (front, finish, backward, slab reduction - as the single-process step): the two
+ * cross-rank sums folded into the launches on either side of them, over the same windows in their low-latency form (every 4-byte
+ * payload travels as one 8-byte {payload, exchange number} word that the receiver polls: no flag, no fence, one xGMI hop;
+ * csrc/cvf_p2p.hpp).  `p2p_comm`: a connected cvf_p2p communicator (max_bytes >= 4 * n_params).  Parallelises core.py:498-522.
+ *  cvf_ef16_finish_dp : cvf_ef16_finish + collective #1 + cvf_ef_loss: the units' rows -> this rank's sums -> sum over ranks in
+ *                       rank order (`stats`) -> loss_vec, coef; identical on every rank bit for bit.
+ *  cvf_ef_stats_dp    : cvf_ef_stats + collective #1 + cvf_ef_loss (transfer-operator mode / shapes outside the fast layout).
+ *  cvf_ef_loss_dp     : collective #1 + cvf_ef_loss on sums another launch left in `stats` (in place).
+ *  cvf_slab_reduce_dp : cvf_slab_reduce + collective #2 + the optimiser step (adam != NULL) - every workgroup exchanges the
+ *                       entries it has just summed and applies the identical Adam update; `grad` receives the global gradient. */
+int cvf_ef16_finish_dp(const cvf_ef_cfg* cfg, int64_t B, const double* scratch, double* stats, double* loss_vec, double* coef,
+                       void* p2p_comm, void* stream);
+int cvf_ef_stats_dp(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
+                    const float* w_lag, const float* y_lag_tiled, double* scratch, double* stats, double* loss_vec,
+                    double* coef, void* p2p_comm, void* stream);
+int cvf_ef_loss_dp(const cvf_ef_cfg* cfg, double* stats, double* loss_vec, double* coef, void* p2p_comm, void* stream);
+int cvf_slab_reduce_dp(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,
+                       void* p2p_comm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -304,12 +304,16 @@ def test_ef_bench_size_vs_reference(dev, name, tag):
     for n, p in model.state_dict().items():
         if n.endswith(last_bias):
             continue
-        np.testing.assert_allclose(p.cpu().numpy(), g["final/" + n], rtol=tol["params"], atol=tol["params"], err_msg=n)
+        noise = 2.0 * np.abs(np.array(g["final/" + n]) - g64["final/" + n]) if tag == "f32" else 0.0   # (as for the rows above)
+        want = np.array(g["final/" + n])
+        assert np.all(np.abs(p.cpu().numpy() - want) <= tol["params"] * (1.0 + np.abs(want)) + noise), n
     probe = torch.tensor(traj[:64], device=dev, dtype=torch.float32)
     cv = task.colvar_model()(probe).detach().cpu().numpy()
     ref_cv = np.array(g["colvar_probe"])
     ref_c = ref_cv - ref_cv.mean(0)
-    np.testing.assert_allclose(cv - cv.mean(0), ref_c, rtol=0, atol=tol["cv"] * np.abs(ref_c).max())
+    cv64 = np.array(g64["colvar_probe"])
+    noise = 2.0 * np.abs(ref_c - (cv64 - cv64.mean(0))) if tag == "f32" else 0.0
+    assert np.all(np.abs(cv - cv.mean(0) - ref_c) <= tol["cv"] * np.abs(ref_c).max() + noise)
 
 
 @pytest.mark.parametrize("tag", ["f64", "f32"])
@@ -1074,6 +1078,28 @@ def test_one_shot_p2p_reduce_between_processes_on_one_gpu(dev, world):
     rep = json.loads(res.stdout.strip().splitlines()[-1]) if res.stdout.strip() else {}
     assert res.returncode == 0 and rep.get("ok"), (rep, res.stderr[-1500:])
     assert rep["raw_mismatches"] == 0 and rep["graph_mismatches"] == 0 and rep["train_max_rel_diff"] < (1e-12 if world == 2 else 1e-5)
+    # the data-parallel step in four launches - both sums inside the finishing launch / the slab reduction -
+    # equals the separate all-reduce launches bit for bit, eagerly and from the epoch hipGraphs
+    for tag, v in rep["fused"].items():
+        assert v["graph_equals_eager"] and v["fused_equals_separate"] and v["finite"], (tag, v)
+    assert rep["launches_ef16_gen"] == ["cvf_ef16_backward", "cvf_ef16_finish_dp", "cvf_ef16_front", "cvf_slab_reduce_dp"], rep["launches_ef16_gen"]
+    assert rep["launches_ef16_tr"] == ["cvf_ef16_backward_transfer", "cvf_ef16_front_transfer", "cvf_ef_stats_dp", "cvf_slab_reduce_dp"]
+
+
+def test_a_late_peer_fails_the_job_loudly(dev):
+    """a rank that reaches a cross-rank sum later than the time-out (0.4 s here, 20 s by default) must not leave the others
+    training on local sums - their results turn NaN, the communicator's host-visible error word is set and _dist.check_comm(), which
+    the tasks call wherever they read results back, raises.  Both forms: the separate all-reduce launch and the fused exchange."""
+    import json
+    import subprocess
+    import sys
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_gloo_available():
+        pytest.skip("gloo not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "check_p2p.py"), "timeout"], capture_output=True, text=True, timeout=600)
+    rep = json.loads(res.stdout.strip().splitlines()[-1]) if res.stdout.strip() else {}
+    assert res.returncode == 0 and rep.get("ok"), (rep, res.stderr[-1500:])
 
 
 def test_large_batch_paths_by_duplication(dev):
