@@ -329,6 +329,7 @@ def main():
     events, task._events = task._events, None
     last_calls, task._last_call = (task._last_call or {}), None
     kern_ms = {name: float(np.mean([s_.elapsed_time(e_) for s_, e_ in ev])) for name, ev in events.items()}
+    launches_per_step = {name: len(ev) / max(1, min(args.steps, 50)) for name, ev in events.items()}   # C-ABI calls + all-reduce launches of one step
 
     coll_ms = {n: v for n, v in kern_ms.items() if n.startswith("allreduce_")}    # the step's two cross-rank sums (N > 1)
     dom = max((n for n in kern_ms if n not in coll_ms), key=kern_ms.get)
@@ -435,6 +436,11 @@ def main():
         "collective_avg_us": ({n: v * 1e3 for n, v in coll_ms.items()} if coll_ms else None),
         "collective_note": ("HIP events around each all-reduce in the eager per-call pass, rank 0 (includes the wait for the slowest rank: "
                             "arrival skew shows here); None on one GPU - the single-process step has no collective"),
+        "launches_per_step": {"total": float(sum(launches_per_step.values())), "calls": launches_per_step,
+                              "cross_rank_sums": (None if world == 1 and not _dist.collectives() else
+                                                  "inside cvf_ef16_finish_dp / cvf_slab_reduce_dp (peer-to-peer windows, csrc/cvf_p2p.hpp)"
+                                                  if _dist.fused_comm() is not None else "separate all-reduce launches"),
+                              "comm_mode": _dist.comm_mode()},
         "hip_graph": bool(graphs),
         "graph_granularity": "one hipGraph replay per chunk of the resident static batches (as train() replays one per epoch)",
         "traffic_note": (f"roofline.traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch from profiles/{prof}_pmc_traffic.json "

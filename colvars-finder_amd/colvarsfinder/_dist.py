@@ -161,11 +161,14 @@ def _p2p_bring_up():
     torch.cuda.synchronize()
     want = base * float(world() * (world() + 1) // 2)
     good = rc == 0 and int(lib.cvf_p2p_error(handle)) == 0 and bool(torch.equal(v, want))
-    if good:   # ... and the low-latency form the fused launches use: a one-row slab summed over the ranks by cvf_slab_reduce_dp
+    if good:   # ... and the low-latency form the fused launches use: 70 doubles, then a one-row slab summed by cvf_slab_reduce_dp
+        d = (base[:70] * float(rank() + 1)).double()
+        rc = lib.cvf_p2p_exchange_f64(handle, _hip.ptr(d), 70, _hip.stream())
         slab, grad = base * float(rank() + 1), torch.empty_like(base)
-        rc = lib.cvf_slab_reduce_dp(_hip.ptr(slab), 1, n, _hip.ptr(grad), None, handle, _hip.stream())
+        rc2 = lib.cvf_slab_reduce_dp(_hip.ptr(slab), 1, n, _hip.ptr(grad), None, handle, _hip.stream())
         torch.cuda.synchronize()
-        good = rc == 0 and int(lib.cvf_p2p_error(handle)) == 0 and bool(torch.equal(grad, want))
+        good = (rc == 0 and rc2 == 0 and int(lib.cvf_p2p_error(handle)) == 0 and bool(torch.equal(grad, want)) and
+                bool(torch.equal(d, want[:70].double())))
     if not _agree(good):
         return None, "the self-test all-reduce through the windows did not give the known sum on every rank"
     return handle, ""
@@ -226,6 +229,9 @@ def allreduce_sum_(t):
         p2p = _p2p() if plain and t.numel() * t.element_size() <= _P2P_MAX_BYTES else None   # (None also when the job sums over RCCL)
         if p2p is not None:
             from . import _hip
+            if t.dtype == torch.float64 and t.numel() <= 80:   # batch sums / loss terms: the low-latency words (one hop, no fence)
+                _hip.check(_hip.lib().cvf_p2p_exchange_f64(p2p, _hip.ptr(t), t.numel(), _hip.stream()), "cvf_p2p_exchange_f64")
+                return t
             fn = _hip.lib().cvf_p2p_allreduce_f64 if t.dtype == torch.float64 else _hip.lib().cvf_p2p_allreduce_f32
             _hip.check(fn(p2p, _hip.ptr(t), t.numel(), _hip.stream()), "cvf_p2p_allreduce")
             return t

@@ -122,6 +122,7 @@ _SIGNATURES = {
     "cvf_ef_stats_dp": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_loss_dp": (C.c_int, [C.POINTER(EFCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_p2p_exchange_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "cvf_slab_reduce_dp": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
     "cvf_ef_stats_scratch_doubles": (C.c_int64, [C.c_int, C.c_int]),
     "cvf_ef_stats": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

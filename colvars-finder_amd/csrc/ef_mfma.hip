@@ -1527,9 +1527,12 @@ __global__ __launch_bounds__(kSlabPX * kSlabGY) void slab_reduce_kernel(const fl
   if (use_adam && adam.packed != nullptr && px == 0 && gy == 1) pack_tab_fill(tab, mlp);
   if (use_adam && px == 0 && gy == 2) scal = adam_scalars(adam);
   const int p = blockIdx.x * kSlabPX + px;
-  // data-parallel step (ll.world > 0): the number of this launch's gradient exchange, read by every workgroup before any of them
-  // can have advanced it (the last one to leave does, below)
-  const unsigned ex = ll.world > 0 ? __hip_atomic_load(ll.epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u : 0u;
+  // data-parallel step (ll.world > 0): the gradient exchange carries the number of the step's STATISTICS exchange (collective #1
+  // ran in an earlier launch of this step: the word is constant while this kernel runs, so every workgroup reads the same number
+  // without a ticket - 207 agent-scope atomic adds on one word were 3 us at the end of this launch).  That exchange is also what
+  // keeps a fast rank from overwriting words a slow rank has not read yet: to finish it the fast rank needed the slow rank's
+  // sums, which the slow rank sent after its previous gradient exchange.
+  const unsigned ex = ll.world > 0 ? __hip_atomic_load(ll.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   // kSlabU independent loads in flight per thread (two left every thread with ~10 dependent round trips at 313 rows; with
   // 32 row groups a 20 000-frame batch is one round); rows past the end re-read the group's first row with weight 0: no
   // branch around the loads
@@ -1570,15 +1573,12 @@ __global__ __launch_bounds__(kSlabPX * kSlabGY) void slab_reduce_kernel(const fl
     grad[p] = s;
     if (use_adam) adam_apply(adam, scal, tab, p, s, m0, v0, th0);
   }
-  if (ll.world > 0) {   // the last workgroup to leave advances the exchange number for the next launch
-    __syncthreads();
-    if (px == 0 && gy == 0) {
-      const unsigned t = __hip_atomic_fetch_add(ll.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t + 1u == gridDim.x) {
-        __hip_atomic_store(ll.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(ll.epoch + 1, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+  // (misuse guard: two gradient exchanges with no statistics exchange between them would carry the same number and read each
+  //  other's words - one thread notes the number this launch used and flags a repeat in the communicator's error word)
+  if (ll.world > 0 && blockIdx.x == 0 && px == 0 && gy == 0) {
+    if (__hip_atomic_load(ll.epoch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ex)
+      __hip_atomic_store(ll.error, 0x40000000u | ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(ll.epoch + 1, ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1919,7 +1919,9 @@ extern "C" int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_para
   return cvf_slab_reduce_impl(slab, n_rows, n_params, grad, nullptr, adam, stream);
 }
 // data-parallel step: sum of the slab rows -> sum over ranks (peer-to-peer exchange inside the launch) -> Adam + fragment refresh.
-// One launch where the step had three (cvf_slab_reduce, all-reduce, cvf_adam_step).  One process per GPU: every workgroup waits
+// One launch where the step had three (cvf_slab_reduce, all-reduce, cvf_adam_step).  Must follow a statistics exchange of the same
+// step (cvf_ef16_finish_dp / cvf_ef_stats_dp / cvf_ef_loss_dp / cvf_p2p_exchange_f64): it borrows that exchange's number, and a
+// second call without one in between sets the communicator's error word.  One process per GPU: every workgroup waits
 // for the peers' words of ITS parameters only, so the launch needs no workgroup of its own to make progress; several ranks on
 // ONE GPU (the tests) must fit their workgroups on the chip together.
 extern "C" int cvf_slab_reduce_dp(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,

@@ -124,6 +124,16 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_allreduce_kernel(P2PDev d, T*
   if (tid == 0) store_sys(d.epoch, e);
 }
 
+// buf[0..n) (doubles) <- sum over ranks, rank order, as ONE low-latency exchange of the statistics region (cvf_p2p.hpp)
+__global__ __launch_bounds__(256) void p2p_ll_exchange_f64_kernel(P2PLL ll, double* __restrict__ buf, int n) {
+  __shared__ double vec[kP2PStatWords / 2];
+  __shared__ unsigned parts[kP2PMaxWorld * kP2PStatWords];
+  const unsigned ex = p2p_ll_next(ll);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) vec[i] = buf[i];
+  p2p_ll_allreduce_stats(ll, vec, n, parts, ex);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) buf[i] = vec[i];
+}
+
 int hip_fail(const char* what, hipError_t e) {
   cvf_set_error("%s: %s", what, hipGetErrorString(e));
   return -1;
@@ -228,6 +238,15 @@ extern "C" int cvf_p2p_error(void* comm) {
   CVF_REQUIRE(c != nullptr, "cvf_p2p_error: bad argument");
   const unsigned v = *static_cast<volatile unsigned*>(c->error_host);
   return (int)(v & 0x7fffffffu);
+}
+
+// small fp64 vectors (n <= 80: batch sums, loss terms) over the low-latency words instead of the flag protocol: one hop, no fence
+extern "C" int cvf_p2p_exchange_f64(void* comm, double* buf, int64_t n, void* stream) {
+  P2PComm* c = static_cast<P2PComm*>(comm);
+  CVF_REQUIRE(c != nullptr && buf != nullptr && n > 0 && n <= kP2PStatWords / 2, "cvf_p2p_exchange_f64: bad argument (1 <= n <= %d)", kP2PStatWords / 2);
+  CVF_REQUIRE(c->connected, "cvf_p2p_exchange_f64: cvf_p2p_connect has not been called");
+  hipLaunchKernelGGL(p2p_ll_exchange_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, c->ll, buf, (int)n);
+  return cvf_check_launch("p2p_ll_exchange_f64_kernel");
 }
 
 // the communicator's device view for the kernels that fold an exchange into their own launch (cvf_p2p.hpp)

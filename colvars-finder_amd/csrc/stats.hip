@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256) void ef_loss_dp_kernel(cvf_ef_cfg cfg, int ns,
                                                          double* __restrict__ coef, P2PLL ll) {
   __shared__ double fin[kMaxStats];
   __shared__ unsigned parts[kP2PMaxWorld * 2 * kMaxStats];
+  const unsigned ex = p2p_ll_next(ll);
   for (int i = threadIdx.x; i < ns; i += blockDim.x) fin[i] = stats[i];
-  p2p_ll_allreduce_stats(ll, fin, ns, parts);
+  p2p_ll_allreduce_stats(ll, fin, ns, parts, ex);
   for (int i = threadIdx.x; i < ns; i += blockDim.x) stats[i] = fin[i];
   if (threadIdx.x < CVF_WAVE) ef_loss_tail_wave(cfg, fin, loss_vec, coef);
 }
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, i
                                                                double* __restrict__ coef, P2PLL ll) {
   __shared__ double fin[kMaxStats];
   __shared__ unsigned parts[kP2PMaxWorld * 2 * kMaxStats];   // (data-parallel exchange only)
+  const unsigned ex = p2p_ll_next(ll);                       // (requested now, used behind the row sums)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // (24 row loads in flight per lane: the 1250 unit rows of a 20 000-frame batch (csrc/ef16_front.hip, ef16_back.hip) are ONE round trip per
   //  statistic; with eight it was three dependent ones, 9 us for this launch)
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, i
   if (ns <= nw) pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 24>{});
   else pass(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
   if (ll.world > 0) {   // data-parallel step: the sum over ranks of the local sums, inside this launch (cvf_p2p.hpp)
-    p2p_ll_allreduce_stats(ll, fin, ns, parts);
+    p2p_ll_allreduce_stats(ll, fin, ns, parts, ex);
     for (int i = threadIdx.x; i < ns; i += blockDim.x) stats[i] = fin[i];
   }
   if (loss_vec == nullptr) return;

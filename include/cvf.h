@@ -416,7 +416,10 @@ int cvf_p2p_destroy(void* comm);
  *  cvf_ef_stats_dp    : cvf_ef_stats + collective #1 + cvf_ef_loss (transfer-operator mode / shapes outside the fast layout).
  *  cvf_ef_loss_dp     : collective #1 + cvf_ef_loss on sums another launch left in `stats` (in place).
  *  cvf_slab_reduce_dp : cvf_slab_reduce + collective #2 + the optimiser step (adam != NULL) - every workgroup exchanges the
- *                       entries it has just summed and applies the identical Adam update; `grad` receives the global gradient. */
+ *                       entries it has just summed and applies the identical Adam update; `grad` receives the global gradient.
+ *                       Must follow one of the three calls above (or cvf_p2p_exchange_f64) of the same step: it carries that
+ *                       exchange's number; a repeat without one in between sets the error word (bit 30).
+ *  cvf_p2p_exchange_f64: any fp64 vector of at most 80 entries, in place, by the same low-latency exchange. */
 int cvf_ef16_finish_dp(const cvf_ef_cfg* cfg, int64_t B, const double* scratch, double* stats, double* loss_vec, double* coef,
                        void* p2p_comm, void* stream);
 int cvf_ef_stats_dp(const cvf_ef_cfg* cfg, int64_t B, const float* w, const float* y_tiled, const float* e_tiled,
@@ -425,6 +428,7 @@ int cvf_ef_stats_dp(const cvf_ef_cfg* cfg, int64_t B, const float* w, const floa
 int cvf_ef_loss_dp(const cvf_ef_cfg* cfg, double* stats, double* loss_vec, double* coef, void* p2p_comm, void* stream);
 int cvf_slab_reduce_dp(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,
                        void* p2p_comm, void* stream);
+int cvf_p2p_exchange_f64(void* comm, double* buf, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

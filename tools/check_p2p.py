@@ -177,6 +177,8 @@ def worker_timeout(out_path):
     if which == "flag":
         _dist.allreduce_sum_(t)
     else:
+        d = torch.ones(13, device=dev, dtype=torch.float64)
+        _dist.allreduce_sum_(d)                  # (the statistics exchange whose number the gradient exchange carries; rank 0 times out here already)
         g = torch.empty_like(t)
         _hip.check(_hip.lib().cvf_slab_reduce_dp(_hip.ptr(t), 1, 100, _hip.ptr(g), None, _dist.fused_comm(), _hip.stream()), "cvf_slab_reduce_dp")
         t = g
