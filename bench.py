@@ -47,11 +47,11 @@ FLOP_METRIC = 2 * K_NETS * 33 * N_ATOMS          # three passes of q = J A J^T g
 FLOP_BWD = 2 * K_NETS * (P_W + 800 + 2 * P_W)  # tangent chain, zbar chain, outer products (h and the d chain come from the forward kernel)
 FLOP_OF_CALL = {"cvf_ef16_front": FLOP_FWD + FLOP_METRIC + FLOP_K1, "cvf_ef16_backward": FLOP_BWD, "cvf_ef_backward": FLOP_BWD, "cvf_ef_mlp_fwd": FLOP_FWD, "cvf_ef_fwd_metric_stats": FLOP_FWD + FLOP_METRIC,
                 "cvf_ef_align_fwd_metric_stats": FLOP_FWD + FLOP_METRIC + FLOP_K1}
-KERNEL_OF_CALL = {"cvf_ef16_front": "ef16_front_kernel", "cvf_ef16_backward": "ef16_back_kernel", "cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wg_kernel", "cvf_metric_apply": "metric_pure_kernel",
+KERNEL_OF_CALL = {"cvf_ef16_front": "ef16_front_kernel", "cvf_ef16_backward": "ef16_back_kernel", "cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wide_kernel", "cvf_metric_apply": "metric_rows_kernel",
                   "cvf_ef_fwd_metric_stats": "ef_fwd_metric_kernel", "cvf_ef_align_fwd_metric_stats": "ef_fwd_metric_kernel",
                   "cvf_align_feature_fwd": "k1_align_quad_kernel", "cvf_align_feature_fwd@1M": "k1_stream_kernel",
                   "cvf_align_feature_fwd@c5": "k1_large_slice_kernel"}
-PROFILE_TAG = "r3"   # profiles/<tag>_pmc_traffic.json is the committed PMC summary `roofline.traffic` is read from
+PROFILE_TAG = "r4"   # profiles/<tag>_pmc_traffic.json is the committed PMC summary `roofline.traffic` is read from
 
 
 def make_shard(n_frames, rank, n_atoms=N_ATOMS, scale=2.0, sigma=0.3):
@@ -392,6 +392,8 @@ def main():
         their frames_per_launch are scaled to `scale` frames)."""
         kernel = KERNEL_OF_CALL.get(call)
         path = os.path.join(ROOT, "profiles", f"{prof}_pmc_traffic.json")
+        if not os.path.exists(path):      # (until this round's counter passes are committed: the previous round's)
+            path = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
         if kernel is None or not os.path.exists(path) or B != 20000 or world != 1:
             return None
         with open(path) as fh:
@@ -487,6 +489,8 @@ def other_configs():
             continue
         row = {"workload": d.get("workload"), "us_per_step": d["ms_per_step"] * 1e3, "frames_per_s": d["value"],
                "call_avg_us": d.get("kernel_avg_us") or d.get("call_avg_us")}
+        if "roofline" in d:
+            row["roofline"] = d["roofline"]
         if wl == "c5":
             bpf = 2 * (12 * C5["n_atoms"] + 4) + 8 * C5["k"]
             gbs = bpf * d["batch_per_gpu"] / (d["ms_per_step"] * 1e-3) / 1e9
@@ -497,42 +501,96 @@ def other_configs():
     return res
 
 
+def gpu_clock_state():
+    """What the power manager reports when the K1 timing loop starts (sysfs text, read in this process): the sclk / mclk tables with
+    the active level starred, and the power cap.  Diagnostic only - lets a slow box be told from a slow kernel."""
+    import glob
+    out = {}
+    for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+        row = {}
+        for name in ("pp_dpm_sclk", "pp_dpm_mclk"):
+            try:
+                row[name] = [ln.strip() for ln in open(os.path.join(card, name)).read().splitlines() if "*" in ln]
+            except OSError:
+                pass
+        for cap in glob.glob(os.path.join(card, "hwmon/hwmon*/power1_cap")):
+            try:
+                row["power1_cap_uW"] = int(open(cap).read().strip())
+            except (OSError, ValueError):
+                pass
+        if row:
+            out[card.split("/")[-2]] = row
+    return out or None
+
+
 def align_feature_roofline(task, ref, dev, pmc_traffic):
     """The align+feature kernel K1 alone, where BASELINE.json's north star puts its HBM roofline.  Inside the 20 000-frame step
     it is part of the fused launch (and any stand-alone launch of that size is latency-bound), so it is timed at shard size,
     OUT OF CACHE: (i) the dipeptide shape over 4 M frames (1.06 GB in, 1.06 GB out - four times the 256 MB Infinity Cache; the
     1 M-frame launch of round 1 is kept beside it); (ii) BASELINE config 5's shape, 5000 atoms x 100 k frames (6 GB in), which is
-    the configuration BASELINE.json names 'HBM-bound align+feature path'.  HIP events per launch, on the launch stream."""
+    the configuration BASELINE.json names 'HBM-bound align+feature path'.  HIP events per launch, on the launch stream.
+    VERDICT r3 item 4: every case runs >= 50 ms of untimed launches first (the power manager's ramp), then >= 30 timed launches,
+    and IN THE SAME LOOP a plain stream over the same footprint (cvf_probe_stream: a float4 copy of half the bytes = the same bytes
+    moved 1:1, and a read-only sweep of the input) so that the line carries what the box delivers at that moment
+    (`copy_GBps`, `read_GBps`) and the kernel's position against it (`k1_over_copy`, `k1_over_read`)."""
     from colvarsfinder import _hip, pp
     lib, P = _hip.lib(), _hip.ptr
 
-    def time_k1(desc, xs, n, d_r, with_aux, reps, scratch=None):
-        T_ = _hip.ntiles(n)
-        f_tmp = torch.empty(T_ * d_r * 64, device=dev)
-        a_tmp = torch.empty(T_ * 18 * 64, device=dev) if with_aux else None
+    def timed(fn, reps, preheat_ms):
+        t0 = time.perf_counter()
+        while True:                               # untimed: at least preheat_ms of back-to-back launches
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            if (time.perf_counter() - t0) * 1e3 >= preheat_ms:
+                break
         evs = []
         for _ in range(reps):
-            torch.cuda._sleep(200_000)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            _hip.check(lib.cvf_align_feature_fwd(desc, P(xs), n, P(f_tmp), None, P(a_tmp), P(scratch), _hip.stream()), "k1")
+            fn()
             e1.record()
             evs.append((e0, e1))
         torch.cuda.synchronize()
-        return float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs[3:]]))
+        ms = np.asarray([a_.elapsed_time(b_) for a_, b_ in evs])
+        return float(np.mean(ms)), float(np.min(ms)), float(np.max(ms))
 
+    def case(desc, xs, n, d_r, bpf, with_aux, scratch=None, reps=30):
+        """K1 on n frames; then, same loop shape, the two plain streams over the same bytes."""
+        T_ = _hip.ntiles(n)
+        f_tmp = torch.empty(T_ * d_r * 64, device=dev)
+        a_tmp = torch.empty(T_ * 18 * 64, device=dev) if with_aux else None
+        s = _hip.stream()
+        k1 = lambda: _hip.check(lib.cvf_align_feature_fwd(desc, P(xs), n, P(f_tmp), None, P(a_tmp), P(scratch), s), "k1")   # noqa: E731
+        mean, lo, hi = timed(k1, reps, 50.0)
+        total = float(bpf) * n
+        row = dict(avg_launch_us=mean * 1e3, min_launch_us=lo * 1e3, max_launch_us=hi * 1e3, launches_timed=reps, preheat_ms=50,
+                   achieved=total / (mean * 1e-3) / 1e9, frac=total / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        if not with_aux:
+            flat = xs.reshape(-1)
+            n4 = int(min(flat.numel() // 4, total // 32))          # copy: n4 pieces read + n4 written = `total` bytes moved
+            dst = torch.empty(int(lib.cvf_probe_stream_out_floats(0, n4)), device=dev)
+            cp = lambda: _hip.check(lib.cvf_probe_stream(0, P(dst), P(flat), n4, s), "probe copy")   # noqa: E731
+            cmean = timed(cp, reps, 20.0)[0]
+            nr = flat.numel() // 4
+            dst_r = torch.empty(int(lib.cvf_probe_stream_out_floats(1, nr)), device=dev)
+            rd = lambda: _hip.check(lib.cvf_probe_stream(1, P(dst_r), P(flat), nr, s), "probe read")   # noqa: E731
+            rmean = timed(rd, reps, 20.0)[0]
+            copy_gbs, read_gbs = 32.0 * n4 / (cmean * 1e-3) / 1e9, 16.0 * nr / (rmean * 1e-3) / 1e9
+            row.update(copy_GBps=copy_gbs, read_GBps=read_gbs, k1_over_copy=row["achieved"] / copy_gbs, k1_over_read=row["achieved"] / read_gbs)
+            del dst, dst_r
+        return row
+
+    clocks = gpu_clock_state()
     res = {}
     for label, n in (("dipeptide_4M", 4_000_000), ("dipeptide_1M", 1_000_000)):
         xs, _ = device_frames(n, ref, 0.3, SEED + 77, dev)
-        t_all = time_k1(task._pp, xs, n, 66, True, 15)
-        t_feat = time_k1(task._pp, xs, n, 66, False, 15)
+        feat = case(task._pp, xs, n, 66, K1_BYTES, False)
+        gen = case(task._pp, xs, n, 66, K1_BYTES, True)
+        gen["note"] = "+ rotation/centroid/K^-1 rows (72 B/frame the 532 B/frame count leaves out)"
         del xs
-        res[label] = dict(frames_per_launch=n, bytes_per_frame=K1_BYTES, footprint_MB=(264 + 264) * n / 1e6,
-                          features_only=dict(avg_launch_us=t_feat * 1e3, achieved=K1_BYTES * n / (t_feat * 1e-3) / 1e9,
-                                             frac=K1_BYTES * n / (t_feat * 1e-3) / 1e9 / HBM_PEAK_GBS),
-                          generator_outputs=dict(avg_launch_us=t_all * 1e3, achieved=K1_BYTES * n / (t_all * 1e-3) / 1e9,
-                                                 frac=K1_BYTES * n / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                 note="+ rotation/centroid/K^-1 rows (72 B/frame the 532 B/frame count leaves out)"))
+        res[label] = dict(frames_per_launch=n, bytes_per_frame=K1_BYTES, footprint_MB=(264 + 264) * n / 1e6, features_only=feat,
+                          generator_outputs=gen)
     # config-5 shape
     n5, na5 = 100_000, C5["n_atoms"]
     ref5 = np.random.RandomState(SEED).normal(scale=2.0, size=(na5, 3))
@@ -540,19 +598,27 @@ def align_feature_roofline(task, ref, dev, pmc_traffic):
     d5 = layer5.pp_desc()
     x5, _ = device_frames(n5, ref5, 0.05, SEED + 78, dev, chunk=5000)
     bpf5 = 12 * na5 + 4 + 4 * layer5.d_r
-    t5 = time_k1(d5, x5, n5, layer5.d_r, False, 8)
+    feat5 = case(d5, x5, n5, layer5.d_r, bpf5, False)
+    # the frame groups of a tile on one XCD (the default when a tiled output is written) against blockIdx order, same lease
+    ab = {}
+    for mode in ("0", "1"):
+        os.environ["CVF_K1_XCD"] = mode
+        ab["blockidx_order" if mode == "0" else "tile_on_one_xcd"] = case(d5, x5, n5, layer5.d_r, bpf5, False, reps=15)["avg_launch_us"]
+    del os.environ["CVF_K1_XCD"]
+    feat5["xcd_placement_ab_us"] = ab
     sc5 = _hip.align_scratch(d5, n5, dev)
-    t5g = time_k1(d5, x5, n5, layer5.d_r, True, 8, scratch=sc5)
+    gen5 = case(d5, x5, n5, layer5.d_r, bpf5, True, scratch=sc5)
+    gen5["note"] = "+ rotation/centroid rows and the slot copy the derivative kernel reads"
     del x5, sc5
     res["config5_100k"] = dict(frames_per_launch=n5, n_atoms=na5, d_r=layer5.d_r, bytes_per_frame=bpf5, footprint_MB=bpf5 * n5 / 1e6,
-                               features_only=dict(avg_launch_us=t5 * 1e3, achieved=bpf5 * n5 / (t5 * 1e-3) / 1e9,
-                                                  frac=bpf5 * n5 / (t5 * 1e-3) / 1e9 / HBM_PEAK_GBS),
-                               generator_outputs=dict(avg_launch_us=t5g * 1e3, achieved=bpf5 * n5 / (t5g * 1e-3) / 1e9,
-                                                      frac=bpf5 * n5 / (t5g * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                      note="+ rotation/centroid rows and the slot copy the derivative kernel reads"))
+                               features_only=feat5, generator_outputs=gen5)
     head = res["config5_100k"]["features_only"]
     return {"kernel": "cvf_align_feature_fwd", "bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": head["frac"], "avg_launch_us": head["avg_launch_us"], "bytes_per_frame": bpf5, "frames_per_launch": n5,
+            "copy_GBps": head["copy_GBps"], "read_GBps": head["read_GBps"], "k1_over_copy": head["k1_over_copy"],
+            "k1_over_read": head["k1_over_read"],
+            "stream_note": "copy / read = cvf_probe_stream over the same bytes, timed in the same loop (>= 50 ms untimed launches, then 30 timed)",
+            "clock_state_at_start": clocks,
             "traffic": pmc_traffic("cvf_align_feature_fwd@c5", n5),
             "workload": "BASELINE config 5 shape (5000 atoms, d_r=384), 100 000 frames resident = 6.2 GB per launch, out of cache",
             "cases": res}
@@ -703,9 +769,27 @@ def main_c2(args):
         loss = step(args.warmup + i)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # per-call pass: HIP events around cvf_ae_step (one C call = ae16_kernel + the slab sum / Adam launch), the GPU parked while queued
+    evs = []
+    for i in range(30):
+        torch.cuda._sleep(1_000_000)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step(args.warmup + args.steps + i)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    call_us = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs])) * 1e3
+    n_par = sum(p.numel() for p in model.parameters())
+    flop = 6.0 * n_par * B          # forward, data gradient, weight gradient: 2 flop per weight and frame each (6 k P)
+    ach = flop / (elapsed / args.steps) / 1e12
     if rank == 0:
         print(json.dumps({"workload": "config 2: AutoEncoderTask [66,20,20,20,2]/[2,10,10,66], 22 atoms, B=20000", "n_gpus": world,
                           "value": world * B * args.steps / elapsed, "unit": "frames/s", "ms_per_step": elapsed / args.steps * 1e3,
+                          "batch_per_gpu": B, "call_avg_us": {"cvf_ae_step": call_us},
+                          "roofline": {"kernel": "cvf_ae_step (ae16_kernel + slab_reduce_kernel)", "bound": "mfma", "flop_per_frame": 6.0 * n_par,
+                                       "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+                                       "note": "6 x 3088 weights x frames / step time; a latency-bound dependent chain, far from the fp32 peak"},
                           "final_loss": float(loss), "init_seconds_incl_feature_trajectory": t_init}))
 
 

@@ -122,6 +122,8 @@ _SIGNATURES = {
     "cvf_ef_stats_dp": (C.c_int, [C.POINTER(EFCfg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvf_ef_loss_dp": (C.c_int, [C.POINTER(EFCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvf_probe_stream_out_floats": (C.c_int64, [C.c_int, C.c_int64]),
+    "cvf_probe_stream": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "cvf_p2p_exchange_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "cvf_slab_reduce_dp": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(AdamArgs), C.c_void_p, C.c_void_p]),
     "cvf_ef_stats_scratch_doubles": (C.c_int64, [C.c_int, C.c_int]),

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
                                                                        float* __restrict__ feat_tiled,
                                                                        float* __restrict__ feat_rows,
                                                                        float* __restrict__ aux_tiled,
-                                                                       float* __restrict__ slot_xyz) {
+                                                                       float* __restrict__ slot_xyz, int same_xcd) {
   extern __shared__ float dyn[];                  // [kGroup][n_slot][3] captured atoms, then [d_r][kGroup] features
   __shared__ float bc[kGroup][CVF_AUX_ROWS + 2];
   __shared__ double cD[kGroup][3];
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
   const int nc = pp.n_coord, nal = pp.n_align, nslot = pp.n_slot, N = nc / 3;
   float* capL = dyn + (size_t)fi * nslot * 3;
   float* featL = dyn + (size_t)kGroup * nslot * 3;
-  const int64_t f0 = k1_group_of_block(slot_xyz != nullptr || feat_tiled != nullptr || aux_tiled != nullptr) * kGroup;
+  const int64_t f0 = k1_group_of_block(same_xcd != 0) * kGroup;
   const bool real = f0 + fi < B;
   const int64_t frame = real ? f0 + fi : B - 1;
   const float* __restrict__ xf = x + frame * nc;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc
                                                                      float* __restrict__ feat_tiled,
                                                                      float* __restrict__ feat_rows,
                                                                      float* __restrict__ aux_tiled,
-                                                                     float* __restrict__ slot_xyz) {
+                                                                     float* __restrict__ slot_xyz, int same_xcd) {
   extern __shared__ float dyn[];                  // [kGroup][n_slot][3] captured atoms | [d_r][kGroup] features (first: reduction scratch)
   __shared__ float bc[kGroup][CVF_AUX_ROWS + 2];
   __shared__ double cD[kGroup][3];
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc
   const int nq = N >> 2, nqa = nal >> 2;
   float* featL = dyn + (size_t)kGroup * nslot * 3;
   float* red = featL + w * (4 * kRedPitch);       // wave-private, reused by the feature staging later
-  const int64_t f0 = k1_group_of_block(slot_xyz != nullptr || feat_tiled != nullptr || aux_tiled != nullptr) * kGroup;
+  const int64_t f0 = k1_group_of_block(same_xcd != 0) * kGroup;
   CVF_STAMP(0);
   // ---- this lane's atoms: reference rows, capture slots (registers for the whole batch)
   const float4* __restrict__ r4 = reinterpret_cast<const float4*>(pp.ref_c);
@@ -518,6 +518,10 @@ size_t cvf_k1_large_scratch_bytes(const cvf_pp_desc* pp, int64_t B) {
 int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
                         float* aux_tiled, float* slot_xyz, hipStream_t s) {
   const bool contig = (pp->flags & CVF_PP_ALIGN_CONTIG) != 0;
+  // the frame groups of a 64-frame tile on ONE XCD (their 32-byte pieces of the tiled rows meet in one L2) whenever a tiled output
+  // is written; CVF_K1_XCD=0/1 forces blockIdx order / that placement (developer switch: bench.py's A/B of the two)
+  const int xcd_env = getenv("CVF_K1_XCD") ? atoi(getenv("CVF_K1_XCD")) : -1;
+  const int same_xcd = xcd_env >= 0 ? (xcd_env != 0) : (feat_tiled || aux_tiled || slot_xyz ? 1 : 0);
   const int64_t groups = feat_tiled || aux_tiled || slot_xyz ? cvf_ntiles(B) * (CVF_TILE / kGroup) : (B + kGroup - 1) / kGroup;
   if (capture_ok(pp, feat_tiled != nullptr)) {
     const size_t ldsc = ((size_t)kGroup * pp->n_slot * 3 + (feat_tiled ? (size_t)pp->d_r * kGroup : 0)) * sizeof(float);
@@ -537,7 +541,7 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
         auto go = [&](auto kernel) {
           if (ldsc > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
           hipLaunchKernelGGL(kernel, dim3((unsigned)groups), dim3(64 * kGroup), ldsc, s, *pp, x, B, feat_tiled, feat_rows, aux_tiled,
-                             slot_xyz);
+                             slot_xyz, same_xcd);
         };
         // non-temporal coordinate loads, a developer switch: measured 1592 us against 1065 us (0.48 vs 0.72 of 8 TB/s) for
         // 100 000 frames of 5000 atoms (tools/bench_k1_c5.py) - the plain loads stay the default
@@ -557,10 +561,10 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
       }
       if (vec4)
         hipLaunchKernelGGL(k1_large_capture_kernel<true>, dim3((unsigned)groups), dim3(64 * kGroup), ldsc, s, *pp, x, B,
-                           feat_tiled, feat_rows, aux_tiled, slot_xyz);
+                           feat_tiled, feat_rows, aux_tiled, slot_xyz, same_xcd);
       else
         hipLaunchKernelGGL(k1_large_capture_kernel<false>, dim3((unsigned)groups), dim3(64 * kGroup), ldsc, s, *pp, x, B,
-                           feat_tiled, feat_rows, aux_tiled, slot_xyz);
+                           feat_tiled, feat_rows, aux_tiled, slot_xyz, same_xcd);
       return cvf_check_launch("k1_large_capture_kernel");
     }
   }
@@ -577,4 +581,47 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
     hipLaunchKernelGGL(k1_large_gather_kernel<false>, dim3((unsigned)groups), dim3(64 * kGroup), lds, s, *pp, x, B, feat_tiled, feat_rows,
                        aux_tiled);
   return cvf_check_launch("k1_large_gather_kernel");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Measurement aid (bench.py roofline_align_feature): what plain streaming reaches on THIS box at THIS moment, timed in the same
+// loop as the alignment kernel so that box-to-box and minute-to-minute spread can be told from a change of the kernel.
+//   mode 0: dst[i] = src[i], one float4 per thread (1:1 read/write traffic: the dipeptide shape's mix)
+//   mode 1: read-only sweep, every thread adds 8 float4 of a contiguous 128-byte run, one float per workgroup written
+//           (the large-molecule shape: 60 KB read, 1.5 KB written per frame)
+namespace {
+__global__ __launch_bounds__(256) void probe_copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void probe_read_kernel(float* __restrict__ dst, const float4* __restrict__ src, int64_t n4) {
+  const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  float4 v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = src[base + j < n4 ? base + j : n4 - 1];
+  float acc = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  acc = wave_sumf(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dst[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+}  // namespace
+
+extern "C" int64_t cvf_probe_stream_out_floats(int mode, int64_t n_float4) {
+  return mode == 0 ? 4 * n_float4 : (n_float4 + 2047) / 2048;
+}
+extern "C" int cvf_probe_stream(int mode, float* dst, const float* src, int64_t n_float4, void* stream) {
+  CVF_REQUIRE(dst && src && n_float4 > 0 && (mode == 0 || mode == 1), "cvf_probe_stream: bad argument");
+  CVF_REQUIRE((((uintptr_t)dst | (uintptr_t)src) & 15) == 0, "cvf_probe_stream: buffers must be 16-byte aligned");
+  if (mode == 0)
+    hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)((n_float4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(dst), reinterpret_cast<const float4*>(src), n_float4);
+  else
+    hipLaunchKernelGGL(probe_read_kernel, dim3((unsigned)((n_float4 + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, dst,
+                       reinterpret_cast<const float4*>(src), n_float4);
+  return cvf_check_launch("probe_stream_kernel");
 }

@@ -430,6 +430,13 @@ int cvf_slab_reduce_dp(const float* slab, int64_t n_rows, int64_t n_params, floa
                        void* p2p_comm, void* stream);
 int cvf_p2p_exchange_f64(void* comm, double* buf, int64_t n, void* stream);
 
+/* --- measurement aid (no reference counterpart): plain streaming on this device, timed by bench.py in the same loop as
+ * cvf_align_feature_fwd so that the alignment kernel's HBM fraction can be read against what the box delivers at that moment.
+ * mode 0: dst <- src, one 16-byte piece per thread; mode 1: read-only sweep (dst receives one float per 2048 pieces).
+ * dst holds cvf_probe_stream_out_floats(mode, n_float4) floats. */
+int64_t cvf_probe_stream_out_floats(int mode, int64_t n_float4);
+int cvf_probe_stream(int mode, float* dst, const float* src, int64_t n_float4, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,7 +2,7 @@
 # Collects the round's rocprofv3 outputs (gpurun_out/$TAG/*) into the tracked summaries under profiles/.
 set -e
 cd "$(dirname "$0")/.."
-TAG="${CVF_PROFILE_TAG:-r3}"
+TAG="${CVF_PROFILE_TAG:-r4}"
 cp gpurun_out/$TAG/kt/bench_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
 [ -f gpurun_out/$TAG/kt_k1/k1_kernel_stats.csv ] && cp gpurun_out/$TAG/kt_k1/k1_kernel_stats.csv profiles/${TAG}_k1_roofline_kernel_stats.csv
 for b in 2000 16000; do [ -f gpurun_out/$TAG/kt_c5_$b/c5_kernel_stats.csv ] && cp gpurun_out/$TAG/kt_c5_$b/c5_kernel_stats.csv profiles/${TAG}_c5_batch${b}_kernel_stats.csv; done

@@ -4,7 +4,7 @@
 # bounded by `timeout`.  Outputs land in gpurun_out/<tag>/ (tag: $CVF_PROFILE_TAG, default r2); tools/make_profile_summary.sh turns them into profiles/<tag>_*.
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-TAG="${CVF_PROFILE_TAG:-r3}"
+TAG="${CVF_PROFILE_TAG:-r4}"
 O="$R/gpurun_out/$TAG"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
