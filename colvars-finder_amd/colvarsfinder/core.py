@@ -496,7 +496,7 @@ class _EFWorkspace:
             self.e = torch.empty(T * k * _hip.TILE, **f32)
         else:
             self.g = self.q = self.e = None
-        self.scratch = torch.zeros(lib.cvf_ef16_scratch_doubles(B, k) if ef16 and lag == 0 else
+        self.scratch = torch.zeros(lib.cvf_ef16_scratch_doubles(B, k) if ef16 else
                                    lib.cvf_metric_stats_scratch_doubles(B, k) if lag == 0 else
                                    lib.cvf_ef_stats_scratch_doubles(k, lag), **f64)
         self.stats = torch.empty(lib.cvf_ef_nstats(k, lag), **f64)
@@ -694,10 +694,23 @@ class EigenFunctionTask(TrainingTask):
         if self._use_ef16() and not aligned and lag > 0:
             # transfer-operator mode: coordinates of the frames and of their lagged partners -> features, y, hidden activations
             # in one launch (16 frames per wave), then the time-lagged batch sums and the loss tail
+            comm = None if single else _dist.fused_comm()
+            if lib.cvf_ef16_transfer_rows(B, k) > 0 and os.environ.get("CVF_NO_TRANSFER_ROWS") is None:
+                # a unit and its lagged partner in one block: the units' rows of the time-lagged sums leave the front launch,
+                # the finishing launch adds them (+ collective #1 in a data-parallel job) and evaluates the loss tail
+                self._call("cvf_ef16_front_transfer", lib.cvf_ef16_front_transfer_rows, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat),
+                           self._pp, P(X), P(X_lag), B, P(ws.y), P(ws.saved), P(w), P(w_lag), P(ws.scratch), s)
+                if comm is not None:
+                    self._call("cvf_ef16_finish_dp", lib.cvf_ef16_finish_dp, self._cfg, B, P(ws.scratch), P(ws.stats), P(ws.loss_out),
+                               P(ws.coef), comm, s)
+                    return ws
+                self._call("cvf_ef16_finish", lib.cvf_ef16_finish, self._cfg, B, P(ws.scratch), P(ws.stats), lv, cf, s)
+                if not single:
+                    self._sum_stats_and_tail(ws)                                                            # collective #1
+                return ws
             self._call("cvf_ef16_front_transfer", lib.cvf_ef16_front_transfer, fl.desc, P(fl.theta), P(fl.packed), P(ws.feat),
                        self._pp, P(X), P(X_lag), B, P(ws.y), P(ws.saved), s)
             y_lag = ws.y[ws.T * k * _hip.TILE:]
-            comm = None if single else _dist.fused_comm()
             if comm is not None:   # collective #1 and the loss tail inside the finishing launch of the sums
                 self._call("cvf_ef_stats_dp", lib.cvf_ef_stats_dp, self._cfg, B, P(w), P(ws.y), None, P(w_lag), P(y_lag),
                            P(ws.scratch), P(ws.stats), P(ws.loss_out), P(ws.coef), comm, s)

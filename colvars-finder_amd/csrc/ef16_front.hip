@@ -27,7 +27,8 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
                                                              float* __restrict__ feat_tiled, float* __restrict__ y_tiled,
                                                              float* __restrict__ saved, float* __restrict__ q_tiled,
                                                              float* __restrict__ e_tiled, double* __restrict__ partial, int ns,
-                                                             const float* __restrict__ x_lag, int64_t units_x) {
+                                                             const float* __restrict__ x_lag, int64_t units_x,
+                                                             const float* __restrict__ w_lag) {
   constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG, SMAX = 18, CTMAX = 5;
   // NIT == 0: the TRANSFER-OPERATOR instance (cvf_ef16_front_transfer) - the block leaves after y and the hand-off of the hidden
   // activations, and everything behind that point is compiled out: no g images in LDS (11 KB per block instead of 26) and fewer
@@ -35,28 +36,59 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
   // held them in two: 5 blocks per CU by registers and LDS)
   constexpr bool kTransfer = NIT == 0;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nw = nthreads >> 6;
+  const int tid = threadIdx.x, lane_in = tid & 63, nthreads = blockDim.x, nw = nthreads >> 6;
   // (the wave number through an SGPR: derived from threadIdx.x alone the compiler treats it - and every address formed
   //  with it, i.e. all of this net's weights and images - as lane-varying, in VGPR pairs)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int net = wave, k = mlp.n_nets, D = mlp.dims[0];
-  // transfer-operator mode (x_lag != NULL): the grid holds the units of x, then the units of the lagged frames, whose tiles
-  // follow the tiles of x in every tiled output; the block stops after y and the hand-off of the hidden activations
-  const bool lagged = x_lag != nullptr && (int64_t)blockIdx.x >= units_x;   // (uniform)
-  const int64_t unit = lagged ? (int64_t)blockIdx.x - units_x : (int64_t)blockIdx.x;   // unit within its frame set
-  const int64_t tile = (unit >> 2) + (lagged ? (units_x >> 2) : 0);
-  const int sub = (int)(unit & 3);
-  if (lagged) x = x_lag;
+  // transfer-operator mode (x_lag != NULL), two launch forms:
+  //   PAIRED (gridDim.x == units_x): the block runs unit u of the frames and then, with the same waves, unit u of their lagged
+  //     partners, so that y and y' of the same 16 frame indices meet in one
+  //     block and wave 0 can form the unit's row of the TIME-LAGGED batch sums (sum w (y' - y)^2 pairs a frame with its
+  //     partner); cvf_ef16_finish then adds the rows as in generator mode (was: cvf_ef_stats, two launches, 15 us).  The
+  //     launch is one round of units_x blocks doing two units each instead of two rounds of 2 units_x blocks.
+  //   unpaired (gridDim.x == 2 units_x): the units of x, then the units of the lagged frames, one per block.
+  // In both the lagged frames' tiles follow the tiles of x in every tiled output, and a pass stops after y and the hand-off.
+  const bool paired = kTransfer && x_lag != nullptr && (int64_t)gridDim.x == units_x;   // (uniform)
   const int nc = pp.n_coord, nal = pp.n_align, N = pp.n_rec;
   const int stride = x_tile_stride(nc);
-  const Front16Lds Lo = front16_lds(nc, nal, k);   // (the transfer instance is launched with Lo.g bytes: no g images)
+  const Front16Lds Lo = front16_lds(nc, nal, k);   // (the transfer instance is launched with Lo.g + 16 floats: no g images)
+  const float* const x_first = x;
+  const float* const w_first = w;
+  // one unit from its coordinates to y (transfer instance) / to the unit's row of batch sums (generator instances).  A lambda so that
+  // a paired transfer block can run it twice as STRAIGHT-LINE code: written as a loop, the by-value descriptors stay in scalar
+  // registers across the iterations, the scalar file overflows into vector lanes and the kernel spills (128 + 37 against 109)
+  auto run_pass = [&](const int pass) __attribute__((always_inline)) {
+  const int lane = lane_in;
+  // ---- this net's weights (requested in every pass, behind the coordinates)
+  const PackLayout L = pack_layout(H, NH, D);
+  const URows pk = urows(packed + (int64_t)net * L.per_net, L.per_net, lane);   // this net's fragments (see URows)
+  const int S = (D + 3) >> 2, CT = (D + 15) >> 4;
+  float a0[SMAX][RT];
+  float bias[NH][RT][4];
+  const int q_ = lane >> 4;
+  auto request_layer0 = [&]() {
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+      const int se = s < S ? s : S - 1;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) a0[s][rt] = pk.ld(L.f0() + (se * RT + rt) * 64);   // (k-steps past S are skipped below)
+    }
+    load_hid_const_u<H>(urows(theta + mlp.b_off[net][0], H, q_), bias[0]);
+  };
+  const bool lagged = x_lag != nullptr && (paired ? pass == 1 : (int64_t)blockIdx.x >= units_x);   // (uniform)
+  const int64_t unit = (lagged && !paired) ? (int64_t)blockIdx.x - units_x : (int64_t)blockIdx.x;   // unit within its frame set
+  const int64_t tile = (unit >> 2) + (lagged ? (units_x >> 2) : 0);
+  const int sub = (int)(unit & 3);
+  x = lagged ? x_lag : x_first;
+  w = lagged ? w_lag : w_first;
   float* xt = lds;
   float* refL = lds + Lo.ref;
   float* aL = lds + Lo.a;
   float* auxL = lds + Lo.aux;
-  float* wL = lds + Lo.w;
+  float* wL = (kTransfer && pass == 1) ? lds + Lo.g : lds + Lo.w;   // (second pass: the partners' weights behind the layout)
   float* rsL = lds + Lo.rs;
-  float* yL = lds + Lo.y;
+  float* yL = lds + Lo.y + (kTransfer ? pass * (k * kU) : 0);   // (second pass: y' goes where the generator instance keeps E)
   float* eL = lds + Lo.e;
   float* featI = lds + Lo.feat;
   float* gI = lds + Lo.g + net * (kU * kImgP);
@@ -84,23 +116,9 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
   // ---- the first layer's weights are requested here, behind the coordinates and the tables (vector memory returns in issue
   //      order: in front of them they delayed the staging by 7 k cycles): their round trip runs beside the barrier and the
   //      alignment (requested after the alignment, layer 0 began with a wait of ~2 k cycles per wave)
-  const PackLayout L = pack_layout(H, NH, D);
-  const URows pk = urows(packed + (int64_t)net * L.per_net, L.per_net, lane);   // this net's fragments (see URows)
-  const int S = (D + 3) >> 2, CT = (D + 15) >> 4;
-  float a0[SMAX][RT];
-  float bias[NH][RT][4];
-  auto request_layer0 = [&]() {
-#pragma unroll
-    for (int s = 0; s < SMAX; ++s) {
-      const int se = s < S ? s : S - 1;
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) a0[s][rt] = pk.ld(L.f0() + (se * RT + rt) * 64);   // (k-steps past S are skipped below)
-    }
-    load_hid_const_u<H>(urows(theta + mlp.b_off[net][0], H, q), bias[0]);
-  };
   // (wave 0 asks after its alignment: the solve's fp64 state and these 36 + 8 registers do not fit 128 together, and
   //  a spilled fragment is stored behind a wait for ALL outstanding loads)
-  if (wave != 0) request_layer0();
+  if (wave != 0) request_layer0();   // (every pass: kept across wave 0's solve of the second pass they would spill)
   __syncthreads();
   const float* my = xt + f * stride;
   CVF_STAMP(21);
@@ -250,6 +268,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     for (int j = p + 4 * wave; j < D; j += 4 * nw) ft[j * CVF_TILE] = fi[j];
     return;
   } else {
+
   // ---- d chain and g = W_1^T d_1 -> this wave's image [frame][feature]
   {
     // (requested behind the hand-off stores of h - vector-memory operations return in issue order - but the d chain below
@@ -530,6 +549,59 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
   }
   CVF_STAMP(30);
   }   // (generator instance)
+  };  // run_pass
+  run_pass(0);
+  if constexpr (kTransfer) {
+    if (!paired) return;                         // (uniform)
+    run_pass(1);                                 // the same waves, the lagged partners of these 16 frames
+    if (partial == nullptr) return;              // (uniform)
+    const int lane = lane_in;
+    const int64_t unit = blockIdx.x;
+    lds_barrier();                               // y and y' of every net are in LDS
+    // ---- wave 0: this unit's row of the time-lagged batch sums [W | S1 | S2(i<=j) | W' | S1' | S2'_ii | T] (cvf_ef_nstats, lag > 0)
+    // in fp64 on the matrix cores, the 16 frames as the contraction index: D1 = [1, y] x [w, w y] holds W, S1_j, S2_ij;
+    // D2 = [1, y'] x [w', w' y'] holds W', S1'_j and S2'_jj on its diagonal; D3 = [y' - y] x [w (y' - y)] holds T_i = sum w (y'_i - y_i)^2
+    // on its diagonal (core.py:412-416, 428).  Products of two floats are exact in fp64, the k-steps add in a fixed order.
+    if (wave == 0) {
+      typedef double f64x4 __attribute__((ext_vector_type(4)));
+      const int np = CVF_NPAIR(k);
+      const int i = lane & 15, kq = lane >> 4;
+      const float* y0 = lds + Lo.y;                  // y of the frames | y' of the partners (the two passes' yL)
+      const float* y1 = y0 + k * kU;
+      const float* w0 = lds + Lo.w;
+      const float* w1 = lds + Lo.g;
+      f64x4 d1 = {0.0, 0.0, 0.0, 0.0}, d2 = {0.0, 0.0, 0.0, 0.0}, d3 = {0.0, 0.0, 0.0, 0.0};
+      const int yi = (i >= 1 && i <= k ? i - 1 : 0) * kU, ti = (i < k ? i : 0) * kU;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const int fr = 4 * s_ + kq;
+        const double wb = (double)w0[fr], wl_ = (double)w1[fr];
+        const double yv = (double)y0[yi + fr], ylv = (double)y1[yi + fr];
+        const double a1 = i == 0 ? 1.0 : (i <= k ? yv : 0.0), b1 = i == 0 ? wb : (i <= k ? wb * yv : 0.0);
+        const double a2 = i == 0 ? 1.0 : (i <= k ? ylv : 0.0), b2 = i == 0 ? wl_ : (i <= k ? wl_ * ylv : 0.0);
+        const double df = i < k ? (double)y1[ti + fr] - (double)y0[ti + fr] : 0.0;
+        d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, d1, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, d2, 0, 0, 0);
+        d3 = __builtin_amdgcn_mfma_f64_16x16x4f64(df, wb * df, d3, 0, 0, 0);
+      }
+      const int cj = lane & 15, o = 1 + k + np;
+      const int64_t G = gridDim.x;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ri = (lane >> 4) + 4 * r;
+        int t = -1;
+        if (ri == 0 && cj <= k) t = cj;
+        else if (ri >= 1 && ri <= cj && cj <= k) {
+          const int a_ = ri - 1, b_ = cj - 1;
+          t = 1 + k + a_ * k - (a_ * (a_ - 1)) / 2 + (b_ - a_);
+        }
+        if (t >= 0) partial[t * G + unit] = d1[r];
+        if (ri == 0 && cj <= k) partial[(o + cj) * G + unit] = d2[r];                             // W', S1'_j
+        if (ri >= 1 && ri == cj && cj <= k) partial[(o + 1 + k + (cj - 1)) * G + unit] = d2[r];   // S2'_jj
+        if (ri == cj && cj < k) partial[(o + 1 + 2 * k + cj) * G + unit] = d3[r];                 // T_i
+      }
+    }
+  }
 }
 }  // namespace
 
@@ -554,7 +626,7 @@ extern "C" int cvf_ef16_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp
 extern "C" int64_t cvf_ef16_scratch_doubles(int64_t B, int k) {
   const int64_t units = 4 * cvf_ntiles(B);
   const int64_t rows = units <= kMaxRows16 ? units : 0;
-  return rows * cvf_ef_nstats(k, 0) + cvf_ef_stats_scratch_doubles(k, 0);
+  return rows * cvf_ef_nstats(k, 1) + cvf_ef_stats_scratch_doubles(k, 1);   // (the time-lagged sums are the longer vector)
 }
 
 // units whose rows of batch sums cvf_ef16_front leaves in `scratch` for cvf_ef16_finish (0: the batch is too large for one
@@ -608,7 +680,7 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
     auto go = [&](auto kernel) {
       if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, *pp, x, B, a, w,
-                         feat_tiled, y_tiled, saved, q_tiled, e_tiled, rows ? scratch : nullptr, ns, (const float*)nullptr, units);
+                         feat_tiled, y_tiled, saved, q_tiled, e_tiled, rows ? scratch : nullptr, ns, (const float*)nullptr, units, (const float*)nullptr);
     };
     const int nit = (pp->n_rec + 3) / 4;   // atoms per lane in the four-lanes-per-frame passes (1..6: d_r <= 72)
     const bool allal = pp->n_align == pp->n_rec;
@@ -641,25 +713,45 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
 // backward pass of both with the coefficients of the time-lagged loss.  Same kernels, same hand-off layout; the front
 // kernel stops after y (no derivative passes), the backward kernel is compiled without the tangent chain.
 // ------------------------------------------------------------------------------------------------------------------
-extern "C" int cvf_ef16_front_transfer(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
-                                       const cvf_pp_desc* pp, const float* x, const float* x_lag, int64_t B, float* y_tiled,
-                                       float* saved, void* stream) {
-  CVF_REQUIRE(cvf_ef16_supported(mlp, pp), "cvf_ef16_front_transfer: shape not covered (cvf_ef16_supported() == 0)");
-  CVF_REQUIRE(theta && packed && feat_tiled && x && x_lag && y_tiled && saved && B > 0, "cvf_ef16_front_transfer: bad argument");
+static int ef16_front_transfer_impl(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                                    const cvf_pp_desc* pp, const float* x, const float* x_lag, int64_t B, float* y_tiled, float* saved,
+                                    const float* w, const float* w_lag, double* rows_out, void* stream, const char* what) {
+  CVF_REQUIRE(cvf_ef16_supported(mlp, pp), "%s: shape not covered (cvf_ef16_supported() == 0)", what);
+  CVF_REQUIRE(theta && packed && feat_tiled && x && x_lag && y_tiled && saved && B > 0, "%s: bad argument", what);
   int H, NH;
   ef16_shape(mlp, &H, &NH);
   const int k = mlp->n_nets;
   const int64_t T = cvf_ntiles(B), units = 4 * T;
-  CVF_REQUIRE(2 * units < (int64_t)1 << 31, "cvf_ef16_front_transfer: batch too large for one launch");
-  const size_t lds = (size_t)front16_lds(pp->n_coord, pp->n_align, k).g * sizeof(float);   // (up to the g images, which this instance lacks)
+  CVF_REQUIRE(2 * units < (int64_t)1 << 31, "%s: batch too large for one launch", what);
+  // a unit and its lagged partner in one block, one after the other (CVF_EF16_UNPAIRED=1: one unit per block, the two sets one after the
+  // other in the grid - the launch of rounds 2-3, kept as a developer switch)
+  const bool paired = rows_out != nullptr || getenv("CVF_EF16_UNPAIRED") == nullptr;
+  const size_t lds = ((size_t)front16_lds(pp->n_coord, pp->n_align, k).g + 16) * sizeof(float);   // (no g images in this instance; + the partners' weights)
   ef16_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
     auto kernel = ef16_front_kernel<kH, kNH, 0, true>;   // NIT = 0: the transfer-operator instance
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(2 * units)), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, *pp, x, B,
-                       (const float*)nullptr, (const float*)nullptr, feat_tiled, y_tiled, saved, (float*)nullptr, (float*)nullptr,
-                       (double*)nullptr, 0, x_lag, units);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(paired ? units : 2 * units)), dim3(64 * k), lds, (hipStream_t)stream, *mlp,
+                       theta, packed, *pp, x, B, (const float*)nullptr, w, feat_tiled, y_tiled, saved, (float*)nullptr, (float*)nullptr,
+                       rows_out, 0, x_lag, units, w_lag);
   });
   return cvf_check_launch("ef16_front_kernel");
 }
 
+extern "C" int cvf_ef16_front_transfer(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                                       const cvf_pp_desc* pp, const float* x, const float* x_lag, int64_t B, float* y_tiled,
+                                       float* saved, void* stream) {
+  return ef16_front_transfer_impl(mlp, theta, packed, feat_tiled, pp, x, x_lag, B, y_tiled, saved, nullptr, nullptr, nullptr, stream,
+                                  "cvf_ef16_front_transfer");
+}
+
+// ... and the units' rows of the time-lagged batch sums in the same launch (cvf_ef16_transfer_rows(B, k) > 0): follow with
+// cvf_ef16_finish / cvf_ef16_finish_dp (cfg.lag_idx > 0) instead of cvf_ef_stats
+extern "C" int64_t cvf_ef16_transfer_rows(int64_t B, int k) { return k >= 1 ? cvf_ef16_rows(B) : 0; }
+extern "C" int cvf_ef16_front_transfer_rows(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                                            const cvf_pp_desc* pp, const float* x, const float* x_lag, int64_t B, float* y_tiled,
+                                            float* saved, const float* w, const float* w_lag, double* scratch, void* stream) {
+  CVF_REQUIRE(w && w_lag && scratch && mlp && cvf_ef16_transfer_rows(B, mlp->n_nets) > 0, "cvf_ef16_front_transfer_rows: bad argument");
+  return ef16_front_transfer_impl(mlp, theta, packed, feat_tiled, pp, x, x_lag, B, y_tiled, saved, w, w_lag, scratch, stream,
+                                  "cvf_ef16_front_transfer_rows");
+}

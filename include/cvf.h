@@ -268,6 +268,14 @@ int cvf_ef16_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const floa
 int cvf_ef16_front_transfer(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
                             const cvf_pp_desc* pp, const float* x, const float* x_lag, int64_t B, float* y_tiled, float* saved,
                             void* stream);
+/* ... and, for k <= 4 (cvf_ef16_transfer_rows(B, k) > 0), the units' rows of the TIME-LAGGED batch sums in the same launch: a block
+ * takes a unit of the frames AND the same unit of their lagged partners, so that sum w (y' - y)^2 (core.py:428) is formed where both
+ * values are; w, w_lag [B]; scratch as cvf_ef16_scratch_doubles.  Follow with cvf_ef16_finish / cvf_ef16_finish_dp (cfg.lag_idx > 0)
+ * instead of cvf_ef_stats (two launches). */
+int64_t cvf_ef16_transfer_rows(int64_t B, int k);
+int cvf_ef16_front_transfer_rows(const cvf_mlp_desc* mlp, const float* theta, const float* packed, float* feat_tiled,
+                                 const cvf_pp_desc* pp, const float* x, const float* x_lag, int64_t B, float* y_tiled, float* saved,
+                                 const float* w, const float* w_lag, double* scratch, void* stream);
 int cvf_ef16_backward_transfer(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed, int64_t B,
                                const float* w, const float* w_lag, const float* feat_tiled, const float* y_tiled,
                                const double* coef, float* slab, int32_t* step_count, const float* saved, void* stream);

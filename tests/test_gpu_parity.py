@@ -1083,7 +1083,7 @@ def test_one_shot_p2p_reduce_between_processes_on_one_gpu(dev, world):
     for tag, v in rep["fused"].items():
         assert v["graph_equals_eager"] and v["fused_equals_separate"] and v["finite"], (tag, v)
     assert rep["launches_ef16_gen"] == ["cvf_ef16_backward", "cvf_ef16_finish_dp", "cvf_ef16_front", "cvf_slab_reduce_dp"], rep["launches_ef16_gen"]
-    assert rep["launches_ef16_tr"] == ["cvf_ef16_backward_transfer", "cvf_ef16_front_transfer", "cvf_ef_stats_dp", "cvf_slab_reduce_dp"]
+    assert rep["launches_ef16_tr"] == ["cvf_ef16_backward_transfer", "cvf_ef16_finish_dp", "cvf_ef16_front_transfer", "cvf_slab_reduce_dp"]
 
 
 def test_a_late_peer_fails_the_job_loudly(dev):
