@@ -29,6 +29,7 @@ for it) and the HIP extension must be built, otherwise construction raises.
 import copy
 import math
 import os
+import types
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -130,20 +131,26 @@ class _CVModel(torch.nn.Sequential):
             return t.device
         return torch.device("cuda")
 
-    _warned_no_graph = False
+    def _autograd_twin(self):
+        """The same map written with torch operators only (the alignment layer replaced by export.ScriptableAlignFeature, the
+        nets as they are), on the compute device - what the reference's own ``Sequential`` is (core.py:372-382): used when the
+        caller wants d xi / d x through autograd.  The HIP kernels carry no autograd graph."""
+        from .export import ScriptableAlignFeature
+        mods = []
+        for m in self.children():
+            mods.append(ScriptableAlignFeature(m).to(self._compute_device()) if hasattr(m, "pp_desc") and hasattr(m, "rec") else m)
+        return torch.nn.Sequential(*mods)
 
     def forward(self, x):
         x = torch.as_tensor(x)
-        if x.requires_grad and torch.is_grad_enabled() and not _CVModel._warned_no_graph:
-            # (the reference returns a differentiable Sequential; this one runs HIP kernels without an autograd graph - say so
-            #  once instead of handing back a silently detached result.  ADVICE r2)
-            _CVModel._warned_no_graph = True
-            import warnings
-            warnings.warn("colvar_model() / reg_model() on MI355X evaluate the CVs with HIP kernels: the result carries no autograd "
-                          "graph (d xi / d x is not available from it). For gradients of the learned CVs load the TorchScript export "
-                          "written by save_model (scripted_cv_cpu.pt / scripted_cv_gpu.pt), which is differentiable.", stacklevel=2)
         dev = _hip.require_gpu(self._compute_device())
         src_dev, src_dt = x.device, (x.dtype if x.dtype.is_floating_point else torch.float32)
+        if x.requires_grad and torch.is_grad_enabled():
+            # differentiable call (the reference returns a plain differentiable Sequential: d xi / d x by autograd, e.g. for the
+            # Dirichlet energy of a learned CV): torch operators on the GPU in fp32, graph attached, answer in the caller's type
+            with torch.cuda.device(dev):
+                out = self._autograd_twin()(x.to(device=dev, dtype=torch.float32))   # (the nets' parameters are fp32)
+            return out.to(device=src_dev, dtype=src_dt)
         with torch.cuda.device(dev):
             out = super().forward(x.detach().to(device=dev, dtype=torch.float32))
         return out.to(device=src_dev, dtype=src_dt)
@@ -1055,7 +1062,17 @@ class AutoEncoderTask(TrainingTask):
         self._traj_host = _HostFrames(traj_obj.trajectory)
         self._n_frames = int(self._traj_host.shape[0])
         self._weights = torch.as_tensor(np.asarray(traj_obj.weights)).to(device=self.device, dtype=torch.float32).contiguous()
-        self._pp = pp = self._pp_desc(int(np.prod(self._traj_host.shape[1:])))
+        # pp_layer: the alignment + feature kernel (AlignFeatureLayer / Identity) or ANY torch module (core.py:65,122,635): this
+        # task applies it exactly once, to build the feature trajectory - a foreign module is run there with torch, on the
+        # device, and the training step (cvf_ae_step on the resident feature rows) is the same either way
+        self._foreign_pp = not isinstance(self.preprocessing_layer, (torch.nn.Identity, AlignFeatureLayer))
+        if self._foreign_pp:
+            with torch.no_grad():
+                probe = self.preprocessing_layer(torch.as_tensor(self._traj_host.rows(np.arange(1))).to(device=self.device, dtype=torch.float32))
+            pp = types.SimpleNamespace(d_r=int(probe.reshape(1, -1).shape[1]))
+            self._pp = pp
+        else:
+            self._pp = pp = self._pp_desc(int(np.prod(self._traj_host.shape[1:])))
         # core.py:635: the feature trajectory r(x) of ALL frames, once.  In a data-parallel job (one process per GPU) each
         # rank computes the features of its own rows only, in train(), once the split is known.
         self._sharded = _dist.world() > 1
@@ -1072,6 +1089,12 @@ class AutoEncoderTask(TrainingTask):
         """K1 over host frames -> row-major feature rows resident in HBM."""
         X = _hip.upload_f32(rows, self.device)
         n = X.shape[0]
+        if self._foreign_pp:     # a module this package has no kernel for: torch, on the device, in bounded chunks, once
+            out = torch.empty(n, self._pp.d_r, device=self.device, dtype=torch.float32)
+            with torch.no_grad():
+                for s0 in range(0, n, 65536):
+                    out[s0:s0 + 65536] = self.preprocessing_layer(X[s0:s0 + 65536]).reshape(-1, self._pp.d_r)
+            return out
         out = torch.empty(n, self._pp.d_r, device=self.device, dtype=torch.float32)
         if n > 0:
             _hip.check(_hip.lib().cvf_align_feature_fwd(self._pp, _hip.ptr(X), n, None, _hip.ptr(out), None,

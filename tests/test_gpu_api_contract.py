@@ -384,3 +384,86 @@ def test_epoch_graphs_in_chunks_equal_eager_launches(dev, tmp_path):
     assert tr_g.shape[1] == 300 and te_g.shape[1] == 75
     np.testing.assert_array_equal(tr_g, tr_e)
     np.testing.assert_array_equal(te_g, te_e)
+
+
+def test_colvar_model_is_differentiable_like_the_reference(dev):
+    """core.py:372-382, 640-647: the reference's colvar_model() is a plain differentiable Sequential.  A call whose input requires
+    grad returns a result WITH an autograd graph (torch operators on the GPU); d xi / d x agrees with autograd through the fp64
+    oracle (the alignment through linalg.svd, as the reference differentiates it at core.py:424), for both tasks' models."""
+    from colvarsfinder import core, nn, pp
+    from oracle import nnref
+    from oracle.pp import AlignFeature
+    from tests.synth import Traj, diag_coeff_for, make_molecule_traj
+    n_atoms, k = 10, 2
+    traj, w, ref = make_molecule_traj(n_atoms, 64, seed=41)
+    feats = [("position", (0, 2, 3, 5)), ("bond", (0, 1)), ("angle", (1, 2, 3)), ("dihedral", (4, 5, 6, 7))]
+    align = [0, 1, 2, 4, 5, 8]
+    layer = pp.AlignFeatureLayer(n_atoms, align, ref[align], feats)
+    dims = [layer.d_r, 12, 12, 1]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(2))
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    a = torch.tensor(diag_coeff_for(n_atoms, 1), dtype=torch.float32)
+    task = core.EigenFunctionTask(Traj(traj, w, 1.0), layer, model, "/tmp/cvf_test", 10.0, [1.0, 0.5], diag_coeff=a, k=k, device=dev,
+                                  verbose=False, save_model_every_step=0)
+    cv = task.colvar_model()
+    x = torch.tensor(traj[:16], dtype=torch.float64, requires_grad=True)
+    y = cv(x)
+    assert y.requires_grad and y.dtype == torch.float64 and y.device == x.device
+    (gx,) = torch.autograd.grad(y[:, 1].sum(), x)
+    torch.set_default_dtype(torch.float64)
+    try:
+        xo = torch.tensor(traj[:16], dtype=torch.float64, requires_grad=True)
+        yo = nnref.eigenfunctions_forward({n: p.double() for n, p in sd0.items()}, k, AlignFeature(align, ref[align], feats)(xo))
+        (go,) = torch.autograd.grad(yo[:, 1].sum(), xo)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(y.detach().numpy(), yo.detach().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(gx.numpy(), go.numpy(), rtol=0, atol=2e-5 * float(go.abs().max()))
+    # the kernel path (no grad wanted) gives the same values in fp32
+    y32 = cv(torch.tensor(traj[:16])).detach()
+    np.testing.assert_allclose(y32.numpy(), yo.detach().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_autoencoder_task_takes_any_module_as_pp_layer(dev):
+    """core.py:65,122,635: pp_layer is ANY torch module; AutoEncoderTask applies it once to build the feature trajectory.  A module
+    this package has no kernel for (here: pairwise distances, hand-written) is run with torch on the device at construction; the
+    training step on the resident feature rows is the usual kernel - first-step loss and a short training against the oracle."""
+    from colvarsfinder import core, nn
+    from oracle import nnref, train as otrain
+    from tests.synth import Traj, make_molecule_traj
+
+    class PairDistances(torch.nn.Module):
+        def __init__(self, n_atoms):
+            super().__init__()
+            i, j = torch.triu_indices(n_atoms, n_atoms, offset=1)
+            self.register_buffer("i", i)
+            self.register_buffer("j", j)
+
+        def forward(self, x):
+            return (x[:, self.i, :] - x[:, self.j, :]).norm(dim=2)
+
+    n_atoms = 6
+    traj, w, _ = make_molecule_traj(n_atoms, 400, seed=17)
+    layer = PairDistances(n_atoms)
+    d_r = n_atoms * (n_atoms - 1) // 2
+    e_dims, d_dims = [d_r, 12, 2], [2, 12, d_r]
+    sd0 = nnref.init_autoencoder(e_dims, d_dims, torch.Generator().manual_seed(4))
+    model = nn.AutoEncoder(e_dims, d_dims)
+    model.load_state_dict(sd0)
+    want_feat = layer(torch.tensor(traj)).numpy()             # (on the CPU, before the task moves the module to its device)
+    task = core.AutoEncoderTask(Traj(traj, w, 1.0), layer, model, "/tmp/cvf_test", learning_rate=2e-3, batch_size=100, num_epochs=2,
+                                device=dev, verbose=False, save_model_every_step=0)
+    np.testing.assert_allclose(task._feature_traj.cpu().numpy(), want_feat, rtol=1e-6, atol=1e-6)
+    np.random.seed(7)
+    task.train()
+    np.random.seed(7)
+    torch.set_default_dtype(torch.float64)
+    try:
+        res = otrain.train_ae({n: p.double() for n, p in sd0.items()}, PairDistances(n_atoms), traj.astype(np.float64), w, learning_rate=2e-3,
+                              batch_size=100, num_epochs=2)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(np.stack([e[0].numpy() for e in task.loss_list]), np.stack([e[0].numpy() for e in res["loss_list"]]), rtol=2e-5)
+    cv = task.colvar_model()(torch.tensor(traj[:8]))          # Sequential(pp_layer, encoder) on CPU input, like the notebooks
+    assert cv.shape == (8, 2) and torch.isfinite(cv).all()
