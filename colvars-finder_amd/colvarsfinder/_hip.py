@@ -14,14 +14,14 @@ TILE = 64
 MAX_NETS = 8
 MAX_LAYERS = 12
 AUX_ROWS = 18
-EF_HIDDEN_WIDTHS = (8, 12, 16, 20, 24, 32)   # hidden widths the eigenfunction kernels are instantiated for (csrc/ef_mfma.hip)
+EF_HIDDEN_WIDTHS = (8, 12, 16, 20, 24, 32, 48, 64)   # hidden widths the eigenfunction kernels are instantiated for (csrc/ef_mfma.hip)
 
 
 def ef_widths(n_hidden):
     """Hidden widths the eigenfunction kernels are instantiated for at this depth (csrc/ef_mfma.hip: ef_dispatch)."""
     if n_hidden >= 4:
         return (20, 32) if n_hidden <= 5 else ()
-    return tuple(w for w in EF_HIDDEN_WIDTHS if w < 24 or n_hidden >= 2)
+    return tuple(w for w in EF_HIDDEN_WIDTHS if w < 24 or n_hidden >= 2)   # (48 and 64: the plain 64-frame kernels, two or three hidden layers)
 
 
 FEAT_ANGLE, FEAT_BOND, FEAT_DIHEDRAL, FEAT_POSITION = 0, 1, 2, 3

@@ -1598,6 +1598,7 @@ bool ef_shape(const cvf_mlp_desc* m, int* H, int* NH) {
 
 int64_t bwd_grid(int64_t n_tiles) { return n_tiles < 1024 ? n_tiles : 1024; }
 
+constexpr int kFusedMaxH = 32;   // widest hidden layer of the fused / register-resident launches (see ef_dispatch)
 template <class F>
 bool ef_dispatch(int H, int NH, F&& f) {
 #define EF_CASE(H_, NH_)                                                        \
@@ -1611,6 +1612,10 @@ bool ef_dispatch(int H, int NH, F&& f) {
   EF_CASE(20, 1) EF_CASE(20, 2) EF_CASE(20, 3)
   EF_CASE(24, 2) EF_CASE(24, 3)
   EF_CASE(32, 2) EF_CASE(32, 3)
+  // wider hidden layers (up to 64 units; other widths are zero-padded to 48 / 64 by the host): the plain forward and backward
+  // kernels only (kWideH) - the fused launches keep a net's whole chain in registers and are instantiated up to 32 units
+  EF_CASE(48, 2) EF_CASE(48, 3)
+  EF_CASE(64, 2) EF_CASE(64, 3)
   // four and five hidden layers (e.g. regulariser o encoder chains of RegAutoEncoderTask's generator mode): two widths,
   // narrower nets are zero-padded to them by the host
   EF_CASE(20, 4) EF_CASE(20, 5)
@@ -1654,6 +1659,7 @@ static bool fwd_wg_ok(const cvf_mlp_desc* mlp, int H, int NH) {
 extern "C" int64_t cvf_ef_saved_floats(const cvf_mlp_desc* mlp, int64_t n_tiles) {
   int H, NH;
   if (!mlp || !ef_shape(mlp, &H, &NH) || getenv("CVF_NO_SAVED")) return 0;
+  if (H > kFusedMaxH) return 0;   // (wider layers: the backward kernel runs the chain forward again)
   const bool wide = mlp->dims[0] > kWideD;   // (+ one vector per (tile, net) for t0 = W0 q, see ef_backward_impl)
   if (!fwd_wg_ok(mlp, H, NH) && !wide) return 0;
   int64_t per_vec = 0;
@@ -1677,23 +1683,31 @@ extern "C" int cvf_ef_mlp_fwd(const cvf_mlp_desc* mlp, const float* theta, const
   CVF_REQUIRE(saved == nullptr || cvf_ef_saved_floats(mlp, 1) > 0, "cvf_ef_mlp_fwd: this shape has no activation hand-off (cvf_ef_saved_floats() == 0)");
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    if (mlp->dims[0] > kWideD && getenv("CVF_NO_FWD_WIDE") == nullptr) {
-      (void)hipFuncSetAttribute((const void*)ef_fwd_wide_kernel<kH, kNH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)wide_lds_bytes<kH>());
-      hipLaunchKernelGGL((ef_fwd_wide_kernel<kH, kNH>), dim3((unsigned)n_tiles, mlp->n_nets), dim3(64 * kWW), wide_lds_bytes<kH>(),
-                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled, saved);
+    bool done = false;
+    if constexpr (kH <= kFusedMaxH) {
+      if (mlp->dims[0] > kWideD && getenv("CVF_NO_FWD_WIDE") == nullptr) {
+        (void)hipFuncSetAttribute((const void*)ef_fwd_wide_kernel<kH, kNH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)wide_lds_bytes<kH>());
+        hipLaunchKernelGGL((ef_fwd_wide_kernel<kH, kNH>), dim3((unsigned)n_tiles, mlp->n_nets), dim3(64 * kWW), wide_lds_bytes<kH>(),
+                           (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled, saved);
+        done = true;
+      } else if (!wg && pre) {
+        if (split)
+          hipLaunchKernelGGL((ef_fwd_pre_kernel<kH, kNH, 2>), dim3((unsigned)(2 * n_tiles), mlp->n_nets), dim3(64), 0,
+                             (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
+        else
+          hipLaunchKernelGGL((ef_fwd_pre_kernel<kH, kNH, 4>), dim3((unsigned)n_tiles, mlp->n_nets), dim3(64), 0,
+                             (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
+        done = true;
+      }
+    }
+    if (done) {
     } else if (wg) {
       if (wlds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)ef_fwd_wg_kernel<kH, kNH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
       hipLaunchKernelGGL((ef_fwd_wg_kernel<kH, kNH>), dim3((unsigned)((n_tiles + 3) / 4), mlp->n_nets), dim3(256), wlds,
                          (hipStream_t)stream, *mlp, theta, packed, feat_tiled, n_tiles, y_tiled, g_tiled, saved);
-    } else if (pre && split)
-      hipLaunchKernelGGL((ef_fwd_pre_kernel<kH, kNH, 2>), dim3((unsigned)(2 * n_tiles), mlp->n_nets), dim3(64), 0,
-                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
-    else if (pre)
-      hipLaunchKernelGGL((ef_fwd_pre_kernel<kH, kNH, 4>), dim3((unsigned)n_tiles, mlp->n_nets), dim3(64), 0,
-                         (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled);
-    else if (split)
+    } else if (split)
       hipLaunchKernelGGL((ef_fwd_mfma_kernel<kH, kNH, 2>), dim3((unsigned)(2 * n_tiles), mlp->n_nets), dim3(64), 0,
                          (hipStream_t)stream, *mlp, theta, packed, feat_tiled, y_tiled, g_tiled, saved);
     else
@@ -1715,7 +1729,7 @@ static size_t fwd_metric_lds(const cvf_pp_desc* pp, int k) {
 extern "C" int cvf_ef_fwd_metric_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp) {
   int H, NH;
   if (!mlp || !pp || !ef_shape(mlp, &H, &NH) || getenv("CVF_NO_FWD_METRIC")) return 0;
-  if (!ef_dispatch(H, NH, [](auto, auto) {})) return 0;
+  if (!ef_dispatch(H, NH, [](auto, auto) {}) || H > kFusedMaxH) return 0;
   const int fast = CVF_PP_ALIGN_CONTIG | CVF_PP_PURE_POSITION;
   if (pp->mode != CVF_PP_ALIGN || pp->align_w || (pp->flags & fast) != fast || pp->n_align > pp->n_rec) return 0;
   if (pp->d_r != 3 * pp->n_rec || pp->d_r != mlp->dims[0] || pp->d_r > 72 || pp->n_coord > 192) return 0;
@@ -1756,8 +1770,10 @@ static int fwd_metric_launch(bool with_k1, const cvf_mlp_desc* mlp, const float*
       hipLaunchKernelGGL(kernel, dim3((unsigned)T), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, feat_tiled, *pp, x, B,
                          aux_tiled, a, y_tiled, saved, q_tiled, e_tiled, f);
     };
-    if (with_k1) go(ef_fwd_metric_kernel<kH, kNH, true>);
-    else go(ef_fwd_metric_kernel<kH, kNH, false>);
+    if constexpr (kH <= kFusedMaxH) {
+      if (with_k1) go(ef_fwd_metric_kernel<kH, kNH, true>);
+      else go(ef_fwd_metric_kernel<kH, kNH, false>);
+    }
   });
   int rc = cvf_check_launch("ef_fwd_metric_kernel");
   if (rc || stats == nullptr) return rc;   // stats == NULL: the caller finishes the rows itself (cvf_ef_stats_finish_rows)
@@ -1788,10 +1804,12 @@ extern "C" int cvf_ef_align_fwd(const cvf_mlp_desc* mlp, const float* theta, con
   CVF_REQUIRE(lds <= 160 * 1024, "cvf_ef_align_fwd: %zu B of LDS per workgroup (> 160 KiB)", lds);
   ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    auto kernel = ef_align_fwd_kernel<kH, kNH>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)n_tiles), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, feat_tiled, *pp, x,
-                       x_lag, T, B, y_tiled, saved);
+    if constexpr (kH <= kFusedMaxH) {
+      auto kernel = ef_align_fwd_kernel<kH, kNH>;
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)n_tiles), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, feat_tiled, *pp, x,
+                         x_lag, T, B, y_tiled, saved);
+    }
   });
   return cvf_check_launch("ef_align_fwd_kernel");
 }
@@ -1882,7 +1900,7 @@ static int ef_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, cons
   const size_t lds_dyn = (size_t)(span - (a.direct0 ? H * mlp->dims[0] + H : 0)) * sizeof(float);
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
-    if (saved != nullptr && wide && cfg->lag_idx == 0 && getenv("CVF_NO_T0") == nullptr) {
+    if (kH <= kFusedMaxH && saved != nullptr && wide && cfg->lag_idx == 0 && getenv("CVF_NO_T0") == nullptr) {
       float* t0 = const_cast<float*>(saved) + a.n_tiles * cfg->k * (int64_t)(kNH * saved_per_vec<kH>());   // (behind the activations)
       (void)hipFuncSetAttribute((const void*)ef_t0_kernel<kH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes<kH>());
       hipLaunchKernelGGL((ef_t0_kernel<kH>), dim3((unsigned)a.T, cfg->k), dim3(64 * kWW), wide_lds_bytes<kH>(), (hipStream_t)stream,

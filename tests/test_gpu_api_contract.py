@@ -218,7 +218,7 @@ def test_unsupported_net_shape_is_rejected_at_construction(dev, tmp_path):
     from colvarsfinder import core, nn
     traj, w, ref = make_molecule_traj(10, 100, seed=1)
     # too wide; six hidden layers; ONE hidden layer wider than the one-hidden-layer kernels' widest (crashed in min())
-    for dims in ([30, 64, 64, 1], [30, 20, 20, 20, 20, 20, 20, 1], [30, 24, 1], [30, 32, 1]):
+    for dims in ([30, 80, 80, 1], [30, 20, 20, 20, 20, 20, 20, 1], [30, 24, 1], [30, 32, 1]):
         model = nn.EigenFunctions(dims, 2)
         with pytest.raises(NotImplementedError, match="no kernel instance"):
             core.EigenFunctionTask(Traj(traj, w, 1.0), _position_layer(10, ref, dev), model, str(tmp_path), 10.0, [1.0, 0.5], k=2,

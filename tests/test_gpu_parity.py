@@ -559,7 +559,7 @@ def test_regae_unbuilt_options_fail_loudly(dev):
     traj, w = make_2d_traj(200, seed=3)
     model = nn.RegAutoEncoder([2, 8, 1], [1, 8, 2], [1, 8, 1], 1)
     kw = dict(eig_weights=[1.0], device=dev, verbose=False)
-    wide_reg = nn.RegAutoEncoder([2, 8, 1], [1, 8, 2], [1, 40, 1], 1)
+    wide_reg = nn.RegAutoEncoder([2, 8, 1], [1, 8, 2], [1, 96, 1], 1)
     with pytest.raises(NotImplementedError):   # generator-mode regulariser on a chain the eigenfunction kernels do not cover
         core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), wide_reg, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0, **kw)
     core.RegAutoEncoderTask(Traj(traj, w, 0.5), torch.nn.Identity(), model, "/tmp/cvf_test", gamma=[1.0, 1.0], lag_tau_reg=0, **kw)   # built
@@ -1307,6 +1307,61 @@ def test_four_and_five_hidden_layers_generator_step_vs_oracle(dev, dims, mixed):
     got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
     # and a few optimiser steps run (the fused Adam path of the deeper instances)
+    np.random.seed(1)
+    task.num_epochs, task.batch_size = 2, 50
+    task.train()
+    assert np.isfinite(task.train_loss_df.to_numpy()).all()
+
+
+@pytest.mark.parametrize("dims,lag,d_in", [([27, 48, 48, 1], 0, "pos"), ([27, 64, 64, 64, 1], 0, "pos"), ([20, 40, 40, 1], 0, "mixed"),
+                                           ([27, 64, 64, 1], 2, "pos"), ([27, 56, 48, 64, 1], 2, "pos"), ([200, 48, 48, 1], 0, "wide")])
+def test_hidden_layers_up_to_64_units_vs_oracle(dev, dims, lag, d_in):
+    """VERDICT r3 item 7 / nn.py:29-59, 242-293 (the reference takes any layer_dims): eigenfunction nets with hidden layers of up to 64
+    units (kernel widths 48 and 64 on the plain 64-frame kernels; 40 / 56 zero-padded to them), generator and transfer mode, a
+    first layer past 128 inputs too: loss, eigenvalues, ordering and every parameter gradient against the fp64 oracle, then a few
+    optimiser steps."""
+    from colvarsfinder import core, nn
+    from oracle import losses, nnref
+    k = 2
+    if d_in == "wide":
+        n_atoms, B = 257, 70
+        traj, w, ref = make_molecule_traj(n_atoms, B + lag, seed=2100 + dims[1], scale=6.0, sigma=0.4)
+        rs = np.random.RandomState(3)
+        feats = [("position", tuple(int(i) for i in rs.choice(n_atoms, 40, replace=False)))]
+        feats += [("dihedral", tuple(int(i) for i in rs.choice(n_atoms, 4, replace=False))) for _ in range(30)]
+        feats += [("bond", tuple(int(i) for i in rs.choice(n_atoms, 2, replace=False))) for _ in range(20)]
+        spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=feats, use_angle_value=False)
+    else:
+        mixed = d_in == "mixed"
+        n_atoms, B = (10, 150) if mixed else (9, 130)
+        traj, w, ref = make_molecule_traj(n_atoms, B + lag, seed=2100 + dims[1], scale=2.0, sigma=0.3)
+        align = [0, 1, 2, 4, 5, 8] if mixed else list(range(n_atoms))
+        spec = dict(align_idx=align, ref_pos=ref[align], features=MIXED if mixed else [("position", tuple(range(n_atoms)))], use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    assert layer.d_r == dims[0]
+    sd0 = nnref.init_eigenfunctions(dims, k, torch.Generator().manual_seed(13))
+    model = nn.EigenFunctions(dims, k)
+    model.load_state_dict(sd0)
+    a = torch.tensor(diag_coeff_for(n_atoms, 3), dtype=torch.float32) if lag == 0 else None
+    task = core.EigenFunctionTask(Traj(traj, w, 0.5), layer, model, "/tmp/cvf_test", 12.0, [1.0, 0.6], diag_coeff=a, beta=1.2, lag_tau=0.5 * lag,
+                                  k=k, device=dev, verbose=False, save_model_every_step=0)
+    X, W = torch.tensor(traj[:B]), torch.tensor(w[:B])
+    Xl, Wl = (torch.tensor(traj[lag:lag + B]), torch.tensor(w[lag:lag + B])) if lag else (None, None)
+    loss, eig, npl, pen, cvec = task.loss_func(X, W, Xl, Wl)
+    task.backward()
+    torch.set_default_dtype(torch.float64)
+    sd = {n: p.double().requires_grad_(True) for n, p in sd0.items()}
+    Xo = X.double().requires_grad_(lag == 0)
+    lo, eo, no, po, co = losses.ef_loss(sd, k, oracle_layer(spec), Xo, W, None if Xl is None else Xl.double(), Wl, alpha=12.0, eig_w=[1.0, 0.6],
+                                        diag_coeff=None if a is None else a.double(), beta=1.2, lag_idx=lag, dt=0.5)
+    lo.backward()
+    torch.set_default_dtype(torch.float32)
+    np.testing.assert_allclose(float(loss), float(lo.detach()), rtol=RTOL64)
+    np.testing.assert_allclose(eig.numpy(), eo.numpy(), rtol=RTOL64)
+    assert list(cvec) == list(co)
+    want = torch.cat([sd[n].grad.reshape(-1) for n, _ in model.named_parameters()]).numpy()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=20 * RTOL64, atol=20 * RTOL64 * np.abs(want).max())
     np.random.seed(1)
     task.num_epochs, task.batch_size = 2, 50
     task.train()
