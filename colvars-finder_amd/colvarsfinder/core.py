@@ -626,6 +626,9 @@ class EigenFunctionTask(TrainingTask):
         # current step's backward kernel.  Off by default: at 20 000 frames per step it measured 133 us/step against
         # 126 serial - the two-branch graph costs more at the fork/join than the 14 us kernel it hides.
         self._ef16 = None
+        # (RegAutoEncoderTask drives an inner task of this class: `_local_only` - evaluate the batch handed in on this rank alone, no
+        #  cross-rank sums; `_grad_local` - leave the parameter gradient un-reduced, the caller sums its own flat gradient later)
+        self._local_only = self._grad_local = False
         self._fused_fm = self._fused_k1 = self._fused_tr = None   # decided on first use: cvf_ef_[align_]fwd_metric_supported(nets, layer)
         self._side = torch.cuda.Stream(device=self.device)
         self._pipeline = os.environ.get("CVF_PIPELINE", "0") == "1"
@@ -694,7 +697,7 @@ class EigenFunctionTask(TrainingTask):
         ws.slot = slot
         fl, k, d_r = self._flat, self.k, self._pp.d_r
         lag = self.lag_idx
-        single = not _dist.collectives()   # no cross-rank reduction: the loss tail runs inside the stats launch
+        single = not _dist.collectives() or self._local_only   # no cross-rank reduction: the loss tail runs inside the stats launch
         ws.loss_out = ws.loss_vec if out is None else out
         assert ws.loss_out.is_contiguous() and ws.loss_out.dtype == torch.float64 and ws.loss_out.numel() == 3 + 2 * k
         lv, cf = (P(ws.loss_out), P(ws.coef)) if single else (None, None)
@@ -805,14 +808,15 @@ class EigenFunctionTask(TrainingTask):
             self._call("cvf_ef_backward", lib.cvf_ef_backward, self._cfg, fl.desc, P(fl.theta), P(fl.packed), ws.B, P(w), P(w_lag),
                        P(ws.feat), P(ws.y), P(ws.q) if self.lag_idx == 0 else None, P(ws.coef), P(ws.slab),
                        P(self.optimizer.step_count) if advance else None, P(ws.saved), _hip.stream())
-        comm = _dist.fused_comm()
+        local = self._local_only or self._grad_local
+        comm = None if local else _dist.fused_comm()
         if comm is not None:   # sum of the slab rows -> collective #2 -> (train_step) the identical Adam update: one launch
             adam = self.optimizer.fused_args() if advance else None
             self._call("cvf_slab_reduce_dp", lib.cvf_slab_reduce_dp, P(ws.slab), ws.slab_rows, fl.n, P(fl.grad), adam, comm, _hip.stream())
             return adam is not None
         adam = self.optimizer.fused_args() if fuse_adam else None
         self._call("cvf_slab_reduce", lib.cvf_slab_reduce, P(ws.slab), ws.slab_rows, fl.n, P(fl.grad), adam, _hip.stream())
-        if not fuse_adam:
+        if not fuse_adam and not local:
             self._allreduce("allreduce_gradient", fl.grad)                                                # collective #2
         return adam is not None
 
@@ -1413,9 +1417,11 @@ class _EncGradPenalty:
             self._ws[B] = ws
         return ws
 
-    def run(self, rows, w, eta0, with_grad):
+    def run(self, rows, w, eta0, with_grad, dp=False):
         """``rows``: [B, d_r] feature rows of the batch (contiguous), ``w``: [B].  Returns the term (0-dim fp64 device tensor);
-        with ``with_grad`` adds d(eta0 * term)/d(encoder parameters) to the encoder's block of the task's flat gradient."""
+        with ``with_grad`` adds d(eta0 * term)/d(encoder parameters) to the encoder's block of the task's flat gradient.
+        ``dp``: the batch is this rank's slice of a global batch - the batch sums are added across the ranks, the gradient
+        contribution stays this rank's share (the caller sums the flat gradient)."""
         task, lib, P, s = self.task, _hip.lib(), _hip.ptr, _hip.stream()
         fl, k = task._flat, self.k
         B = int(rows.shape[0])
@@ -1428,6 +1434,8 @@ class _EncGradPenalty:
         task._call("cvf_metric_apply", lib.cvf_metric_apply_stats, self.pp, P(rows), B, None, P(self.ones), k, P(ws["g"]), P(ws["q"]),
                    P(ws["e"]), None, None, self.cfg, P(w), P(ws["y"]), P(ws["scratch"]), P(ws["stats"]), None, None, s)
         st = ws["stats"]                                   # [W, S1(k), S2(i<=j), E(k)]
+        if dp:
+            task._allreduce("allreduce_batch_sums", st)
         e0 = 1 + k + k * (k + 1) // 2
         term = st[e0:e0 + k].sum() / st[0]
         if with_grad:
@@ -1533,10 +1541,13 @@ class _RegGenerator:
                 out.append(torch.nn.functional.pad(b, (0, fo - b.shape[0])))
         return torch.cat(out)
 
-    def forward(self, X, w, with_grad):
+    def forward(self, X, w, with_grad, dp=False):
         """Loss terms of the batch ``X`` (raw coordinates on the device): returns the inner task's device loss vector
-        ``[npl + (gamma_1/gamma_0) pen, npl, pen, eig_1..K sorted, cvec]`` (fp64)."""
+        ``[npl + (gamma_1/gamma_0) pen, npl, pen, eig_1..K sorted, cvec]`` (fp64).  ``dp``: ``X`` is this rank's slice of a global
+        batch - the inner task adds its batch sums across the ranks (collective #1) and leaves its gradient local; else the
+        batch is evaluated on the calling rank alone."""
         inner = self.inner
+        inner._local_only, inner._grad_local = not dp, True
         with torch.enable_grad() if with_grad else torch.no_grad():
             self._tv = self._theta()
         inner._flat.theta.copy_(self._tv.detach())
@@ -1603,10 +1614,8 @@ class RegAutoEncoderTask(TrainingTask):
         # Data-parallel job (one process per GPU): the batch's frames are split over the ranks, the three kinds of batch sums
         # (reconstruction error, latent statistics, regulariser heads) and the gradient are summed across them;
         # the feature trajectory itself is small (d_r floats per frame) and stays whole on every rank.  The two parts that run on
-        # an inner EigenFunctionTask (generator-mode regulariser, gradient-norm penalty eta[0]) are single-process.
-        if _dist.world() > 1 and ((self._use_reg and self.lag_idx == 0) or self.eta[0] > self._eps):
-            raise NotImplementedError("RegAutoEncoderTask on MI355X, data-parallel: the generator-mode regulariser (lag_tau_reg = 0) and the "
-                                      "gradient-norm penalty eta[0] run in one process only; use lag_tau_reg > 0 / eta[0] = 0 or one GPU")
+        # an inner EigenFunctionTask (generator-mode regulariser, gradient-norm penalty eta[0]) add their batch sums across the
+        # ranks too and leave their gradient shares in the flat gradient, which is summed once, at the end of the step.
         self.init_model_and_optimizer()
         # --- data: the feature trajectory r(x) of every frame, once (the layer has no parameters), resident in HBM
         traj = _HostFrames(traj_obj.trajectory).all()
@@ -1755,10 +1764,8 @@ class RegAutoEncoderTask(TrainingTask):
                        P(ws["coef"]) if use_reg else None, self._n_enc_layers, P(ws["ecoef"]) if use_enc else None,
                        P(ws["scratch"]), P(fl.grad), P(fl.mask),
                        P(self.optimizer.step_count) if advance else None, adam, _hip.stream())
-            if dp:
-                self._allreduce("allreduce_gradient", fl.grad)
         if gen is not None:
-            lv = gen.forward(X if X is not None else (self._traj[:B] if idx is None else self._traj.index_select(0, idx)), w, with_grad)
+            lv = gen.forward(X if X is not None else (self._traj[:B] if idx is None else self._traj.index_select(0, idx)), w, with_grad, dp)
             out[2:4] = lv[1:3]
             out[4:4 + K] = lv[3:3 + K]
             out[0] += float(self.gamma[0]) * lv[1] + float(self.gamma[1]) * lv[2]
@@ -1766,9 +1773,11 @@ class RegAutoEncoderTask(TrainingTask):
             if with_grad:
                 gen.backward(w, float(self.gamma[0]))
         if eg is not None:
-            term = eg.run(rows, w, float(self.eta[0]), with_grad and not self.freeze_encoder)
+            term = eg.run(rows, w, float(self.eta[0]), with_grad and not self.freeze_encoder, dp)
             out[4 + K] = term
             out[0] += float(self.eta[0]) * term
+        if with_grad and dp:
+            self._allreduce("allreduce_gradient", fl.grad)      # collective #2: every part's share, once
         if with_grad and advance and adam is None:
             self.optimizer.step(advance=False)
         return out
