@@ -613,6 +613,10 @@ class EigenFunctionTask(TrainingTask):
         # large molecules (streaming alignment path): moments of (diag_coeff, reference) used by the derivative kernel
         self._dense = None
         if self.lag_idx == 0 and _hip.lib().cvf_align_feature_scratch_bytes(self._pp, 64) > 0:
+            why = self.preprocessing_layer.derivative_table_limits()
+            if why is not None:   # (here, not as a generic message at the first step)
+                raise NotImplementedError(f"EigenFunctionTask (generator mode) on MI355X: the feature list has {why} "
+                                          "(csrc/metric_large.hip). Use lag_tau > 0 (no derivative through the features) or fewer features per atom.")
             self._dense = torch.zeros(_hip.lib().cvf_metric_dense_doubles(self._pp), device=self.device, dtype=torch.float64)
             _hip.check(_hip.lib().cvf_metric_dense_tensors(self._pp, _hip.ptr(self._diag_coeff), _hip.ptr(self._dense),
                                                            _hip.stream()), "cvf_metric_dense_tensors")

@@ -176,6 +176,19 @@ class AlignFeatureLayer(torch.nn.Module):
         self.register_buffer("ref_c", torch.tensor(ref_c, dtype=torch.float32))
         self.register_buffer("rec", torch.tensor(rec, dtype=torch.int32).reshape(-1, 6))
 
+    def derivative_table_limits(self):
+        """None, or why the large-molecule derivative kernel (csrc/metric_large.hip: metric_rows_kernel) cannot take this feature
+        list: its tables pack a record's slots and rows into 16-bit fields, a record's position among its atom's rows into 8 bits
+        and a slot's row count into 12 bits.  EigenFunctionTask's generator mode asks at construction."""
+        rows_per_slot = int(np.diff(np.concatenate([[0], self.slot_row.cpu().numpy()])).max()) if self.slot_row.numel() else 0
+        for what, have, limit in (("contribution rows (atoms summed over the features)", self._n_ref, 65536),
+                                  ("distinct feature atoms", self._n_slot, 65536),
+                                  ("features that share one atom", getattr(self, "_row_off_max", 0) + 1, 256),
+                                  ("contribution rows of one atom", rows_per_slot, 4096)):
+            if have >= limit:
+                return f"{have} {what}; the derivative kernel's tables hold fewer than {limit}"
+        return None
+
     def pp_desc(self):
         assert self.rec.is_cuda, "preprocessing layer is not on the GPU (call .to(device))"
         d = _hip.PPDesc()

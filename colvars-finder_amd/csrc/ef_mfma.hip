@@ -1848,7 +1848,7 @@ extern "C" int64_t cvf_ef_backward_slab_rows(int64_t n_tiles) { return bwd_grid(
 static int ef_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
                             int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
                             const float* y_tiled, const float* q_tiled, const double* coef, float* slab,
-                            int32_t* step_count, const float* saved, void* stream) {
+                            int32_t* step_count, float* saved, void* stream) {
   CVF_REQUIRE(cfg && mlp && theta && packed && w && feat_tiled && y_tiled && coef && slab && B > 0,
               "cvf_ef_backward: bad argument");
   CVF_REQUIRE(cfg->lag_idx > 0 || q_tiled, "cvf_ef_backward: generator mode needs q");
@@ -1901,7 +1901,7 @@ static int ef_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, cons
   const bool launched = ef_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
     if (kH <= kFusedMaxH && saved != nullptr && wide && cfg->lag_idx == 0 && getenv("CVF_NO_T0") == nullptr) {
-      float* t0 = const_cast<float*>(saved) + a.n_tiles * cfg->k * (int64_t)(kNH * saved_per_vec<kH>());   // (behind the activations)
+      float* t0 = saved + a.n_tiles * cfg->k * (int64_t)(kNH * saved_per_vec<kH>());   // (behind the activations)
       (void)hipFuncSetAttribute((const void*)ef_t0_kernel<kH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes<kH>());
       hipLaunchKernelGGL((ef_t0_kernel<kH>), dim3((unsigned)a.T, cfg->k), dim3(64 * kWW), wide_lds_bytes<kH>(), (hipStream_t)stream,
                          *mlp, packed, q_tiled, t0);
@@ -1921,7 +1921,7 @@ static int ef_backward_impl(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, cons
 extern "C" int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed,
                                int64_t B, const float* w, const float* w_lag, const float* feat_tiled,
                                const float* y_tiled, const float* q_tiled, const double* coef, float* slab,
-                               int32_t* step_count, const float* saved, void* stream) {
+                               int32_t* step_count, float* saved, void* stream) {
   return ef_backward_impl(cfg, mlp, theta, packed, B, w, w_lag, feat_tiled, y_tiled, q_tiled, coef, slab, step_count, saved,
                           stream);
 }

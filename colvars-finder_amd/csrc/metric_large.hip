@@ -581,6 +581,10 @@ extern "C" int64_t cvf_metric_dense_doubles(const cvf_pp_desc* pp) {
 
 extern "C" int cvf_metric_dense_tensors(const cvf_pp_desc* pp, const float* a, double* dense, void* stream) {
   CVF_REQUIRE(pp && a && dense && pp->mode == CVF_PP_ALIGN && pp->align_idx && pp->ref_c, "cvf_metric_dense_tensors: bad argument");
+  // (the packed fields of the record / row tables: 16-bit slots and rows; the host validates the 8-bit row offsets and the 12-bit
+  //  per-slot row counts when it builds the tables - colvarsfinder/pp.py derivative_table_limits)
+  CVF_REQUIRE(pp->slot_row == nullptr || (pp->n_slot < 65536 && pp->n_ref < 65536 && pp->n_ref >= pp->n_slot),
+              "cvf_metric_dense_tensors: %d slots / %d contribution rows do not fit the tables' 16-bit fields", pp->n_slot, pp->n_ref);
   hipLaunchKernelGGL(metric_dense_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *pp, a, dense);
   return cvf_check_launch("metric_dense_kernel");
 }

@@ -302,9 +302,11 @@ int cvf_ef_loss(const cvf_ef_cfg* cfg, const double* stats, double* loss_vec, do
 int64_t cvf_ef_backward_slab_rows(int64_t n_tiles);
 int cvf_ef_backward(const cvf_ef_cfg* cfg, const cvf_mlp_desc* mlp, const float* theta, const float* packed, int64_t B,
                     const float* w, const float* w_lag, const float* feat_tiled, const float* y_tiled,
-                    const float* q_tiled, const double* coef, float* slab, int32_t* step_count, const float* saved,
+                    const float* q_tiled, const double* coef, float* slab, int32_t* step_count, float* saved,
                     void* stream);
-                    /* step_count (may be NULL): the optimiser's device step counter, advanced by one */
+                    /* step_count (may be NULL): the optimiser's device step counter, advanced by one.  saved: the hand-off buffer of
+                     * cvf_ef_mlp_fwd, cvf_ef_saved_floats(mlp, n_tiles) floats - NOT const: for first layers wider than 128 inputs
+                     * the call writes t0 = W0 q behind the activations (the extra vector per (tile, net) that size includes). */
 int cvf_slab_reduce(const float* slab, int64_t n_rows, int64_t n_params, float* grad, const cvf_adam_args* adam,
                     void* stream); /* adam (may be NULL): apply the update in the same launch */
 

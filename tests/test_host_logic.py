@@ -415,3 +415,18 @@ def test_row_reader_serves_rows_from_a_memory_mapped_file(tmp_path):
     for src in (x, np.load(path, mmap_mode="r"), t.trajectory):
         h = _HostFrames(src)
         assert h.shape == (1000, 7, 3) and np.array_equal(h.rows(rows), x[rows]) and np.array_equal(h.all(), x)
+
+
+def test_derivative_table_limits_are_reported_at_construction():
+    """the large-molecule derivative kernel's tables pack row offsets into 8 bits (fewer than 256 features may share one
+    atom) and slots / rows into 16 bits; a feature list past a limit is named by AlignFeatureLayer.derivative_table_limits() - which
+    EigenFunctionTask's generator mode turns into a NotImplementedError at construction - instead of a generic message at the
+    first training step."""
+    from colvarsfinder import pp
+    n_atoms = 400
+    ref = np.random.RandomState(0).normal(size=(n_atoms, 3))
+    ok = pp.AlignFeatureLayer(n_atoms, list(range(n_atoms)), ref, [("position", (0, 1, 2))] + [("bond", (3, 4 + i)) for i in range(100)])
+    assert ok.derivative_table_limits() is None
+    crowded = pp.AlignFeatureLayer(n_atoms, list(range(n_atoms)), ref, [("bond", (3, 4 + i)) for i in range(300)])
+    why = crowded.derivative_table_limits()
+    assert why is not None and "share one atom" in why and "256" in why
