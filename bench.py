@@ -555,13 +555,15 @@ def align_feature_roofline(task, ref, dev, pmc_traffic):
         ms = np.asarray([a_.elapsed_time(b_) for a_, b_ in evs])
         return float(np.mean(ms)), float(np.min(ms)), float(np.max(ms))
 
-    def case(desc, xs, n, d_r, bpf, with_aux, scratch=None, reps=30):
-        """K1 on n frames; then, same loop shape, the two plain streams over the same bytes."""
+    def case(desc, xs, n, d_r, bpf, with_aux, scratch=None, reps=30, rows=False):
+        """K1 on n frames; then, same loop shape, the two plain streams over the same bytes.  rows: the row-major output
+        [frame][d_r] (what AutoEncoderTask's one-off feature trajectory is, core.py:635) instead of the tiled one."""
         T_ = _hip.ntiles(n)
-        f_tmp = torch.empty(T_ * d_r * 64, device=dev)
+        f_tmp = torch.empty(n * d_r if rows else T_ * d_r * 64, device=dev)
         a_tmp = torch.empty(T_ * 18 * 64, device=dev) if with_aux else None
         s = _hip.stream()
-        k1 = lambda: _hip.check(lib.cvf_align_feature_fwd(desc, P(xs), n, P(f_tmp), None, P(a_tmp), P(scratch), s), "k1")   # noqa: E731
+        k1 = lambda: _hip.check(lib.cvf_align_feature_fwd(desc, P(xs), n, None if rows else P(f_tmp), P(f_tmp) if rows else None,   # noqa: E731
+                                                          P(a_tmp), P(scratch), s), "k1")
         mean, lo, hi = timed(k1, reps, 50.0)
         total = float(bpf) * n
         row = dict(avg_launch_us=mean * 1e3, min_launch_us=lo * 1e3, max_launch_us=hi * 1e3, launches_timed=reps, preheat_ms=50,
@@ -586,6 +588,8 @@ def align_feature_roofline(task, ref, dev, pmc_traffic):
     for label, n in (("dipeptide_4M", 4_000_000), ("dipeptide_1M", 1_000_000)):
         xs, _ = device_frames(n, ref, 0.3, SEED + 77, dev)
         feat = case(task._pp, xs, n, 66, K1_BYTES, False)
+        feat_rows = case(task._pp, xs, n, 66, K1_BYTES, False, rows=True)
+        feat["row_major_output"] = {k_: feat_rows[k_] for k_ in ("avg_launch_us", "frac", "k1_over_copy")}
         gen = case(task._pp, xs, n, 66, K1_BYTES, True)
         gen["note"] = "+ rotation/centroid/K^-1 rows (72 B/frame the 532 B/frame count leaves out)"
         del xs
@@ -607,7 +611,13 @@ def align_feature_roofline(task, ref, dev, pmc_traffic):
     del os.environ["CVF_K1_XCD"]
     feat5["xcd_placement_ab_us"] = ab
     sc5 = _hip.align_scratch(d5, n5, dev)
+    abg = {}
+    for mode in ("0", "1"):
+        os.environ["CVF_K1_XCD"] = mode
+        abg["blockidx_order" if mode == "0" else "tile_on_one_xcd"] = case(d5, x5, n5, layer5.d_r, bpf5, True, scratch=sc5, reps=15)["avg_launch_us"]
+    del os.environ["CVF_K1_XCD"]
     gen5 = case(d5, x5, n5, layer5.d_r, bpf5, True, scratch=sc5)
+    gen5["xcd_placement_ab_us"] = abg
     gen5["note"] = "+ rotation/centroid rows and the slot copy the derivative kernel reads"
     del x5, sc5
     res["config5_100k"] = dict(frames_per_launch=n5, n_atoms=na5, d_r=layer5.d_r, bytes_per_frame=bpf5, footprint_MB=bpf5 * n5 / 1e6,

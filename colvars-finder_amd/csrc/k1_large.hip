@@ -518,10 +518,13 @@ size_t cvf_k1_large_scratch_bytes(const cvf_pp_desc* pp, int64_t B) {
 int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float* feat_tiled, float* feat_rows,
                         float* aux_tiled, float* slot_xyz, hipStream_t s) {
   const bool contig = (pp->flags & CVF_PP_ALIGN_CONTIG) != 0;
-  // the frame groups of a 64-frame tile on ONE XCD (their 32-byte pieces of the tiled rows meet in one L2) whenever a tiled output
-  // is written; CVF_K1_XCD=0/1 forces blockIdx order / that placement (developer switch: bench.py's A/B of the two)
+  // CVF_K1_XCD=1: the frame groups of a 64-frame tile on ONE XCD (their 32-byte pieces of the tiled rows meet in one L2); 0 / unset:
+  // blockIdx order (developer switch: bench.py's A/B of the two)
   const int xcd_env = getenv("CVF_K1_XCD") ? atoi(getenv("CVF_K1_XCD")) : -1;
-  const int same_xcd = xcd_env >= 0 ? (xcd_env != 0) : (feat_tiled || aux_tiled || slot_xyz ? 1 : 0);
+  // (round 4, A/B in one lease, both flavours: blockIdx order 1160 / 1351 us per 100 000 frames of 5000 atoms against 1240 / 1371 us
+  //  with the tile on one XCD on one box, equal on another - the slot copy has been one contiguous run per workgroup since round 3,
+  //  which is what the placement was for.  Default: blockIdx order.)
+  const int same_xcd = xcd_env >= 0 ? (xcd_env != 0) : 0;
   const int64_t groups = feat_tiled || aux_tiled || slot_xyz ? cvf_ntiles(B) * (CVF_TILE / kGroup) : (B + kGroup - 1) / kGroup;
   if (capture_ok(pp, feat_tiled != nullptr)) {
     const size_t ldsc = ((size_t)kGroup * pp->n_slot * 3 + (feat_tiled ? (size_t)pp->d_r * kGroup : 0)) * sizeof(float);
