@@ -128,8 +128,15 @@ static __device__ unsigned long long g_stamps[64 * 4096];
     if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4096 && (threadIdx.x >> 6) < CVF_STAMP_WPB)   \
       g_stamps[(blockIdx.x * CVF_STAMP_WPB + (threadIdx.x >> 6)) % 4096 * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+// the same with the chip-wide 100 MHz counter (s_memtime is per compute unit: not comparable between workgroups)
+#define CVF_STAMP_RT(i)                                                                           \
+  do {                                                                                            \
+    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4096 && (threadIdx.x >> 6) < CVF_STAMP_WPB)   \
+      g_stamps[(blockIdx.x * CVF_STAMP_WPB + (threadIdx.x >> 6)) % 4096 * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define CVF_STAMP(i) do {} while (0)
+#define CVF_STAMP_RT(i) do {} while (0)
 #endif
 
 // ------------------------------------------------------------------------------------

@@ -20,13 +20,13 @@
 
 namespace {
 template <int H, int NH, int NIT, bool ALLAL>
-__global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
+__global__ __launch_bounds__(1024, 4) void ef16_front_kernel(cvf_mlp_desc mlp, const float* __restrict__ theta,
                                                              const float* __restrict__ packed, cvf_pp_desc pp,
                                                              const float* __restrict__ x, int64_t B,
                                                              const float* __restrict__ a, const float* __restrict__ w,
                                                              float* __restrict__ feat_tiled, float* __restrict__ y_tiled,
                                                              float* __restrict__ saved, float* __restrict__ q_tiled,
-                                                             float* __restrict__ e_tiled, double* __restrict__ partial, int ns,
+                                                             float* __restrict__ e_tiled, double* __restrict__ partial, int launch,
                                                              const float* __restrict__ x_lag, int64_t units_x,
                                                              const float* __restrict__ w_lag) {
   constexpr int RT = Hid<H>::RT, NG = Hid<H>::NG, SMAX = 18, CTMAX = 5;
@@ -35,24 +35,38 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
   // registers, so that the 2 x units of the frames and their lagged partners are resident in ONE round (the generator instance
   // held them in two: 5 blocks per CU by registers and LDS)
   constexpr bool kTransfer = NIT == 0;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane_in = tid & 63, nthreads = blockDim.x, nw = nthreads >> 6;
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  // `launch` = units per workgroup | paired << 8.  Several units per workgroup (a developer switch, off by default - measured
+  // slower, see ef16_units_per_wg): a workgroup of upb k waves takes upb consecutive units, each on its own k waves and its own
+  // copy of the LDS layout, exactly as upb workgroups of one unit would - the units only share the workgroup's barriers.
+  const int upb = launch & 0xff;
+  const int k = mlp.n_nets, D = mlp.dims[0];
   // (the wave number through an SGPR: derived from threadIdx.x alone the compiler treats it - and every address formed
   //  with it, i.e. all of this net's weights and images - as lane-varying, in VGPR pairs)
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int net = wave, k = mlp.n_nets, D = mlp.dims[0];
+  const int wave_b = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int usub = upb > 1 ? wave_b / k : 0;                 // this wave's unit within the workgroup (wave-uniform)
+  const int wave = wave_b - usub * k;
+  const int tid = (int)threadIdx.x - usub * (64 * k), lane_in = tid & 63;
+  const int nthreads = upb > 1 ? 64 * k : (int)blockDim.x, nw = nthreads >> 6;
+  const int net = wave;
+  const int64_t ublock = (int64_t)blockIdx.x * upb + usub;   // what blockIdx.x is with one unit per workgroup
   // transfer-operator mode (x_lag != NULL), two launch forms:
-  //   PAIRED (gridDim.x == units_x): the block runs unit u of the frames and then, with the same waves, unit u of their lagged
+  //   PAIRED (launch bit 8): the block runs unit u of the frames and then, with the same waves, unit u of their lagged
   //     partners, so that y and y' of the same 16 frame indices meet in one
   //     block and wave 0 can form the unit's row of the TIME-LAGGED batch sums (sum w (y' - y)^2 pairs a frame with its
   //     partner); cvf_ef16_finish then adds the rows as in generator mode (was: cvf_ef_stats, two launches, 15 us).  The
   //     launch is one round of units_x blocks doing two units each instead of two rounds of 2 units_x blocks.
-  //   unpaired (gridDim.x == 2 units_x): the units of x, then the units of the lagged frames, one per block.
+  //   unpaired: the units of x, then the units of the lagged frames, one per block.
   // In both the lagged frames' tiles follow the tiles of x in every tiled output, and a pass stops after y and the hand-off.
-  const bool paired = kTransfer && x_lag != nullptr && (int64_t)gridDim.x == units_x;   // (uniform)
+  const bool paired = kTransfer && x_lag != nullptr && (launch >> 8) != 0;   // (uniform)
   const int nc = pp.n_coord, nal = pp.n_align, N = pp.n_rec;
   const int stride = x_tile_stride(nc);
-  const Front16Lds Lo = front16_lds(nc, nal, k);   // (the transfer instance is launched with Lo.g + 16 floats: no g images)
+  const Front16Lds Lo = front16_lds(nc, nal, k);   // (the transfer instance is launched with Lo.g + 16 floats per unit: no g images)
+  float* lds = lds_all + usub * (kTransfer ? Lo.g + 16 : Lo.total);
+  // units past the last one (the last workgroup of a launch whose unit count is not a multiple of upb) repeat the last unit: the
+  // same values into the same places, and every wave meets the workgroup's barriers
+  const int64_t n_ublock = (kTransfer && !paired) ? 2 * units_x : units_x;
+  const int64_t ub = ublock < n_ublock ? ublock : n_ublock - 1;
   const float* const x_first = x;
   const float* const w_first = w;
   // one unit from its coordinates to y (transfer instance) / to the unit's row of batch sums (generator instances).  A lambda so that
@@ -76,8 +90,8 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     }
     load_hid_const_u<H>(urows(theta + mlp.b_off[net][0], H, q_), bias[0]);
   };
-  const bool lagged = x_lag != nullptr && (paired ? pass == 1 : (int64_t)blockIdx.x >= units_x);   // (uniform)
-  const int64_t unit = (lagged && !paired) ? (int64_t)blockIdx.x - units_x : (int64_t)blockIdx.x;   // unit within its frame set
+  const bool lagged = x_lag != nullptr && (paired ? pass == 1 : ub >= units_x);   // (wave-uniform)
+  const int64_t unit = (lagged && !paired) ? ub - units_x : ub;   // unit within its frame set
   const int64_t tile = (unit >> 2) + (lagged ? (units_x >> 2) : 0);
   const int sub = (int)(unit & 3);
   x = lagged ? x_lag : x_first;
@@ -532,7 +546,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     }
     // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 r
     const int cj = lane & 15;
-    const int64_t G = gridDim.x;
+    const int64_t G = units_x;   // rows of the launch = its units
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ri = (lane >> 4) + 4 * r;
@@ -556,7 +570,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
     run_pass(1);                                 // the same waves, the lagged partners of these 16 frames
     if (partial == nullptr) return;              // (uniform)
     const int lane = lane_in;
-    const int64_t unit = blockIdx.x;
+    const int64_t unit = ub;
     lds_barrier();                               // y and y' of every net are in LDS
     // ---- wave 0: this unit's row of the time-lagged batch sums [W | S1 | S2(i<=j) | W' | S1' | S2'_ii | T] (cvf_ef_nstats, lag > 0)
     // in fp64 on the matrix cores, the 16 frames as the contraction index: D1 = [1, y] x [w, w y] holds W, S1_j, S2_ij;
@@ -585,7 +599,7 @@ __global__ __launch_bounds__(512, 4) void ef16_front_kernel(cvf_mlp_desc mlp, co
         d3 = __builtin_amdgcn_mfma_f64_16x16x4f64(df, wb * df, d3, 0, 0, 0);
       }
       const int cj = lane & 15, o = 1 + k + np;
-      const int64_t G = gridDim.x;
+      const int64_t G = units_x;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ri = (lane >> 4) + 4 * r;
@@ -610,6 +624,27 @@ int cvf_ef_stats_finish_impl(const cvf_ef_cfg* cfg, int n_rows, int stat_major, 
                              double* loss_vec, double* coef, hipStream_t s);
 int cvf_ef_stats_finish_ll(const cvf_ef_cfg* cfg, int n_rows, int stat_major, const double* partial, double* stats,
                            double* loss_vec, double* coef, hipStream_t s, const P2PLL* ll);
+
+// Units per workgroup of a front launch (see the kernel).  ONE by default.  Several (CVF_EF16_UPB = 2..5, a developer switch, results
+// bit for bit those of one: tools/upb_check.py) were built on the observation that the 1250 one-unit workgroups of a 20 000-frame
+// batch reach their first stamp over 4.4 us - and measured SLOWER: 37.2 us per launch with five units per workgroup against 34.6
+// (two or three: 47-49 us, a second round under the 16-waves-per-CU limit).  tools/dispatch_probe.hip settled why: starting 1250
+// workgroups of 3 waves costs the same as 250 of 15 (2.5-2.8 us per empty launch, identical with work inside), so the spread of
+// the first stamps is the cold instruction cache and kernel-argument fetch, which every wave pays wherever it sits; what the
+// large workgroup adds is five units waiting at each other's barriers (two of the five alignment solves share a SIMD).
+static int ef16_units_per_wg(int64_t units, int k, size_t lds_unit_bytes) {
+  int cap = 16 / k;
+  if (cap > 5) cap = 5;
+  while (cap > 1 && (size_t)cap * lds_unit_bytes > 150 * 1024) --cap;
+  if (cap < 1) cap = 1;
+  int upb = 1;
+  (void)units;
+  if (const char* e = getenv("CVF_EF16_UPB")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= cap) upb = v;
+  }
+  return upb;
+}
 
 extern "C" int cvf_ef16_supported(const cvf_mlp_desc* mlp, const cvf_pp_desc* pp) {
   int H, NH;
@@ -674,13 +709,17 @@ extern "C" int cvf_ef16_front(const cvf_mlp_desc* mlp, const float* theta, const
   const int64_t T = cvf_ntiles(B), units = 4 * T;
   const int ns = cvf_ef_nstats(k, 0);
   const bool rows = units <= kMaxRows16;
-  const size_t lds = (size_t)front16_lds(pp->n_coord, pp->n_align, k).total * sizeof(float);
+  const size_t lds1 = (size_t)front16_lds(pp->n_coord, pp->n_align, k).total * sizeof(float);
+  const int upb = ef16_units_per_wg(units, k, lds1);
+  const size_t lds = lds1 * upb;
+  (void)ns;
   ef16_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
     auto go = [&](auto kernel) {
       if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(64 * k), lds, (hipStream_t)stream, *mlp, theta, packed, *pp, x, B, a, w,
-                         feat_tiled, y_tiled, saved, q_tiled, e_tiled, rows ? scratch : nullptr, ns, (const float*)nullptr, units, (const float*)nullptr);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)((units + upb - 1) / upb)), dim3(64 * k * upb), lds, (hipStream_t)stream, *mlp, theta, packed, *pp,
+                         x, B, a, w, feat_tiled, y_tiled, saved, q_tiled, e_tiled, rows ? scratch : nullptr, upb, (const float*)nullptr, units,
+                         (const float*)nullptr);
     };
     const int nit = (pp->n_rec + 3) / 4;   // atoms per lane in the four-lanes-per-frame passes (1..6: d_r <= 72)
     const bool allal = pp->n_align == pp->n_rec;
@@ -726,14 +765,16 @@ static int ef16_front_transfer_impl(const cvf_mlp_desc* mlp, const float* theta,
   // a unit and its lagged partner in one block, one after the other (CVF_EF16_UNPAIRED=1: one unit per block, the two sets one after the
   // other in the grid - the launch of rounds 2-3, kept as a developer switch)
   const bool paired = rows_out != nullptr || getenv("CVF_EF16_UNPAIRED") == nullptr;
-  const size_t lds = ((size_t)front16_lds(pp->n_coord, pp->n_align, k).g + 16) * sizeof(float);   // (no g images in this instance; + the partners' weights)
+  const size_t lds1 = ((size_t)front16_lds(pp->n_coord, pp->n_align, k).g + 16) * sizeof(float);   // (no g images in this instance; + the partners' weights)
+  const int upb = paired ? ef16_units_per_wg(units, k, lds1) : 1;
+  const size_t lds = lds1 * upb;
   ef16_dispatch(H, NH, [&](auto h_, auto nh_) {
     constexpr int kH = decltype(h_)::value, kNH = decltype(nh_)::value;
     auto kernel = ef16_front_kernel<kH, kNH, 0, true>;   // NIT = 0: the transfer-operator instance
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(paired ? units : 2 * units)), dim3(64 * k), lds, (hipStream_t)stream, *mlp,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(paired ? (units + upb - 1) / upb : 2 * units)), dim3(64 * k * upb), lds, (hipStream_t)stream, *mlp,
                        theta, packed, *pp, x, B, (const float*)nullptr, w, feat_tiled, y_tiled, saved, (float*)nullptr, (float*)nullptr,
-                       rows_out, 0, x_lag, units, w_lag);
+                       rows_out, upb | (paired ? 256 : 0), x_lag, units, w_lag);
   });
   return cvf_check_launch("ef16_front_kernel");
 }

@@ -12,6 +12,29 @@
 #include <random>
 #include <vector>
 
+
+// launch-level view from (start, end) stamps of many blocks: s_memtime has a different base on every XCD, so the blocks are grouped
+// by base (values within 1e8 cycles of each other) and the figures are per group: span = last end - first start, the blocks'
+// start times after the group's first, their own durations
+static void launch_view(const char* what, std::vector<std::pair<unsigned long long, unsigned long long>> se) {
+  std::sort(se.begin(), se.end());
+  size_t i = 0;
+  int g = 0;
+  double span_sum = 0, start_avg = 0, start_max = 0, dur = 0;
+  size_t n = 0;
+  while (i < se.size()) {
+    size_t j = i;
+    unsigned long long last_end = 0;
+    while (j < se.size() && se[j].first - se[i].first < 100000000ull) { last_end = std::max(last_end, se[j].second); ++j; }
+    span_sum += double(last_end - se[i].first);
+    for (size_t t = i; t < j; ++t) { start_avg += double(se[t].first - se[i].first); start_max = std::max(start_max, double(se[t].first - se[i].first)); dur += double(se[t].second - se[t].first); ++n; }
+    ++g;
+    i = j;
+  }
+  printf("== %s: %zu blocks, %d clock domain(s) | span first start -> last end %.2f us | block start after the first: avg %.2f max %.2f us | block duration avg %.2f us (100 MHz chip-wide counter)\n",
+         what, n, g, span_sum / g / 100.0, start_avg / n / 100.0, start_max / 100.0, dur / n / 100.0);
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 int main(int argc, char** argv) {
@@ -106,6 +129,15 @@ int main(int argc, char** argv) {
     cvf_ef16_front(&m, dth, dpk, dfeat, &pp, dx, B, da, dy, dsaved, dq, de, &cfg, dw, dscr, dstats, dlv, dcoef, nullptr);
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
+    {
+      std::vector<std::pair<unsigned long long, unsigned long long>> se;
+      for (int u = 0; u < 4 * (int)cvf_ntiles(B) && u * CVF_STAMP_WPB < 4096; ++u) {
+        const unsigned long long* s_ = &st[(size_t)(u * CVF_STAMP_WPB) * 64];
+        if (s_[40] && s_[41]) se.push_back({s_[40], s_[41]});
+      }
+      char nm[64]; snprintf(nm, sizeof nm, "front B=%d", B);
+      launch_view(nm, se);
+    }
     const char* fn[10] = {"stage", "kabsch(w0)+barrier", "weights req + features + barrier", "layer 0", "hidden + y + hand-off", "d chain + g", "pass 1", "pass 2", "pass 3", "stats row"};
     const int units = 4 * (int)cvf_ntiles(B);
     for (int wv = 0; wv < (CVF_STAMP_WPB < 2 ? CVF_STAMP_WPB : 2); ++wv) {
@@ -140,6 +172,17 @@ int main(int argc, char** argv) {
     cvf_ef16_backward(&cfg, &m, dth, dpk, B, dw, dfeat, dy, dq, dcoef, dslab, nullptr, dsaved, nullptr);
     CK(hipDeviceSynchronize());
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
+    {
+      std::vector<std::pair<unsigned long long, unsigned long long>> se;
+      double pro = 0;
+      for (int t = 0; t < (int)cvf_ntiles(B) && t * CVF_STAMP_WPB < 4096; ++t) {
+        const unsigned long long* s_ = &st[(size_t)(t * CVF_STAMP_WPB) * 64];
+        if (s_[40] && s_[41]) { se.push_back({s_[40], s_[41]}); pro += double(s_[8] - s_[7]); }
+      }
+      char nm[64]; snprintf(nm, sizeof nm, "back B=%d (net 0)", B);
+      launch_view(nm, se);
+      printf("   prologue (kernel entry -> tile loop) avg %.0f cycles\n", pro / se.size());
+    }
     const char* bn[9] = {"requests + alpha", "-", "tangent chain", "last layer", "reverse l=2", "reverse l=1", "reverse l=0", "flush", "-"};
     const int tiles = (int)cvf_ntiles(B);
     for (int wv = 0; wv < CVF_STAMP_WPB; wv += 3) {
