@@ -52,10 +52,16 @@ __global__ __launch_bounds__(256, 4) void ef16_back_kernel(Back16Args args, cvf_
   const int gspan = mlp.b_off[net][NH] + 1 - gbase;
   float* out = slab + (int64_t)blockIdx.x * mlp.n_params + gbase;   // this block's slab row, this net's span
 
-  for (int i = tid; i < kRows * kPitch; i += NT) IMG[i] = 0.0f;
+  {   // (16-byte LDS writes: kRows * kPitch is a multiple of 4)
+    static_assert((kRows * kPitch) % 4 == 0, "IMG is zeroed in 16-byte pieces");
+    float4* img4 = reinterpret_cast<float4*>(IMG);
+    for (int i = tid; i < kRows * kPitch / 4; i += NT) img4[i] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
   if (MULTI)
     for (int i = tid; i < gspan; i += NT) GI[i] = 0.0f;
-  __syncthreads();
+  // (LDS only: __syncthreads() would also wait for the coefficient / last-layer loads requested above - a whole global round trip
+  //  at the head of every block before the tile's own requests go out; stamped prologue 4.4 k cycles)
+  lds_barrier();
   if (tid < 64) SB1[H * kPitch + tid] = 1.0f;  // bias column of [h ; 1]  (row H of SB2 stays 0)
 
   const PackLayout L = pack_layout(H, NH, D);
