@@ -591,7 +591,7 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
 // Measurement aid (bench.py roofline_align_feature): what plain streaming reaches on THIS box at THIS moment, timed in the same
 // loop as the alignment kernel so that box-to-box and minute-to-minute spread can be told from a change of the kernel.
 //   mode 0: dst[i] = src[i], one float4 per thread (1:1 read/write traffic: the dipeptide shape's mix)
-//   mode 1: read-only sweep, every thread adds 8 float4 of a contiguous 128-byte run, one float per workgroup written
+//   mode 1: read-only sweep, a workgroup adds a contiguous 32 KB run (eight 16-byte loads per thread in flight), one float written
 //           (the large-molecule shape: 60 KB read, 1.5 KB written per frame)
 namespace {
 __global__ __launch_bounds__(256) void probe_copy_kernel(float4* __restrict__ dst, const float4* __restrict__ src, int64_t n4) {
@@ -599,10 +599,10 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(float4* __restrict__ ds
   if (i < n4) dst[i] = src[i];
 }
 __global__ __launch_bounds__(256) void probe_read_kernel(float* __restrict__ dst, const float4* __restrict__ src, int64_t n4) {
-  const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  const int64_t base = (int64_t)blockIdx.x * 2048 + threadIdx.x;   // the block's 32 KB run, 4 KB (one piece per lane) per load
   float4 v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = src[base + j < n4 ? base + j : n4 - 1];
+  for (int j = 0; j < 8; ++j) v[j] = src[base + 256 * j < n4 ? base + 256 * j : n4 - 1];
   float acc = 0.0f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc += (v[j].x + v[j].y) + (v[j].z + v[j].w);

@@ -39,7 +39,7 @@ f = mean_counter(f"gpurun_out/{TAG}/pmc_fetch/bench_counter_collection.csv", "FE
 w = mean_counter(f"gpurun_out/{TAG}/pmc_write/bench_counter_collection.csv", "WRITE_SIZE")
 out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-extras; mean per launch, KiB",
        "_correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts 128-B read requests as 64 B for 16-B-per-lane streaming loads (MI355X_MICROARCH.md, HBM); other access widths are uncalibrated, Infinity-Cache hits are included",
-       "kernels": {k: {"FETCH_SIZE_KiB": f[k], "WRITE_SIZE_KiB": w.get(k, 0.0)} for k in f if not k.startswith("at::") and not k.startswith("__amd")}}
+       "kernels": {k: {"FETCH_SIZE_KiB": f[k], "WRITE_SIZE_KiB": w.get(k, 0.0)} for k in f if not k.startswith("at::") and not k.startswith("__amd") and not k.startswith("Cijk")}}
 # the align+feature kernel alone at the config-5 shape (tools/bench_k1_c5.py 20000: two launch flavours per pass - features only,
 # then with the generator-mode extras)
 try:
