@@ -3,7 +3,7 @@ fixtures the reference produced.
 
 Tolerances.  Everything on this path is floating point.  north_star asks for per-step loss and learned-CV outputs within
 1e-5 relative of the reference's CPU path.  The bars below are about THREE TIMES the errors actually achieved, as recorded by
-tools/parity_errors.py in profiles/r3_parity_errors.json (a regression of an order of magnitude must turn
+tools/parity_errors.py in profiles/r4_parity_errors.json (round 3's figures, unchanged in round 4) (a regression of an order of magnitude must turn
 the suite red, not sit inside a 50x margin):
 
   quantity (worst over the fixtures)              achieved vs the fp64 run    bar      achieved vs the fp32 run      bar
@@ -15,6 +15,10 @@ the suite red, not sit inside a 50x margin):
   final parameters, |d| / (|p| + 1)                1.4e-6                      1e-5     4.4e-5 (idem)                 1.5e-4
   learned CVs / largest |CV|                       4.4e-6                      1e-5     1.7e-5 (= the reference's     5e-5
                                                                                          own fp32 vs fp64 distance)
+  bench-sized fixtures (round 4: 100 000 frames, batches of 20 000 - config 3, its transfer-mode twin, config 2), same bars:
+  loss of one call 2.5e-8, gradient 3.6e-7, every step's loss 6.5e-8, rows 2.9e-7, parameters 2.9e-7, CVs 2.1e-6 vs the fp64 run
+  (profiles/r4_parity_errors.json "bench_size"); config-5 shape at 2 000 / 16 000 frames vs the chunked fp64 oracle: loss 1.0e-7,
+  eigenvalues 9.0e-7, gradient 1.9e-6 of its largest entry ("config5_bench_batches"; bars C5_BATCH_TOL)
 The fp32 fixtures carry the reference's own fp32 rounding (its fp32 and fp64 runs differ by exactly these amounts), which no
 implementation can undercut; against the exact (fp64) answer every figure is inside the north star's 1e-5.
 """
@@ -713,7 +717,7 @@ def _config5_task(dev, traj, w, ref):
     return task, model, spec, sd0, a, eig_w
 
 
-C5_BATCH_TOL = dict(loss=2e-6, eig=5e-6, grad=2e-5)   # achieved: profiles/r4_parity_errors.json ("config5_bench_batches")
+C5_BATCH_TOL = dict(loss=5e-7, eig=3e-6, grad=6e-6)   # ~3x the achieved 1.0e-7 / 9.0e-7 / 1.9e-6: profiles/r4_parity_errors.json ("config5_bench_batches")
 
 
 def config5_bench_batch_errors(dev, B):
