@@ -610,6 +610,16 @@ def align_feature_roofline(task, ref, dev, pmc_traffic):
         ab["blockidx_order" if mode == "0" else "tile_on_one_xcd"] = case(d5, x5, n5, layer5.d_r, bpf5, False, reps=15)["avg_launch_us"]
     del os.environ["CVF_K1_XCD"]
     feat5["xcd_placement_ab_us"] = ab
+    rows5 = case(d5, x5, n5, layer5.d_r, bpf5, False, rows=True)
+    feat5["row_major_output"] = {k_: rows5[k_] for k_ in ("avg_launch_us", "frac", "k1_over_copy")}
+    # where the launch's time goes (developer probes of csrc/k1_large.hip, results discarded): the streaming loop alone, and the launch
+    # without its feature stores - the tail behind the loop (eight 3x3 solves per workgroup, features, stores) is what varies by box
+    parts = {}
+    for mode, label in (("2", "streaming_loop_only_us"), ("4", "without_feature_stores_us")):
+        os.environ["CVF_K1_XCD"] = mode
+        parts[label] = case(d5, x5, n5, layer5.d_r, bpf5, False, reps=15)["avg_launch_us"]
+    del os.environ["CVF_K1_XCD"]
+    feat5["launch_decomposition"] = parts
     sc5 = _hip.align_scratch(d5, n5, dev)
     abg = {}
     for mode in ("0", "1"):

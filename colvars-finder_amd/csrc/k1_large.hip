@@ -84,7 +84,13 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_gather_kernel(cvf_pp_des
     H[1][0] = t[6] - c1 * t[12]; H[1][1] = t[7] - c1 * t[13]; H[1][2] = t[8] - c1 * t[14];
     H[2][0] = t[9] - c2 * t[12]; H[2][1] = t[10] - c2 * t[13]; H[2][2] = t[11] - c2 * t[14];
     KabschOut ko;
-    kabsch_from_H(H, ko);
+    if (aux_tiled != nullptr) {   // (uniform) rotation + K^-1 for the derivative kernel
+      kabsch_from_H<true>(H, ko);
+    } else {                      // features only: the rotation alone, one Newton step less (as k1_stream_kernel)
+      kabsch_from_H<false>(H, ko);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ko.Kinv[i] = 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < 9; ++i) bc[tid][i] = ko.R[i];
     bc[tid][9] = (float)c0; bc[tid][10] = (float)c1; bc[tid][11] = (float)c2;
@@ -194,7 +200,13 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
     H[1][0] = t[6] - c1 * t[12]; H[1][1] = t[7] - c1 * t[13]; H[1][2] = t[8] - c1 * t[14];
     H[2][0] = t[9] - c2 * t[12]; H[2][1] = t[10] - c2 * t[13]; H[2][2] = t[11] - c2 * t[14];
     KabschOut ko;
-    kabsch_from_H(H, ko);
+    if (aux_tiled != nullptr) {   // (uniform) rotation + K^-1 for the derivative kernel
+      kabsch_from_H<true>(H, ko);
+    } else {                      // features only: the rotation alone, one Newton step less (as k1_stream_kernel)
+      kabsch_from_H<false>(H, ko);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ko.Kinv[i] = 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < 9; ++i) bc[tid][i] = ko.R[i];
     bc[tid][9] = (float)c0; bc[tid][10] = (float)c1; bc[tid][11] = (float)c2;
@@ -227,9 +239,15 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = bc[fi][i];
   const double cc0 = cD[fi][0], cc1 = cD[fi][1], cc2 = cD[fi][2];
-  float* fr = (feat_rows && real) ? feat_rows + frame * pp.d_r : nullptr;
+  // staged == 1: the features go through LDS as [feature][frame] for the tiled output (rows, if also wanted, straight from the lanes);
+  // staged == 2 (row-major output alone - what AutoEncoderTask's one-off feature trajectory is, core.py:635): as [frame][feature], the
+  // workgroup's eight rows then leave as ONE contiguous run in 16-byte stores (round 4: this flavour used to fall to the gather
+  // kernel - 1473 us per 100 000 frames of 5000 atoms against 1060)
+  const int staged = feat_tiled != nullptr ? 1 : (featL != nullptr && feat_rows != nullptr ? 2 : 0);
+  float* fr = (feat_rows && real && staged != 2) ? feat_rows + frame * pp.d_r : nullptr;
   auto emit = [&](int o, float v) {
-    if (feat_tiled) featL[o * kGroup + fi] = v;
+    if (staged == 1) featL[o * kGroup + fi] = v;
+    else if (staged == 2) featL[fi * pp.d_r + o] = v;
     if (fr) fr[o] = v;
   };
   auto satom = [&](int sl) { return V3{capL[3 * sl], capL[3 * sl + 1], capL[3 * sl + 2]}; };
@@ -266,11 +284,23 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
     feature(Rec{p[0], p[1], p[2], p[3], p[4], p[5]});
   }
   CVF_STAMP(7);
-  if (feat_tiled != nullptr) {
+  if (staged == 1) {
     __syncthreads();
     for (int idx = tid; idx < pp.d_r * kGroup; idx += 64 * kGroup) {
       const int o = idx / kGroup, f = idx % kGroup;
       feat_tiled[(tile * pp.d_r + o) * CVF_TILE + l0 + f] = featL[idx];
+    }
+  } else if (staged == 2) {
+    __syncthreads();
+    const int64_t nreal = B - f0 < kGroup ? B - f0 : kGroup;     // frames of this workgroup inside the batch
+    float* dst = feat_rows + f0 * pp.d_r;
+    const int total = (int)nreal * pp.d_r;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (total & 3) == 0) {
+      const float4* s4 = reinterpret_cast<const float4*>(featL);
+      float4* d4 = reinterpret_cast<float4*>(dst);
+      for (int i = tid; i < total / 4; i += 64 * kGroup) d4[i] = s4[i];
+    } else {
+      for (int i = tid; i < total; i += 64 * kGroup) dst[i] = featL[i];
     }
   }
   CVF_STAMP(8);
@@ -306,7 +336,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
   const int nc = pp.n_coord, nal = pp.n_align, nslot = pp.n_slot, N = nc / 3;
   float* capL = dyn + (size_t)fi * nslot * 3;
   float* featL = dyn + (size_t)kGroup * nslot * 3;
-  const int64_t f0 = k1_group_of_block(same_xcd != 0) * kGroup;
+  const int64_t f0 = k1_group_of_block((same_xcd & 1) != 0) * kGroup;
   const bool real = f0 + fi < B;
   const int64_t frame = real ? f0 + fi : B - 1;
   const float* __restrict__ xf = x + frame * nc;
@@ -361,7 +391,8 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
     if (lane < 15) sums[fi][lane] = mine;
   }
   __syncthreads();
-  large_solve_features(pp, B, f0, tid, lane, fi, real, frame, sums, bc, cD, capL, featL, feat_tiled, feat_rows, aux_tiled,
+  const bool staging = feat_tiled != nullptr || feat_rows != nullptr;   // (the launch reserves the staging area for either output)
+  large_solve_features(pp, B, f0, tid, lane, fi, real, frame, sums, bc, cD, capL, staging ? featL : nullptr, feat_tiled, feat_rows, aux_tiled,
                        slot_xyz);
 }
 
@@ -393,7 +424,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc
   const int nq = N >> 2, nqa = nal >> 2;
   float* featL = dyn + (size_t)kGroup * nslot * 3;
   float* red = featL + w * (4 * kRedPitch);       // wave-private, reused by the feature staging later
-  const int64_t f0 = k1_group_of_block(same_xcd != 0) * kGroup;
+  const int64_t f0 = k1_group_of_block((same_xcd & 1) != 0) * kGroup;
   CVF_STAMP(0);
   // ---- this lane's atoms: reference rows, capture slots (registers for the whole batch)
   const float4* __restrict__ r4 = reinterpret_cast<const float4*>(pp.ref_c);
@@ -479,6 +510,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc
     }
   }
   CVF_STAMP(2);
+  if (same_xcd & 2) return;   // developer probe (CVF_K1_XCD=2 / 3): the streaming loop alone - wrong results, its time is the point
   __syncthreads();
   CVF_STAMP(3);
   if (tid < kGroup * 15) {   // sums[frame][value] over the eight waves, fixed order
@@ -498,8 +530,8 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc
   const bool real = f0 + fi < B;
   const int64_t frame = real ? f0 + fi : B - 1;
   const float* capL = dyn + (size_t)fi * nslot * 3;
-  large_solve_features(pp, B, f0, tid, lane, fi, real, frame, sums, bc, cD, capL, featL, feat_tiled, feat_rows, aux_tiled,
-                       slot_xyz);
+  large_solve_features(pp, B, f0, tid, lane, fi, real, frame, sums, bc, cD, capL, featL, (same_xcd & 4) ? nullptr : feat_tiled, feat_rows, aux_tiled,
+                       slot_xyz);   // (same_xcd & 4: developer probe - the launch without its tiled feature stores)
 }
 
 }  // namespace
@@ -524,10 +556,11 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
   // (round 4, A/B in one lease, both flavours: blockIdx order 1160 / 1351 us per 100 000 frames of 5000 atoms against 1240 / 1371 us
   //  with the tile on one XCD on one box, equal on another - the slot copy has been one contiguous run per workgroup since round 3,
   //  which is what the placement was for.  Default: blockIdx order.)
-  const int same_xcd = xcd_env >= 0 ? (xcd_env != 0) : 0;
+  const int same_xcd = xcd_env >= 0 ? xcd_env : 0;
   const int64_t groups = feat_tiled || aux_tiled || slot_xyz ? cvf_ntiles(B) * (CVF_TILE / kGroup) : (B + kGroup - 1) / kGroup;
-  if (capture_ok(pp, feat_tiled != nullptr)) {
-    const size_t ldsc = ((size_t)kGroup * pp->n_slot * 3 + (feat_tiled ? (size_t)pp->d_r * kGroup : 0)) * sizeof(float);
+  const bool staged = feat_tiled != nullptr || feat_rows != nullptr;   // features leave through an LDS staging area
+  if (capture_ok(pp, staged)) {
+    const size_t ldsc = ((size_t)kGroup * pp->n_slot * 3 + (staged ? (size_t)pp->d_r * kGroup : 0)) * sizeof(float);
     {
       const int N = pp->n_coord / 3;
       const bool vec4 = contig && (N % 4 == 0) && (pp->n_align % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
@@ -538,7 +571,7 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
       }
       const int ni = (N / 4 + 64 * kGroup - 1) / (64 * kGroup);
       // (the slice kernel stages its reductions in the feature staging area: needs the tiled output's buffer)
-      const bool slice = vec4 && ni <= 4 && feat_tiled != nullptr && (size_t)pp->d_r * kGroup >= (size_t)kGroup * 4 * 68 &&
+      const bool slice = vec4 && ni <= 4 && staged && (size_t)pp->d_r * kGroup >= (size_t)kGroup * 4 * 68 &&
                          getenv("CVF_K1_NOSLICE") == nullptr;
       if (slice) {
         auto go = [&](auto kernel) {
