@@ -175,7 +175,7 @@ __device__ __forceinline__ void acc_atom(Acc15& A, float x0, float x1, float x2,
 // problems (one per lane of one wave) from sums[frame][0..14] = {sum x (3), sum x (x) ref (9), sum ref (3)}, then
 // per frame (wave fi) aux, the compact feature-atom copy, the features from the captured atoms, and the flush.
 __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int64_t B, int64_t f0, int tid, int lane, int fi,
-                                                     bool real, int64_t frame, const double (*sums)[16],
+                                                     bool /*real*/, int64_t /*frame*/, const double (*sums)[16],
                                                      float (*bc)[CVF_AUX_ROWS + 2], double (*cD)[3], const float* capL,
                                                      float* featL, float* __restrict__ feat_tiled,
                                                      float* __restrict__ feat_rows, float* __restrict__ aux_tiled,
@@ -191,6 +191,41 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
     const int32_t* p = pp.rec_slot + 6 * (r < nrs ? r : nrs - 1);
     pre[it] = Rec{p[0], p[1], p[2], p[3], p[4], p[5]};
   }
+  // ---- staging of the features (decided here: the invariant features below are emitted before the solve is known)
+  // staged == 1: the features go through LDS as [feature][frame] for the tiled output (rows, if also wanted, straight from the lanes);
+  // staged == 2 (row-major output alone - what AutoEncoderTask's one-off feature trajectory is, core.py:635): as [frame][feature], the
+  // workgroup's eight rows then leave as ONE contiguous run in 16-byte stores (round 4: this flavour used to fall to the gather
+  // kernel - 1473 us per 100 000 frames of 5000 atoms against 1060)
+  const int staged = feat_tiled != nullptr ? 1 : (featL != nullptr && feat_rows != nullptr ? 2 : 0);
+  const float* capBase = capL - (size_t)fi * nslot * 3;      // [kGroup][nslot * 3]: every frame's captured atoms
+  // features of frame `fs` of the group (fs = fi: this wave's own; fs = 0: a share of wave 0's, see below)
+  auto emit_to = [&](int fs, int o, float v) {
+    if (staged == 1) featL[o * kGroup + fs] = v;
+    else if (staged == 2) featL[fs * pp.d_r + o] = v;
+    if (staged != 2 && feat_rows != nullptr && f0 + fs < B) feat_rows[(f0 + fs) * pp.d_r + o] = v;
+  };
+  // bonds, angles and dihedrals do not see the alignment: they are evaluated WHILE wave 0 solves the group's eight 3x3 problems
+  // (round 4; stamped tail of a workgroup: barrier 2.5 k | solve 6.1 k | features 5.6 k | flush 1.6 k cycles behind 41 k of streaming
+  // - solve and features now run side by side).  Wave 0's own frame is shared out: wave w takes its record batches it = w - 1 (mod 7).
+  auto invariant = [&](const Rec& rc, int fs) {
+    if (rc.type < 0 || rc.type == CVF_FEAT_POSITION) return;
+    const float* cp = capBase + (size_t)fs * nslot * 3;
+    auto sat = [&](int sl) { return V3{cp[3 * sl], cp[3 * sl + 1], cp[3 * sl + 2]}; };
+    if (rc.type == CVF_FEAT_BOND) {
+      emit_to(fs, rc.out, bond_eval(sat(rc.a0), sat(rc.a1)).val);
+    } else if (rc.type == CVF_FEAT_ANGLE) {
+      const float cs = angle_eval(sat(rc.a0), sat(rc.a1), sat(rc.a2)).cs;
+      emit_to(fs, rc.out, pp.use_angle_value ? acosf(cs) : cs);
+    } else {
+      const DihedralG dg = dihedral_eval(sat(rc.a0), sat(rc.a1), sat(rc.a2), sat(rc.a3));
+      if (pp.use_angle_value) {
+        emit_to(fs, rc.out, atan2f(dg.sn, dg.cs));
+      } else {
+        emit_to(fs, rc.out, dg.cs);
+        emit_to(fs, rc.out + 1, dg.sn);
+      }
+    }
+  };
   if (tid < kGroup) {  // the group's 3x3 problems, one per lane of one wave
     const double* t = sums[tid];
     const double inv = fast_rcp((double)nal);
@@ -213,21 +248,40 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
 #pragma unroll
     for (int i = 0; i < 6; ++i) bc[tid][12 + i] = ko.Kinv[i];
     cD[tid][0] = c0; cD[tid][1] = c1; cD[tid][2] = c2;
-  } else if (slot_xyz != nullptr && tid >= 64) {
-    // meanwhile the other waves write the compact copy of the feature atoms for the derivative kernel (metric_large.hip), which
-    // works with one frame per lane: coordinate rows of this workgroup's kGroup frames, [frame group][n_slot * 3][kGroup] - one
-    // contiguous run per workgroup, written in 16-byte pieces.  (As rows of the 64-frame tile - 32 bytes per row and workgroup -
-    // the partial lines of eight workgroups cost 1406-1733 us per 100 000 frames against 1231-1321 us.)
-    static_assert(kGroup == 8, "two 16-byte pieces per row");
-    typedef float nt4 __attribute__((ext_vector_type(4)));
-    const float* img = capL - (size_t)fi * nslot * 3;      // [kGroup][nslot * 3]
-    const int ns3 = nslot * 3;
-    nt4* dst = reinterpret_cast<nt4*>(slot_xyz + (f0 / kGroup) * (int64_t)ns3 * kGroup);
-    for (int i = tid - 64; i < 2 * ns3; i += 64 * (kGroup - 1)) {
-      const int row = i >> 1, fr = 4 * (i & 1);
-      const nt4 v = {img[fr * ns3 + row], img[(fr + 1) * ns3 + row], img[(fr + 2) * ns3 + row], img[(fr + 3) * ns3 + row]};
-      __builtin_nontemporal_store(v, dst + i);   // written once, read by a later kernel
+  } else if (tid >= 64) {
+    if (slot_xyz != nullptr) {
+      // meanwhile the other waves write the compact copy of the feature atoms for the derivative kernel (metric_large.hip), which
+      // works with one frame per lane: coordinate rows of this workgroup's kGroup frames, [frame group][n_slot * 3][kGroup] - one
+      // contiguous run per workgroup, written in 16-byte pieces.  (As rows of the 64-frame tile - 32 bytes per row and workgroup -
+      // the partial lines of eight workgroups cost 1406-1733 us per 100 000 frames against 1231-1321 us.)
+      static_assert(kGroup == 8, "two 16-byte pieces per row");
+      typedef float nt4 __attribute__((ext_vector_type(4)));
+      const float* img = capL - (size_t)fi * nslot * 3;      // [kGroup][nslot * 3]
+      const int ns3 = nslot * 3;
+      nt4* dst = reinterpret_cast<nt4*>(slot_xyz + (f0 / kGroup) * (int64_t)ns3 * kGroup);
+      for (int i = tid - 64; i < 2 * ns3; i += 64 * (kGroup - 1)) {
+        const int row = i >> 1, fr = 4 * (i & 1);
+        const nt4 v = {img[fr * ns3 + row], img[(fr + 1) * ns3 + row], img[(fr + 2) * ns3 + row], img[(fr + 3) * ns3 + row]};
+        __builtin_nontemporal_store(v, dst + i);   // written once, read by a later kernel
+      }
+
     }
+    // this wave's frame, then its share of wave 0's frame
+#pragma unroll
+    for (int it = 0; it < kRecPre; ++it)
+      if (lane + 64 * it < nrs) invariant(pre[it], fi);
+    for (int r = lane + 64 * kRecPre; r < nrs; r += 64) {
+      const int32_t* p = pp.rec_slot + 6 * r;
+      invariant(Rec{p[0], p[1], p[2], p[3], p[4], p[5]}, fi);
+    }
+#pragma unroll
+    for (int it = 0; it < kRecPre; ++it)
+      if (it % (kGroup - 1) == fi - 1 && lane + 64 * it < nrs) invariant(pre[it], 0);
+    for (int it = kRecPre; 64 * it < nrs; ++it)
+      if (it % (kGroup - 1) == fi - 1 && lane + 64 * it < nrs) {
+        const int32_t* p = pp.rec_slot + 6 * (lane + 64 * it);
+        invariant(Rec{p[0], p[1], p[2], p[3], p[4], p[5]}, 0);
+      }
   }
   __syncthreads();
   CVF_STAMP(5);
@@ -239,56 +293,30 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = bc[fi][i];
   const double cc0 = cD[fi][0], cc1 = cD[fi][1], cc2 = cD[fi][2];
-  // staged == 1: the features go through LDS as [feature][frame] for the tiled output (rows, if also wanted, straight from the lanes);
-  // staged == 2 (row-major output alone - what AutoEncoderTask's one-off feature trajectory is, core.py:635): as [frame][feature], the
-  // workgroup's eight rows then leave as ONE contiguous run in 16-byte stores (round 4: this flavour used to fall to the gather
-  // kernel - 1473 us per 100 000 frames of 5000 atoms against 1060)
-  const int staged = feat_tiled != nullptr ? 1 : (featL != nullptr && feat_rows != nullptr ? 2 : 0);
-  float* fr = (feat_rows && real && staged != 2) ? feat_rows + frame * pp.d_r : nullptr;
-  auto emit = [&](int o, float v) {
-    if (staged == 1) featL[o * kGroup + fi] = v;
-    else if (staged == 2) featL[fi * pp.d_r + o] = v;
-    if (fr) fr[o] = v;
+  // ---- the position features (the only ones that need the rotation), every wave its own frame
+  auto position = [&](const Rec& rc) {
+    if (rc.type != CVF_FEAT_POSITION) return;
+    const V3 xa = V3{capL[3 * rc.a0], capL[3 * rc.a0 + 1], capL[3 * rc.a0 + 2]};
+    const V3 xc = v3((float)((double)xa.x - cc0), (float)((double)xa.y - cc1), (float)((double)xa.z - cc2));
+    const V3 al = row_times(xc, R);
+    emit_to(fi, rc.out, al.x);
+    emit_to(fi, rc.out + 1, al.y);
+    emit_to(fi, rc.out + 2, al.z);
   };
-  auto satom = [&](int sl) { return V3{capL[3 * sl], capL[3 * sl + 1], capL[3 * sl + 2]}; };
-  auto feature = [&](const Rec& rc) {
-    if (rc.type < 0) return;   // padding
-    if (rc.type == CVF_FEAT_POSITION) {
-      const V3 xa = satom(rc.a0);
-      const V3 xc = v3((float)((double)xa.x - cc0), (float)((double)xa.y - cc1), (float)((double)xa.z - cc2));
-      const V3 al = row_times(xc, R);
-      emit(rc.out, al.x);
-      emit(rc.out + 1, al.y);
-      emit(rc.out + 2, al.z);
-    } else if (rc.type == CVF_FEAT_BOND) {
-      emit(rc.out, bond_eval(satom(rc.a0), satom(rc.a1)).val);
-    } else if (rc.type == CVF_FEAT_ANGLE) {
-      const float cs = angle_eval(satom(rc.a0), satom(rc.a1), satom(rc.a2)).cs;
-      emit(rc.out, pp.use_angle_value ? acosf(cs) : cs);
-    } else {
-      const DihedralG dg = dihedral_eval(satom(rc.a0), satom(rc.a1), satom(rc.a2), satom(rc.a3));
-      if (pp.use_angle_value) {
-        emit(rc.out, atan2f(dg.sn, dg.cs));
-      } else {
-        emit(rc.out, dg.cs);
-        emit(rc.out + 1, dg.sn);
-      }
-    }
-  };
-  // the first kRecPre records of each lane were fetched before the solve (their round trip to L2 is hidden there)
 #pragma unroll
   for (int it = 0; it < kRecPre; ++it)
-    if (lane + 64 * it < nrs) feature(pre[it]);
+    if (lane + 64 * it < nrs) position(pre[it]);
   for (int r = lane + 64 * kRecPre; r < nrs; r += 64) {
     const int32_t* p = pp.rec_slot + 6 * r;   // like rec, atom fields hold slots
-    feature(Rec{p[0], p[1], p[2], p[3], p[4], p[5]});
+    const Rec rc{p[0], p[1], p[2], p[3], p[4], p[5]};
+    position(rc);
   }
   CVF_STAMP(7);
   if (staged == 1) {
     __syncthreads();
     for (int idx = tid; idx < pp.d_r * kGroup; idx += 64 * kGroup) {
       const int o = idx / kGroup, f = idx % kGroup;
-      feat_tiled[(tile * pp.d_r + o) * CVF_TILE + l0 + f] = featL[idx];
+      feat_tiled[(tile * pp.d_r + o) * CVF_TILE + l0 + f] = featL[idx];   // (non-temporal stores here: no difference, 1217 vs 1217 us)
     }
   } else if (staged == 2) {
     __syncthreads();
