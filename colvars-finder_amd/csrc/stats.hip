@@ -165,7 +165,7 @@ __global__ __launch_bounds__(1024) void ef_stats_finish_kernel(cvf_ef_cfg cfg, i
     }
   };
   if (ns <= nw) pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 24>{});
-  else if (ns <= 2 * nw) pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 12>{});   // (the 20 time-lagged sums at k = 3: two round trips, not four)
+  else if (ns <= 2 * nw) pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 20>{});   // (the 20 time-lagged sums at k = 3: 40 loads in flight per lane - the 1250 unit rows of a 20 000-frame batch in ONE round trip, not four)
   else pass(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
   if (ll.world > 0) {   // data-parallel step: the sum over ranks of the local sums, inside this launch (cvf_p2p.hpp)
     p2p_ll_allreduce_stats(ll, fin, ns, parts, ex);
