@@ -5,7 +5,7 @@ import numpy as np, torch
 import bench
 from colvarsfinder import core, nn, pp
 from tests.synth import Traj, diag_coeff_for
-epochs=2000
+epochs=int(os.environ.get('EPOCHS','2001'))
 dev=torch.device("cuda:0")
 x,w,ref=bench.make_shard(100_000,0)
 a=torch.tensor(diag_coeff_for(bench.N_ATOMS,bench.SEED),dtype=torch.float32)
@@ -24,4 +24,6 @@ core._AsyncEpochLog.push=push
 with tempfile.TemporaryDirectory() as tmp:
     task=core.EigenFunctionTask(Traj(x,w,1.0),layer,model,tmp,bench.ALPHA,bench.EIG_W,diag_coeff=a,beta=bench.BETA,lag_tau=0,learning_rate=bench.LR,k=bench.K_NETS,batch_size=20000,num_epochs=epochs,test_ratio=0.2,device=dev,verbose=False,save_model_every_step=0)
     torch.cuda.synchronize(); t0=time.perf_counter(); task.train(); torch.cuda.synchronize(); wall=time.perf_counter()-t0
-print(json.dumps(dict(wall_us_per_epoch=wall/epochs*1e6, graph_call_us=T["graph"]/T["n"]*1e6, push_us=T["push"]/epochs*1e6)))
+import hashlib
+h=hashlib.sha1(b"".join(np.ascontiguousarray(torch.cat([e[0],e[1]]).double().numpy()).tobytes() for e in task.loss_list)).hexdigest()
+print(json.dumps(dict(n_loss_rows=len(task.loss_list),loss_sha1=h,wall_us_per_epoch=wall/epochs*1e6, graph_call_us=T["graph"]/T["n"]*1e6, push_us=T["push"]/epochs*1e6)))
