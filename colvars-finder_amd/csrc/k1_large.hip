@@ -314,9 +314,10 @@ __device__ __forceinline__ void large_solve_features(const cvf_pp_desc& pp, int6
   CVF_STAMP(7);
   if (staged == 1) {
     __syncthreads();
-    for (int idx = tid; idx < pp.d_r * kGroup; idx += 64 * kGroup) {
-      const int o = idx / kGroup, f = idx % kGroup;
-      feat_tiled[(tile * pp.d_r + o) * CVF_TILE + l0 + f] = featL[idx];   // (non-temporal stores here: no difference, 1217 vs 1217 us)
+    static_assert(kGroup == 8, "a row's piece of this group: two 16-byte stores");
+    for (int idx = tid; idx < pp.d_r * 2; idx += 64 * kGroup) {   // (non-temporal stores here: no difference, 1217 vs 1217 us)
+      const int o = idx >> 1, h = 4 * (idx & 1);
+      *reinterpret_cast<float4*>(feat_tiled + (tile * pp.d_r + o) * CVF_TILE + l0 + h) = *reinterpret_cast<const float4*>(featL + o * kGroup + h);
     }
   } else if (staged == 2) {
     __syncthreads();
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
                                                                        float* __restrict__ feat_rows,
                                                                        float* __restrict__ aux_tiled,
                                                                        float* __restrict__ slot_xyz, int same_xcd) {
-  extern __shared__ float dyn[];                  // [kGroup][n_slot][3] captured atoms, then [d_r][kGroup] features
+  extern __shared__ __attribute__((aligned(16))) float dyn[];                  // [kGroup][n_slot][3] captured atoms, then [d_r][kGroup] features
   __shared__ float bc[kGroup][CVF_AUX_ROWS + 2];
   __shared__ double cD[kGroup][3];
   __shared__ double sums[kGroup][16];
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc
                                                                      float* __restrict__ feat_rows,
                                                                      float* __restrict__ aux_tiled,
                                                                      float* __restrict__ slot_xyz, int same_xcd) {
-  extern __shared__ float dyn[];                  // [kGroup][n_slot][3] captured atoms | [d_r][kGroup] features (first: reduction scratch)
+  extern __shared__ __attribute__((aligned(16))) float dyn[];                  // [kGroup][n_slot][3] captured atoms | [d_r][kGroup] features (first: reduction scratch)
   __shared__ float bc[kGroup][CVF_AUX_ROWS + 2];
   __shared__ double cD[kGroup][3];
   __shared__ double sums[kGroup][16];
@@ -562,6 +563,431 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc
                        slot_xyz);   // (same_xcd & 4: developer probe - the launch without its tiled feature stores)
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Pipelined variant of the slice kernel (round 4; large batches).  In the slice kernel a workgroup streams its eight frames and
+// then spends a fifth of its life in the tail (sums -> 3x3 solves -> features -> flush) with no load in flight; two workgroups per
+// CU overlap that only by chance, and the streaming loop alone (CVF_K1_XCD=2) runs at the read sweep's rate while the whole kernel
+// is 10-15 % below it.  Here ONE workgroup per CU stays for the whole launch and is split by role:
+//   waves 0..7   stream: exactly the slice kernel's loop (same atoms per lane, same partial sums, same order: bit-identical sums),
+//                but over group after group, and with the NEXT frame's loads requested before the current frame's arithmetic
+//                (one workgroup per CU leaves 168 registers per lane: room for the second set of 36) - also across the group
+//                boundary, so the memory pipe never drains;
+//   waves 8..11  tail: after the barrier that ends group n they turn it into its outputs, two frames per wave (sums, solve on two
+//                lanes, all feature records, aux rows, a quarter of the slot copy), meet at an LDS counter and flush the staged
+//                features together - while the streaming waves are already capturing group n + 1 into the other LDS buffer.
+// The roles meet at counters in LDS (in the kernel).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kStream = 8, kTail = 4;
+// developer aid (tools/k1_large_probe.hip, -DCVF_STAMPS): cycles a wave spends between two marks, summed over its groups
+#ifdef CVF_STAMPS
+#define PIPE_T(i)                                                            \
+  do {                                                                       \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+    acc_[i] += now_ - last_;                                                 \
+    last_ = now_;                                                            \
+  } while (0)
+#define PIPE_T_OUT()                                                                                                   \
+  do {                                                                                                                 \
+    if (lane == 0)                                                                                                     \
+      for (int i_ = 0; i_ < 9; ++i_) g_stamps[((blockIdx.x * (kStream + kTail) + w) % 4096) * 64 + i_] = acc_[i_];     \
+  } while (0)
+#else
+#define PIPE_T(i) do {} while (0)
+#define PIPE_T_OUT() do {} while (0)
+#endif
+static_assert(kStream == kGroup && kGroup == 2 * kTail, "slice mapping: eight streaming waves; two frames per tail wave");
+constexpr int kRedPitchP = 68;
+
+template <int NI>
+__global__ __launch_bounds__(64 * (kStream + kTail)) void k1_large_pipe_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
+                                                                              int64_t nquads, float* __restrict__ feat_tiled,
+                                                                              float* __restrict__ feat_rows,
+                                                                              float* __restrict__ aux_tiled,
+                                                                              float* __restrict__ slot_xyz, int probe) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];   // [2][kGroup][n_slot * 3] captured atoms | [d_r * kGroup] feature staging | [kStream][4 * 68] reduction scratch | [n_rec_slot][6] record table
+  __shared__ float bc[kGroup][CVF_AUX_ROWS + 2];
+  __shared__ double cD[kGroup][3];
+  __shared__ double sums[kGroup][16];
+  __shared__ double part[2][kGroup][kStream][12];   // [buffer][frame][streaming wave][value]
+  __shared__ double rpart[kStream][3];
+  __shared__ int ctr[5];   // LDS counters the roles meet at (below)
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nc = pp.n_coord, nal = pp.n_align, nslot = pp.n_slot, N = nc / 3;
+  const int nq = N >> 2, nqa = nal >> 2;
+  const int cap_floats = kGroup * nslot * 3;
+  float* featL = dyn + 2 * (size_t)cap_floats;
+  // a workgroup takes QUADS of four consecutive frame groups (half a 64-frame tile: blockIdx.x, + gridDim.x, ...) - see the flush below
+  const int nit = 4 * (int)((nquads - blockIdx.x + gridDim.x - 1) / gridDim.x);   // its groups, numbered n = 0 .. nit - 1
+  auto group_of = [&](int n) __attribute__((always_inline)) { return ((int64_t)blockIdx.x + (int64_t)(n >> 2) * gridDim.x) * 4 + (n & 3); };
+  // The roles meet at COUNTERS in LDS, not at the workgroup barrier (a barrier per group made every streaming wave wait for the slowest one
+  // with one frame of loads in flight - stamped: waves 0..3 stream a group in 33 k cycles and then waited 16 k for waves 4..7):
+  //   kDone  += 1 by a streaming wave that has captured its share of group n       -> the tail starts group n at 8 (n / 2 + 1); one counter per
+  //             parity of n: a streaming wave may be a group ahead of the slowest one, and its count must not complete the older group's
+  //   kFree  += 1 by a tail wave that is through with group n's capture buffer     -> streaming may overwrite it (group n + 2) at 4 (n + 1)
+  //   kMet   += 1 by a tail wave whose features of group n are staged              -> waves 1..3 gather them at 4 (n + 1)
+  //   kTaken += 1 by tail waves 1..3 when group n's staged features are in their registers -> the staging area is free at 3 (n + 1)
+  // (LDS operations of a wave complete in order: data written before the increment is visible to whoever has seen the count.)
+  enum { kDone = 0, kFree = 2, kMet = 3, kTaken = 4 };   // (kDone, kDone + 1: even and odd groups)
+  if (tid < 5) ctr[tid] = 0;
+  auto post = [&](int c) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&ctr[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto await = [&](int c, int target) __attribute__((always_inline)) {
+    while (__hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+  // the feature records, once per launch into LDS: while the streaming waves keep the memory pipe full a global load takes ~6 k cycles
+  // to come back, and the tail waves' record reads (one dependent round trip per 64 records) made THEM the slower role (stamped: features
+  // 47 k cycles per group next to 32 k of streaming)
+  const int nrs = pp.n_rec_slot > 0 ? pp.n_rec_slot : pp.n_rec;
+  int32_t* recL = reinterpret_cast<int32_t*>(featL + (size_t)pp.d_r * kGroup + kStream * (4 * kRedPitchP));
+  for (int i = tid; i < 6 * nrs; i += 64 * (kStream + kTail)) recL[i] = pp.rec_slot[i];
+  __syncthreads();   // (the only barrier)
+#ifdef CVF_STAMPS
+  unsigned long long last_ = __builtin_amdgcn_s_memtime(), acc_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  typedef float nt4 __attribute__((ext_vector_type(4)));
+  if (w < kStream) {
+    // ================================================= streaming waves
+    float* red = featL + (size_t)pp.d_r * kGroup + w * (4 * kRedPitchP);
+    const float4* __restrict__ r4 = reinterpret_cast<const float4*>(pp.ref_c);
+    const int4* __restrict__ s4 = reinterpret_cast<const int4*>(pp.atom_slot);
+    float4 rp[NI], rq[NI], rr[NI];
+    uint2 sl[NI];
+    int vo[NI];        // byte offset of the lane's group of four atoms inside a frame (past the frame for lanes without one: such loads return 0 and fetch nothing)
+    float mk[NI];
+    float rs0 = 0.0f, rs1 = 0.0f, rs2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int g = (i * kStream + w) * 64 + lane;
+      const bool valid = g < nq, al = g < nqa;
+      vo[i] = valid ? g * 48 : nc * 4;
+      const int ga = al ? g : 0;
+      const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+      const float4 p = r4[3 * ga], q = r4[3 * ga + 1], r = r4[3 * ga + 2];
+      rp[i] = al ? p : z;
+      rq[i] = al ? q : z;
+      rr[i] = al ? r : z;
+      mk[i] = al ? 1.0f : 0.0f;
+      const int4 sv = s4[valid ? g : nq - 1];
+      // 3 x slot = the atom's place in a frame's capture image, 0xffff: not a feature atom; two atoms to a register (the loop below is at
+      // the register limit: unpacked, the twelve values were spilled - and a spill's reload waits for every load in flight)
+      auto place = [&](int sv_) { return valid && sv_ >= 0 ? (unsigned)(3 * sv_) : 0xffffu; };
+      sl[i] = uint2{place(sv.x) | (place(sv.y) << 16), place(sv.z) | (place(sv.w) << 16)};
+      rs0 += rp[i].x + rp[i].w + rq[i].z + rr[i].y;
+      rs1 += rp[i].y + rq[i].x + rq[i].w + rr[i].z;
+      rs2 += rp[i].z + rq[i].y + rr[i].x + rr[i].w;
+    }
+    {
+      const double t0 = wave_sum((double)rs0), t1 = wave_sum((double)rs1), t2 = wave_sum((double)rs2);
+      if (lane == 0) { rpart[w][0] = t0; rpart[w][1] = t1; rpart[w][2] = t2; }
+    }
+    // frame number t of this workgroup (8 per group) -> a buffer descriptor of its coordinates (scalar registers; the lane's offset is one
+    // 32-bit register per group of atoms); past the end: the last frame again (harmless, cached)
+    auto frame_of = [&](int t) __attribute__((always_inline)) {
+      int n = t >> 3;
+      n = n < nit ? n : nit - 1;
+      int64_t f = group_of(n) * kGroup + (t & 7);
+      f = f < B ? f : B - 1;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + f * nc), 0, nc * 4, 0x00020000);
+    };
+    auto ld16 = [&](__amdgpu_buffer_rsrc_t r, int voff, int imm) __attribute__((always_inline)) {
+      return __builtin_bit_cast(nt4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, imm, 0));
+    };
+    auto request = [&](nt4 (&a)[NI], nt4 (&b)[NI], nt4 (&c)[NI], __amdgpu_buffer_rsrc_t r) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        a[i] = ld16(r, vo[i], 0);
+        b[i] = ld16(r, vo[i], 16);
+        c[i] = ld16(r, vo[i], 32);
+      }
+    };
+    // one frame: its sums and captures
+    auto step = [&](nt4 (&a)[NI], nt4 (&b)[NI], nt4 (&c)[NI], int capoff, double* pw) __attribute__((always_inline)) {
+      capoff = __builtin_amdgcn_readfirstlane(capoff);
+      asm volatile("" : "+s"(capoff));   // (keeps `image + slot` sums out of the loop preheader: 24 hoisted addresses spilled, and a spill's reload waits for every load in flight)
+      float* capL = dyn + capoff;
+      float s[12];
+#pragma unroll
+      for (int v = 0; v < 12; ++v) s[v] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        auto atom4 = [&](float x0, float x1, float x2, float r0, float r1, float r2) {
+          s[0] = fmaf(mk[i], x0, s[0]); s[1] = fmaf(mk[i], x1, s[1]); s[2] = fmaf(mk[i], x2, s[2]);
+          s[3] = fmaf(x0, r0, s[3]); s[4] = fmaf(x0, r1, s[4]); s[5] = fmaf(x0, r2, s[5]);
+          s[6] = fmaf(x1, r0, s[6]); s[7] = fmaf(x1, r1, s[7]); s[8] = fmaf(x1, r2, s[8]);
+          s[9] = fmaf(x2, r0, s[9]); s[10] = fmaf(x2, r1, s[10]); s[11] = fmaf(x2, r2, s[11]);
+        };
+        atom4(a[i].x, a[i].y, a[i].z, rp[i].x, rp[i].y, rp[i].z);
+        atom4(a[i].w, b[i].x, b[i].y, rp[i].w, rq[i].x, rq[i].y);
+        atom4(b[i].z, b[i].w, c[i].x, rq[i].z, rq[i].w, rr[i].x);
+        atom4(c[i].y, c[i].z, c[i].w, rr[i].y, rr[i].z, rr[i].w);
+        {
+          unsigned p0 = sl[i].x, p1 = sl[i].y;
+          asm volatile("" : "+v"(p0), "+v"(p1));   // (unpacked at the use: not in the loop preheader)
+          const unsigned sx = p0 & 0xffffu, sy = p0 >> 16, sz = p1 & 0xffffu, sw = p1 >> 16;
+          if (sx != 0xffffu) { capL[sx] = a[i].x; capL[sx + 1] = a[i].y; capL[sx + 2] = a[i].z; }
+          if (sy != 0xffffu) { capL[sy] = a[i].w; capL[sy + 1] = b[i].x; capL[sy + 2] = b[i].y; }
+          if (sz != 0xffffu) { capL[sz] = b[i].z; capL[sz + 1] = b[i].w; capL[sz + 2] = c[i].x; }
+          if (sw != 0xffffu) { capL[sw] = c[i].y; capL[sw + 1] = c[i].z; capL[sw + 2] = c[i].w; }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[v * kRedPitchP + lane] = s[4 * r + v];
+        const float4 t = *reinterpret_cast<const float4*>(red + (lane >> 4) * kRedPitchP + 4 * (lane & 15));
+        double d = ((double)t.x + (double)t.y) + ((double)t.z + (double)t.w);
+        d += dpp_movd<0x111, 0xf>(d);
+        d += dpp_movd<0x112, 0xf>(d);
+        d += dpp_movd<0x114, 0xf>(d);
+        d += dpp_movd<0x118, 0xf>(d);
+        if ((lane & 15) == 15) pw[4 * r + (lane >> 4)] = d;
+      }
+    };
+    nt4 a0[NI], b0[NI], c0[NI], a1[NI], b1[NI], c1[NI];
+    request(a0, b0, c0, frame_of(0));
+    __builtin_amdgcn_sched_barrier(0);
+    // (the buffer of group n as integers that flip between 0 and the buffer's size: written as `n & 1` the compiler carried a lane mask through
+    //  the loop and rebuilt the offsets from it in vector registers - which it then spilled.  Requesting a lane's group of atoms again the moment
+    //  it is used up - instead of a whole frame at a time - was tried: the register allocator answers with a second copy of the buffer and a
+    //  wait for every load at the loop header.)
+    int capG = 0, partG = 0;
+    double* part0 = &part[0][0][0][0];
+#pragma unroll 1
+    for (int n = 0; n < nit; ++n) {
+      if (n >= 2) await(kFree, kTail * (n - 1));   // (group n - 2 used this capture buffer; the next frame's loads stay in flight meanwhile)
+      PIPE_T(2);
+#pragma unroll 1
+      for (int j = 0; j < kGroup; j += 2) {
+        request(a1, b1, c1, frame_of(8 * n + j + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        step(a0, b0, c0, capG + j * nslot * 3, part0 + partG + (j * kStream + w) * 12);
+        __builtin_amdgcn_sched_barrier(0);
+        request(a0, b0, c0, frame_of(8 * n + j + 2));   // (j + 2 == 8: the next group's first frame)
+        __builtin_amdgcn_sched_barrier(0);
+        step(a1, b1, c1, capG + (j + 1) * nslot * 3, part0 + partG + ((j + 1) * kStream + w) * 12);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      post(kDone + (n & 1));
+      PIPE_T(1);
+      capG = cap_floats - capG;
+      partG = kGroup * kStream * 12 - partG;
+    }
+    PIPE_T_OUT();
+    return;
+  }
+  // =================================================== tail waves
+  // Tail wave 0 solves the group's eight 3x3 problems (one per lane) and evaluates the features that need the rotation (positions); tail waves
+  // 1..3 evaluate the others (bonds, angles, dihedrals do not see the alignment), write the slot copy, and hold the quad's features in registers:
+  //
+  // THE FLUSH.  Written group by group the staged features are 32-byte pieces of the tiled rows (or 12 KB runs of the row-major output)
+  // trickling into a pure read stream, and that costs far more than their 2.5 % of the bytes: 1222 us per 100 000 frames of 5000 atoms with
+  // the pieces, 969 us without any store, 1005 us when the same stores stay in L2 - and 1050 us when the same bytes leave as whole 128-byte
+  // lines once per four groups (developer probes of this kernel, one lease).  So the features of four consecutive groups = 32 frames = one
+  // 128-byte line per feature row wait in REGISTERS of tail waves 1..3 (a lane: kHold 16-byte items; item (row o, piece p) is filled when group
+  // p / 2 of the quad is staged) and are stored after the fourth group, eight lanes to a line.  (Held by all four tail waves next to the solve's
+  // fp64 state they were spilled: 189 registers.)
+  const int tw = w - kStream;
+  const int staged = feat_tiled != nullptr ? 1 : 2;   // (the launch takes this kernel only with a staged output; 2: row-major alone)
+  const int ns3 = nslot * 3;
+  const int nb = (nrs + 63) >> 6;                     // batches of 64 records
+  // one feature record of frame j of the group
+  auto feature = [&](const float* capG, int64_t f0, int j, int r, bool positions) __attribute__((always_inline)) {
+    const int32_t* p = recL + 6 * r;   // like rec, atom fields hold slots
+    const Rec rc{p[0], p[1], p[2], p[3], p[4], p[5]};
+    if (rc.type < 0 || (rc.type == CVF_FEAT_POSITION) != positions) return;   // (type < 0: padding entries of batched lists)
+    const float* cp = capG + (size_t)j * ns3;
+    auto sat = [&](int s_) { return V3{cp[3 * s_], cp[3 * s_ + 1], cp[3 * s_ + 2]}; };
+    auto emit = [&](int o, float v) {
+      if (staged == 1) featL[o * kGroup + j] = v;
+      else featL[j * pp.d_r + o] = v;
+      if (staged == 1 && feat_rows != nullptr && f0 + j < B) feat_rows[(f0 + j) * pp.d_r + o] = v;
+    };
+    if (rc.type == CVF_FEAT_POSITION) {
+      const V3 xa = sat(rc.a0);
+      const V3 xc = v3((float)((double)xa.x - cD[j][0]), (float)((double)xa.y - cD[j][1]), (float)((double)xa.z - cD[j][2]));
+      float R[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) R[q] = bc[j][q];
+      const V3 al = row_times(xc, R);
+      emit(rc.out, al.x);
+      emit(rc.out + 1, al.y);
+      emit(rc.out + 2, al.z);
+    } else if (rc.type == CVF_FEAT_BOND) {
+      emit(rc.out, bond_eval(sat(rc.a0), sat(rc.a1)).val);
+    } else if (rc.type == CVF_FEAT_ANGLE) {
+      const float cs = angle_eval(sat(rc.a0), sat(rc.a1), sat(rc.a2)).cs;
+      emit(rc.out, pp.use_angle_value ? acosf(cs) : cs);
+    } else {
+      const DihedralG dg = dihedral_eval(sat(rc.a0), sat(rc.a1), sat(rc.a2), sat(rc.a3));
+      if (pp.use_angle_value) {
+        emit(rc.out, atan2f(dg.sn, dg.cs));
+      } else {
+        emit(rc.out, dg.cs);
+        emit(rc.out + 1, dg.sn);
+      }
+    }
+  };
+  if (tw == 0) {
+    // ------------------------------------------------- tail wave 0: sums, solve, aux rows, position features
+#pragma unroll 1
+    for (int n = 0; n < nit; ++n) {
+      PIPE_T(8);
+      await(kDone + (n & 1), kStream * ((n >> 1) + 1));
+      PIPE_T(1);
+      if (probe & 1) {   // developer probe (CVF_K1_PIPE_PROBE=1): the streaming waves alone - wrong results, the time is the point
+        post(kFree);
+        continue;
+      }
+      const int64_t f0 = group_of(n) * kGroup;
+      const float* capG = dyn + (size_t)(n & 1) * cap_floats;
+      for (int i = lane; i < kGroup * 15; i += 64) {   // sums[frame][value] over the eight streaming waves, fixed order
+        const int j = i / 15, v = i - 15 * j;
+        double t = 0.0;
+        if (v < 12) {
+#pragma unroll
+          for (int ww = 0; ww < kStream; ++ww) t += part[n & 1][j][ww][v];
+        } else {
+#pragma unroll
+          for (int ww = 0; ww < kStream; ++ww) t += rpart[ww][v - 12];
+        }
+        sums[j][v] = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PIPE_T(2);
+      if (lane < kGroup) {
+        const int j = lane;
+        const double* t = sums[j];
+        const double inv = fast_rcp((double)nal);
+        const double c0 = t[0] * inv, c1 = t[1] * inv, c2 = t[2] * inv;
+        double H[3][3];
+        H[0][0] = t[3] - c0 * t[12]; H[0][1] = t[4] - c0 * t[13]; H[0][2] = t[5] - c0 * t[14];
+        H[1][0] = t[6] - c1 * t[12]; H[1][1] = t[7] - c1 * t[13]; H[1][2] = t[8] - c1 * t[14];
+        H[2][0] = t[9] - c2 * t[12]; H[2][1] = t[10] - c2 * t[13]; H[2][2] = t[11] - c2 * t[14];
+        KabschOut ko;
+        if (aux_tiled != nullptr) {
+          kabsch_from_H<true>(H, ko);
+        } else {
+          kabsch_from_H<false>(H, ko);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) ko.Kinv[i] = 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) bc[j][i] = ko.R[i];
+        bc[j][9] = (float)c0; bc[j][10] = (float)c1; bc[j][11] = (float)c2;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bc[j][12 + i] = ko.Kinv[i];
+        cD[j][0] = c0; cD[j][1] = c1; cD[j][2] = c2;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PIPE_T(3);
+      if (aux_tiled != nullptr) {
+        const int64_t tile = f0 / CVF_TILE;
+        const int l0 = (int)(f0 % CVF_TILE);
+        for (int i = lane; i < kGroup * CVF_AUX_ROWS; i += 64) {
+          const int row = i / kGroup, j = i - row * kGroup;
+          aux_tiled[(tile * CVF_AUX_ROWS + row) * CVF_TILE + l0 + j] = bc[j][row];
+        }
+      }
+      if (n >= 1) await(kTaken, (kTail - 1) * n);   // the staging area still held group n - 1
+      for (int m = 0; m < kGroup * nb; ++m) {
+        const int j = m / nb, r = (m - j * nb) * 64 + lane;
+        if (r < nrs) feature(capG, f0, j, r, true);
+      }
+      PIPE_T(4);
+      post(kFree);
+      post(kMet);
+    }
+    PIPE_T_OUT();
+    return;
+  }
+  // --------------------------------------------------- tail waves 1..3
+  constexpr int kHold = 16;   // x 192 lanes x 16 bytes = 32 frames x 384 features (the launch checks d_r)
+  float4 hold[kHold];
+  const int hl = (tw - 1) * 64 + lane;   // this lane among the 192 that hold
+#pragma unroll
+  for (int k = 0; k < kHold; ++k) hold[k] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+  const int d8 = pp.d_r * 8;   // items of a quad: tiled - (row o, 16-byte piece p8 of its 128-byte line); row-major - float4 i of its 4 x 8 d_r floats
+#pragma unroll 1
+  for (int n = 0; n < nit; ++n) {
+    PIPE_T(8);
+    await(kDone + (n & 1), kStream * ((n >> 1) + 1));
+    PIPE_T(1);
+    if (probe & 1) {
+      post(kFree);
+      continue;
+    }
+    const int gq = n & 3;
+    const int64_t f0 = group_of(n) * kGroup;
+    const float* capG = dyn + (size_t)(n & 1) * cap_floats;
+    if (slot_xyz != nullptr) {   // the compact copy of the feature atoms for the derivative kernel: [frame group][n_slot * 3][kGroup]
+      nt4* dst = reinterpret_cast<nt4*>(slot_xyz + (f0 / kGroup) * (int64_t)ns3 * kGroup);
+      for (int i = hl; i < 2 * ns3; i += 64 * (kTail - 1)) {
+        const int row = i >> 1, fr = 4 * (i & 1);
+        const nt4 v = {capG[fr * ns3 + row], capG[(fr + 1) * ns3 + row], capG[(fr + 2) * ns3 + row], capG[(fr + 3) * ns3 + row]};
+        __builtin_nontemporal_store(v, dst + i);
+      }
+    }
+    PIPE_T(2);
+    if (n >= 1) await(kTaken, (kTail - 1) * n);
+    for (int m = tw - 1; m < kGroup * nb; m += kTail - 1) {   // (frame, batch of 64 records) pairs dealt to the three waves
+      const int j = m / nb, r = (m - j * nb) * 64 + lane;
+      if (r < nrs) feature(capG, f0, j, r, false);
+    }
+    PIPE_T(3);
+    post(kFree);
+    post(kMet);
+    await(kMet, kTail * (n + 1));
+    PIPE_T(5);
+    if (probe & 8) {   // developer probe: no feature stores
+      post(kTaken);
+      continue;
+    }
+#pragma unroll
+    for (int k = 0; k < kHold; ++k) {
+      const int idx = hl + 192 * k;
+      const int gi = staged == 1 ? (idx & 7) >> 1 : idx / (2 * pp.d_r);   // the group of the quad that fills this item
+      if (idx < d8 && gi == gq) {
+        const int src = staged == 1 ? (idx & ~7) + 4 * (idx & 1) : 4 * (idx - gq * 2 * pp.d_r);
+        hold[k] = *reinterpret_cast<const float4*>(featL + src);
+      }
+    }
+    post(kTaken);
+    if (gq == 3) {
+      const int64_t f0q = f0 - 3 * kGroup;   // first frame of the quad: a multiple of 32
+      if (staged == 1) {
+        float* row0 = feat_tiled + (f0q / CVF_TILE) * pp.d_r * CVF_TILE + (int)(f0q % CVF_TILE);
+#pragma unroll
+        for (int k = 0; k < kHold; ++k) {
+          int idx = hl + 192 * k;
+          asm volatile("" : "+v"(idx));   // (the address is formed here: hoisted out of the group loop the sixteen 64-bit addresses were spilled)
+          if (idx < d8) *reinterpret_cast<float4*>(row0 + (idx >> 3) * CVF_TILE + 4 * (idx & 7)) = hold[k];
+        }
+      } else {
+        const int64_t base = f0q * pp.d_r, lim = B * pp.d_r;   // (the launch checked that feat_rows is 16-byte aligned)
+#pragma unroll
+        for (int k = 0; k < kHold; ++k) {
+          int idx = hl + 192 * k;
+          asm volatile("" : "+v"(idx));
+          const int64_t e = base + 4 * (int64_t)idx;
+          if (idx < d8 && e + 3 < lim) {
+            *reinterpret_cast<float4*>(feat_rows + e) = hold[k];
+          } else if (idx < d8 && e < lim) {   // the output's last, partial float4
+            feat_rows[e] = hold[k].x;
+            if (e + 1 < lim) feat_rows[e + 1] = hold[k].y;
+            if (e + 2 < lim) feat_rows[e + 2] = hold[k].z;
+          }
+        }
+      }
+    }
+    PIPE_T(6);
+  }
+  PIPE_T_OUT();
+}
+
 }  // namespace
 
 static bool capture_ok(const cvf_pp_desc* pp, bool tiled) {
@@ -601,6 +1027,25 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
       // (the slice kernel stages its reductions in the feature staging area: needs the tiled output's buffer)
       const bool slice = vec4 && ni <= 4 && staged && (size_t)pp->d_r * kGroup >= (size_t)kGroup * 4 * 68 &&
                          getenv("CVF_K1_NOSLICE") == nullptr;
+      // large batches: the pipelined kernel (one resident workgroup per CU; streaming waves + tail waves).  It needs two capture
+      // buffers in LDS and enough groups per workgroup for the overlap to matter; CVF_K1_NOPIPE=1: developer switch (A/B).
+      const int ncu = cvf_cu_count();
+      const size_t lds_pipe = (2 * (size_t)kGroup * pp->n_slot * 3 + (size_t)pp->d_r * kGroup + (size_t)kStream * 4 * kRedPitchP +
+                               6 * (size_t)(pp->n_rec_slot > 0 ? pp->n_rec_slot : pp->n_rec)) * sizeof(float);   // (+ 14.4 KB of static arrays: 160 KB in all)
+      if (vec4 && ni <= 3 && staged && groups >= 4 * (int64_t)ncu && lds_pipe <= 145 * 1024 && 3 * pp->n_slot < 0xffff && pp->d_r <= 384 &&
+          (feat_tiled != nullptr || ((uintptr_t)feat_rows & 15) == 0) && getenv("CVF_K1_NOPIPE") == nullptr) {
+        const int64_t nquads = (groups + 3) / 4;   // (tiled outputs: groups is a multiple of 8)
+        auto go = [&](auto kernel) {
+          (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe);
+          const int probe = getenv("CVF_K1_PIPE_PROBE") ? atoi(getenv("CVF_K1_PIPE_PROBE")) : 0;
+          hipLaunchKernelGGL(kernel, dim3((unsigned)(nquads < ncu ? nquads : ncu)), dim3(64 * (kStream + kTail)), lds_pipe, s, *pp, x, B, nquads,
+                             feat_tiled, feat_rows, aux_tiled, slot_xyz, probe);
+        };
+        if (ni == 1) go(k1_large_pipe_kernel<1>);
+        else if (ni == 2) go(k1_large_pipe_kernel<2>);
+        else go(k1_large_pipe_kernel<3>);
+        return cvf_check_launch("k1_large_pipe_kernel");
+      }
       if (slice) {
         auto go = [&](auto kernel) {
           if (ldsc > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);

@@ -603,6 +603,67 @@ def test_k1_streaming_kernel_vs_oracle(dev, n_atoms, B, contig):
     np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=5e-6)
 
 
+def _device_molecule_frames(n_atoms, B, seed, dev, scale=8.0, sigma=0.4):
+    """x_b = Q_b (ref + sigma xi_b) + t_b generated on the device (large batches: the host generator takes minutes)"""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ref = np.random.RandomState(seed).normal(scale=scale, size=(n_atoms, 3))
+    A = torch.randn(B, 3, 3, device=dev, generator=g, dtype=torch.float64)
+    Q, _ = torch.linalg.qr(A)
+    Q = Q * torch.sign(torch.linalg.det(Q))[:, None, None]
+    x = torch.tensor(ref, device=dev)[None] + sigma * torch.randn(B, n_atoms, 3, device=dev, generator=g, dtype=torch.float64)
+    x = torch.einsum("bij,baj->bai", Q, x) + torch.randn(B, 1, 3, device=dev, generator=g, dtype=torch.float64)
+    return x.float().contiguous(), ref
+
+
+@pytest.mark.parametrize("n_atoms,B", [(1000, 8192 + 37), (2600, 8192 + 64), (5000, 8192 + 5)])
+def test_k1_pipelined_kernel_equals_the_slice_kernel_and_the_oracle(dev, n_atoms, B, monkeypatch):
+    """Batches of >= 1024 frame groups take the resident, role-split kernel (streaming waves + tail waves, csrc/k1_large.hip): every
+    output flavour bit for bit what the one-group-per-workgroup kernel writes, ragged last tile included, and the oracle's numbers."""
+    from colvarsfinder import _hip
+    rs = np.random.RandomState(n_atoms)
+    feats = [("position", tuple(int(i) for i in rs.choice(n_atoms, 16, replace=False)))]
+    feats += [("dihedral", tuple(int(i) for i in rs.choice(n_atoms, 4, replace=False))) for _ in range(100)]
+    feats += [("bond", tuple(int(i) for i in rs.choice(n_atoms, 2, replace=False))) for _ in range(60)]
+    feats += [("angle", tuple(int(i) for i in rs.choice(n_atoms, 3, replace=False))) for _ in range(10)]
+    x, ref = _device_molecule_frames(n_atoms, B, 4100 + n_atoms, dev)
+    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=feats, use_angle_value=False)
+    layer = make_layer(spec, n_atoms, dev)
+    desc, T, d_r = layer.pp_desc(), _hip.ntiles(B), layer.d_r
+    assert d_r >= 272
+    scratch = _hip.align_scratch(desc, B, dev)
+    lib, P, st = _hip.lib(), _hip.ptr, _hip.stream()
+
+    def run(flavour):
+        nan = float("nan")
+        tiled = torch.full((T * d_r * 64,), nan, device=dev)
+        rows = torch.full((B * d_r,), nan, device=dev)
+        aux = torch.full((T * 18 * 64,), nan, device=dev)
+        if scratch is not None:
+            scratch.fill_(nan)
+        args = dict(features=(P(tiled), None, None, None), generator=(P(tiled), None, P(aux), P(scratch)),
+                    rows=(None, P(rows), None, None), both=(P(tiled), P(rows), None, None))[flavour]
+        _hip.check(lib.cvf_align_feature_fwd(desc, P(x), B, *args, st), "k1")
+        torch.cuda.synchronize()
+        used = dict(features=[tiled], generator=[tiled, aux, scratch], rows=[rows], both=[tiled, rows])[flavour]
+        return [u.clone() for u in used]
+
+    for flavour in ("features", "generator", "rows", "both"):
+        monkeypatch.delenv("CVF_K1_NOPIPE", raising=False)
+        got = run(flavour)
+        monkeypatch.setenv("CVF_K1_NOPIPE", "1")
+        want = run(flavour)
+        for g, w_ in zip(got, want):
+            assert torch.isfinite(w_.view(torch.float32)).all() if w_.dtype == torch.float32 else True
+            assert torch.equal(g.view(torch.int32) if g.dtype == torch.float32 else g.view(torch.int64),
+                               w_.view(torch.int32) if w_.dtype == torch.float32 else w_.view(torch.int64)), flavour
+    monkeypatch.delenv("CVF_K1_NOPIPE", raising=False)
+    rows = run("rows")[0].view(B, d_r)
+    pick = list(range(40)) + list(range(B - 40, B))
+    torch.set_default_dtype(torch.float64)
+    want = oracle_layer(spec)(x[pick].double().cpu()).numpy()
+    np.testing.assert_allclose(rows[pick].cpu().numpy(), want, rtol=2e-5, atol=3e-6 * np.abs(want).max())
+
+
 @pytest.mark.parametrize("n_atoms,B,contig,k", [(257, 96, True, 2), (300, 70, False, 3)])
 def test_large_molecule_generator_step_vs_oracle(dev, n_atoms, B, contig, k):
     """EigenFunctionTask in generator mode on frames that take the streaming alignment path: loss, eigenvalues and

@@ -27,14 +27,25 @@ def t(fn, reps=15):
 s = _hip.stream()
 for rnd in range(3):
     row = {}
-    for mode in ("0", "1", "2", "4"):
-        os.environ["CVF_K1_XCD"] = mode
-        row["feat_xcd" + mode] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, None, None, s)), 1)
-        row["gen_xcd" + mode] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, P(a_tmp), P(sc5), s)), 1)
     rows_out = torch.empty(n5 * layer5.d_r, device=dev)
     os.environ["CVF_K1_XCD"] = "0"
-    row["feat_rows_only"] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, None, P(rows_out), None, None, s)), 1)
-    row["feat_tiled_and_rows"] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), P(rows_out), None, None, s)), 1)
+    for tag, nopipe in (("pipe", None), ("slice", "1")):
+        if nopipe is None:
+            os.environ.pop("CVF_K1_NOPIPE", None)
+        else:
+            os.environ["CVF_K1_NOPIPE"] = nopipe
+        row["feat_" + tag] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, None, None, s)), 1)
+        row["gen_" + tag] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, P(a_tmp), P(sc5), s)), 1)
+        row["rows_" + tag] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, None, P(rows_out), None, None, s)), 1)
+        row["c5step16k_" + tag] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), 16000, P(f_tmp), None, P(a_tmp), P(sc5), s)), 1)
+    os.environ.pop("CVF_K1_NOPIPE", None)
+    for pb in (1, 8):
+        os.environ["CVF_K1_PIPE_PROBE"] = str(pb)
+        row["feat_pipe_probe%d" % pb] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, None, None, s)), 1)
+    os.environ.pop("CVF_K1_PIPE_PROBE", None)
+    os.environ["CVF_K1_XCD"] = "2"; os.environ["CVF_K1_NOPIPE"] = "1"
+    row["feat_slice_streamonly"] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, None, None, s)), 1)
+    os.environ["CVF_K1_XCD"] = "0"; os.environ.pop("CVF_K1_NOPIPE", None)
     n4 = x5.numel() // 4
     dst_r = torch.empty(int(lib.cvf_probe_stream_out_floats(1, n4)), device=dev)
     row["read_sweep_us"] = round(t(lambda: lib.cvf_probe_stream(1, P(dst_r), P(x5.reshape(-1)), n4, s)), 1)

@@ -93,6 +93,44 @@ int main(int argc, char** argv) {
   printf("B=%lld N=%d n_slot=%d d_r=%d: %.1f us/launch, %.0f GB/s algorithmic (%.0f B/frame)\n", (long long)B, N, pp.n_slot, d_r, us,
          bpf * B / us * 1e-3, bpf);
   std::vector<unsigned long long> st(64 * 4096);
+  if (B / 8 >= 4 * 256) {   // the pipelined kernel: per-role phase sums (PIPE_T), one launch on zeroed counters
+    std::fill(st.begin(), st.end(), 0ull);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), st.data(), st.size() * 8);
+    cvf_k1_large_launch(&pp, dx, B, dfeat, nullptr, argc > 2 ? daux : nullptr, argc > 2 ? dslot : nullptr, nullptr);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+    const double groups_per_wg = double((B + 63) / 64 * 8) / 256.0;
+    const char* sn[3] = {"", "stream 8 frames", "wait at the barrier"};
+    const char* tn[9] = {"", "slot copy + sums", "solve", "features + aux", "wait for the tail waves", "flush", "", "wait at the barrier"};
+    for (int wv : {0, 1, 2, 3, 4, 5, 6, 7}) {
+      double a1 = 0, a2 = 0;
+      for (int b = 0; b < 256; ++b) { a1 += st[(b * 12 + wv) * 64 + 1]; a2 += st[(b * 12 + wv) * 64 + 2]; }
+      printf("   streaming wave %d: %s %8.0f | %s %8.0f cycles per group\n", wv, sn[1], a1 / 256 / groups_per_wg, sn[2], a2 / 256 / groups_per_wg);
+    }
+    {
+      const int order0[5] = {1, 2, 3, 4, 8};
+      const char* names0[5] = {"barrier exit", "sums", "solve", "aux + position features", "wait at the barrier"};
+      printf("   tail wave 0:");
+      for (int q = 0; q < 5; ++q) {
+        double a = 0;
+        for (int b = 0; b < 256; ++b) a += st[(b * 12 + 8) * 64 + order0[q]];
+        printf(" %s %.0f |", names0[q], a / 256 / groups_per_wg);
+      }
+      printf(" cycles per group\n");
+    }
+    for (int wv : {9, 11}) {
+      printf("   tail wave %d:", wv - 8);
+      const int order[6] = {1, 2, 3, 5, 6, 8};
+      const char* names[6] = {"barrier exit", "slot copy", "other features", "tail waves meet", "gather + flush", "wait at the barrier"};
+      for (int q = 0; q < 6; ++q) {
+        double a = 0;
+        for (int b = 0; b < 256; ++b) a += st[(b * 12 + wv) * 64 + order[q]];
+        printf(" %s %.0f |", names[q], a / 256 / groups_per_wg);
+      }
+      printf(" cycles per group\n");
+    }
+    return 0;
+  }
   (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
   const char* nm[9] = {"", "static ref/slot loads", "8-frame stream + reduce", "barrier", "sum over waves", "solve", "aux + slot copy", "features", "flush"};
   double acc[9] = {0}; int n = 0;
