@@ -50,7 +50,7 @@ FLOP_OF_CALL = {"cvf_ef16_front": FLOP_FWD + FLOP_METRIC + FLOP_K1, "cvf_ef16_ba
 KERNEL_OF_CALL = {"cvf_ef16_front": "ef16_front_kernel", "cvf_ef16_backward": "ef16_back_kernel", "cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wide_kernel", "cvf_metric_apply": "metric_rows_kernel",
                   "cvf_ef_fwd_metric_stats": "ef_fwd_metric_kernel", "cvf_ef_align_fwd_metric_stats": "ef_fwd_metric_kernel",
                   "cvf_align_feature_fwd": "k1_align_quad_kernel", "cvf_align_feature_fwd@1M": "k1_stream_kernel",
-                  "cvf_align_feature_fwd@c5": "k1_large_slice_kernel"}
+                  "cvf_align_feature_fwd@c5": "k1_large_pipe_kernel"}
 PROFILE_TAG = "r4"   # profiles/<tag>_pmc_traffic.json is the committed PMC summary `roofline.traffic` is read from
 
 
@@ -603,31 +603,27 @@ def align_feature_roofline(task, ref, dev, pmc_traffic):
     x5, _ = device_frames(n5, ref5, 0.05, SEED + 78, dev, chunk=5000)
     bpf5 = 12 * na5 + 4 + 4 * layer5.d_r
     feat5 = case(d5, x5, n5, layer5.d_r, bpf5, False)
-    # the frame groups of a tile on one XCD (the default when a tiled output is written) against blockIdx order, same lease
-    ab = {}
-    for mode in ("0", "1"):
-        os.environ["CVF_K1_XCD"] = mode
-        ab["blockidx_order" if mode == "0" else "tile_on_one_xcd"] = case(d5, x5, n5, layer5.d_r, bpf5, False, reps=15)["avg_launch_us"]
-    del os.environ["CVF_K1_XCD"]
-    feat5["xcd_placement_ab_us"] = ab
+    # large batches take the resident role-split kernel (k1_large_pipe_kernel, round 4); the one-group-per-workgroup kernel it replaced
+    # (k1_large_slice_kernel, still what small batches run) in the same lease
+    def with_env(name, value, fn):
+        os.environ[name] = value
+        try:
+            return fn()
+        finally:
+            del os.environ[name]
+    feat5["kernel_ab_us"] = {"pipelined": feat5["avg_launch_us"],
+                             "one_group_per_workgroup": with_env("CVF_K1_NOPIPE", "1", lambda: case(d5, x5, n5, layer5.d_r, bpf5, False, reps=15)["avg_launch_us"])}
     rows5 = case(d5, x5, n5, layer5.d_r, bpf5, False, rows=True)
     feat5["row_major_output"] = {k_: rows5[k_] for k_ in ("avg_launch_us", "frac", "k1_over_copy")}
-    # where the launch's time goes (developer probes of csrc/k1_large.hip, results discarded): the streaming loop alone, and the launch
-    # without its feature stores - the tail behind the loop (eight 3x3 solves per workgroup, features, stores) is what varies by box
-    parts = {}
-    for mode, label in (("2", "streaming_loop_only_us"), ("4", "without_feature_stores_us")):
-        os.environ["CVF_K1_XCD"] = mode
-        parts[label] = case(d5, x5, n5, layer5.d_r, bpf5, False, reps=15)["avg_launch_us"]
-    del os.environ["CVF_K1_XCD"]
-    feat5["launch_decomposition"] = parts
+    # where the launch's time goes (developer probes of csrc/k1_large.hip, results discarded): the streaming waves alone, and the launch
+    # without its feature stores
+    feat5["launch_decomposition"] = {
+        "streaming_waves_only_us": with_env("CVF_K1_PIPE_PROBE", "1", lambda: case(d5, x5, n5, layer5.d_r, bpf5, False, reps=15)["avg_launch_us"]),
+        "without_feature_stores_us": with_env("CVF_K1_PIPE_PROBE", "8", lambda: case(d5, x5, n5, layer5.d_r, bpf5, False, reps=15)["avg_launch_us"])}
     sc5 = _hip.align_scratch(d5, n5, dev)
-    abg = {}
-    for mode in ("0", "1"):
-        os.environ["CVF_K1_XCD"] = mode
-        abg["blockidx_order" if mode == "0" else "tile_on_one_xcd"] = case(d5, x5, n5, layer5.d_r, bpf5, True, scratch=sc5, reps=15)["avg_launch_us"]
-    del os.environ["CVF_K1_XCD"]
     gen5 = case(d5, x5, n5, layer5.d_r, bpf5, True, scratch=sc5)
-    gen5["xcd_placement_ab_us"] = abg
+    gen5["kernel_ab_us"] = {"pipelined": gen5["avg_launch_us"],
+                            "one_group_per_workgroup": with_env("CVF_K1_NOPIPE", "1", lambda: case(d5, x5, n5, layer5.d_r, bpf5, True, scratch=sc5, reps=15)["avg_launch_us"])}
     gen5["note"] = "+ rotation/centroid rows and the slot copy the derivative kernel reads"
     del x5, sc5
     res["config5_100k"] = dict(frames_per_launch=n5, n_atoms=na5, d_r=layer5.d_r, bytes_per_frame=bpf5, footprint_MB=bpf5 * n5 / 1e6,

@@ -601,7 +601,8 @@ constexpr int kRedPitchP = 68;
 
 template <int NI>
 __global__ __launch_bounds__(64 * (kStream + kTail)) void k1_large_pipe_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
-                                                                              int64_t nquads, float* __restrict__ feat_tiled,
+                                                                              int64_t nquads, int64_t groups, int rounds,
+                                                                              float* __restrict__ feat_tiled,
                                                                               float* __restrict__ feat_rows,
                                                                               float* __restrict__ aux_tiled,
                                                                               float* __restrict__ slot_xyz, int probe) {
@@ -617,9 +618,16 @@ __global__ __launch_bounds__(64 * (kStream + kTail)) void k1_large_pipe_kernel(c
   const int nq = N >> 2, nqa = nal >> 2;
   const int cap_floats = kGroup * nslot * 3;
   float* featL = dyn + 2 * (size_t)cap_floats;
-  // a workgroup takes QUADS of four consecutive frame groups (half a 64-frame tile: blockIdx.x, + gridDim.x, ...) - see the flush below
-  const int nit = 4 * (int)((nquads - blockIdx.x + gridDim.x - 1) / gridDim.x);   // its groups, numbered n = 0 .. nit - 1
-  auto group_of = [&](int n) __attribute__((always_inline)) { return ((int64_t)blockIdx.x + (int64_t)(n >> 2) * gridDim.x) * 4 + (n & 3); };
+  // a workgroup takes QUADS of four consecutive frame groups (half a 64-frame tile: blockIdx.x, + gridDim.x, ...; see the flush below).  With
+  // `rounds` >= 0 every workgroup takes exactly `rounds` quads and the groups behind them go round the workgroups ONE AT A TIME (100 000 frames
+  // are 12.2 quads per workgroup: 13 rounds of quads would idle 6 % of the chip-time, 12 rounds + one single group 0.3 %).
+  const int nq_mine = rounds >= 0 ? rounds : (int)((nquads - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  const int64_t single0 = 4 * (int64_t)gridDim.x * (rounds >= 0 ? rounds : 0) + blockIdx.x;   // this workgroup's first single group
+  const int nx_mine = rounds >= 0 && single0 < groups ? (int)((groups - single0 + gridDim.x - 1) / gridDim.x) : 0;
+  const int nit = 4 * nq_mine + nx_mine;   // its groups, numbered n = 0 .. nit - 1
+  auto group_of = [&](int n) __attribute__((always_inline)) {
+    return n < 4 * nq_mine ? ((int64_t)blockIdx.x + (int64_t)(n >> 2) * gridDim.x) * 4 + (n & 3) : single0 + (int64_t)(n - 4 * nq_mine) * gridDim.x;
+  };
   // The roles meet at COUNTERS in LDS, not at the workgroup barrier (a barrier per group made every streaming wave wait for the slowest one
   // with one frame of loads in flight - stamped: waves 0..3 stream a group in 33 k cycles and then waited 16 k for waves 4..7):
   //   kDone  += 1 by a streaming wave that has captured its share of group n       -> the tail starts group n at 8 (n / 2 + 1); one counter per
@@ -946,6 +954,29 @@ __global__ __launch_bounds__(64 * (kStream + kTail)) void k1_large_pipe_kernel(c
       post(kTaken);
       continue;
     }
+    if (n >= 4 * nq_mine) {   // a single group behind the quads: its staged features leave at once (32-byte pieces of the tiled rows / one 8 d_r run)
+      if (staged == 1) {
+        float* row0 = feat_tiled + (f0 / CVF_TILE) * pp.d_r * CVF_TILE + (int)(f0 % CVF_TILE);
+        for (int idx = hl; idx < pp.d_r * 2; idx += 192)
+          *reinterpret_cast<float4*>(row0 + (idx >> 1) * CVF_TILE + 4 * (idx & 1)) = *reinterpret_cast<const float4*>(featL + (idx >> 1) * kGroup + 4 * (idx & 1));
+      } else {
+        const int64_t base = f0 * pp.d_r, lim = B * pp.d_r;
+        for (int idx = hl; idx < 2 * pp.d_r; idx += 192) {
+          const int64_t e = base + 4 * (int64_t)idx;
+          const float4 v = *reinterpret_cast<const float4*>(featL + 4 * idx);
+          if (e + 3 < lim) {
+            *reinterpret_cast<float4*>(feat_rows + e) = v;
+          } else if (e < lim) {
+            feat_rows[e] = v.x;
+            if (e + 1 < lim) feat_rows[e + 1] = v.y;
+            if (e + 2 < lim) feat_rows[e + 2] = v.z;
+          }
+        }
+      }
+      post(kTaken);
+      PIPE_T(6);
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < kHold; ++k) {
       const int idx = hl + 192 * k;
@@ -1035,10 +1066,15 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
       if (vec4 && ni <= 3 && staged && groups >= 4 * (int64_t)ncu && lds_pipe <= 145 * 1024 && 3 * pp->n_slot < 0xffff && pp->d_r <= 384 &&
           (feat_tiled != nullptr || ((uintptr_t)feat_rows & 15) == 0) && getenv("CVF_K1_NOPIPE") == nullptr) {
         const int64_t nquads = (groups + 3) / 4;   // (tiled outputs: groups is a multiple of 8)
+        const int64_t grid = nquads < ncu ? nquads : ncu;
+        // quads only, or whole rounds of quads and the groups behind them one at a time - whichever gives the busiest workgroup fewer groups
+        const int64_t r_all = (nquads + grid - 1) / grid, r_full = nquads / grid;
+        const int64_t left = groups - 4 * grid * r_full, with_singles = 4 * r_full + (left + grid - 1) / grid;
+        const int rounds = r_full >= 1 && with_singles < 4 * r_all ? (int)r_full : -1;
         auto go = [&](auto kernel) {
           (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe);
           const int probe = getenv("CVF_K1_PIPE_PROBE") ? atoi(getenv("CVF_K1_PIPE_PROBE")) : 0;
-          hipLaunchKernelGGL(kernel, dim3((unsigned)(nquads < ncu ? nquads : ncu)), dim3(64 * (kStream + kTail)), lds_pipe, s, *pp, x, B, nquads,
+          hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * (kStream + kTail)), lds_pipe, s, *pp, x, B, nquads, groups, rounds,
                              feat_tiled, feat_rows, aux_tiled, slot_xyz, probe);
         };
         if (ni == 1) go(k1_large_pipe_kernel<1>);

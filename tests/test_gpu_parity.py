@@ -615,7 +615,7 @@ def _device_molecule_frames(n_atoms, B, seed, dev, scale=8.0, sigma=0.4):
     return x.float().contiguous(), ref
 
 
-@pytest.mark.parametrize("n_atoms,B", [(1000, 8192 + 37), (2600, 8192 + 64), (5000, 8192 + 5)])
+@pytest.mark.parametrize("n_atoms,B", [(1000, 8192 + 37), (2600, 8192 + 64), (5000, 8192 + 5), (1000, 16000 + 19), (1000, 25000)])
 def test_k1_pipelined_kernel_equals_the_slice_kernel_and_the_oracle(dev, n_atoms, B, monkeypatch):
     """Batches of >= 1024 frame groups take the resident, role-split kernel (streaming waves + tail waves, csrc/k1_large.hip): every
     output flavour bit for bit what the one-group-per-workgroup kernel writes, ragged last tile included, and the oracle's numbers."""

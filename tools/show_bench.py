@@ -16,7 +16,7 @@ if r:
         f, g = v["features_only"], v["generator_outputs"]
         print(" ", k, "feat us", round(f["avg_launch_us"], 1), "[", round(f["min_launch_us"], 1), round(f["max_launch_us"], 1), "] frac", round(f["frac"], 3), "copy",
               round(f["copy_GBps"]), "read", round(f["read_GBps"]), "k1/copy", round(f["k1_over_copy"], 3), "| gen us", round(g["avg_launch_us"], 1), "frac",
-              round(g["frac"], 3), f.get("xcd_placement_ab_us") or "", g.get("xcd_placement_ab_us") or "", "rows:", f.get("row_major_output") or "", f.get("launch_decomposition") or "")
+              round(g["frac"], 3), f.get("kernel_ab_us") or f.get("xcd_placement_ab_us") or "", g.get("kernel_ab_us") or g.get("xcd_placement_ab_us") or "", "rows:", f.get("row_major_output") or "", f.get("launch_decomposition") or "")
 for k, v in (d.get("other_configs") or {}).items():
     print(" ", k, "us/step", v.get("us_per_step") and round(v["us_per_step"], 1), "frac", (v.get("roofline") or v.get("roofline_c5_step") or {}).get("frac"),
           {a: round(b, 1) for a, b in (v.get("call_avg_us") or {}).items()}, v.get("error") or "")
