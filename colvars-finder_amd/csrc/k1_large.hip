@@ -565,18 +565,23 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Pipelined variant of the slice kernel (round 4; large batches).  In the slice kernel a workgroup streams its eight frames and
-// then spends a fifth of its life in the tail (sums -> 3x3 solves -> features -> flush) with no load in flight; two workgroups per
-// CU overlap that only by chance, and the streaming loop alone (CVF_K1_XCD=2) runs at the read sweep's rate while the whole kernel
-// is 10-15 % below it.  Here ONE workgroup per CU stays for the whole launch and is split by role:
+// Pipelined variant of the slice kernel (round 4; large batches: >= 4 frame groups per compute unit).  In the slice kernel a workgroup
+// streams its eight frames and then spends a fifth of its life in the tail (sums -> 3x3 solves -> features -> flush) with no load in
+// flight; two workgroups per CU overlap that only by chance, and the streaming loop alone (CVF_K1_XCD=2) runs at the read sweep's rate
+// while the whole kernel is 10-15 % below it.  Here ONE workgroup per CU stays for the whole launch and is split by role:
 //   waves 0..7   stream: exactly the slice kernel's loop (same atoms per lane, same partial sums, same order: bit-identical sums),
 //                but over group after group, and with the NEXT frame's loads requested before the current frame's arithmetic
 //                (one workgroup per CU leaves 168 registers per lane: room for the second set of 36) - also across the group
 //                boundary, so the memory pipe never drains;
-//   waves 8..11  tail: after the barrier that ends group n they turn it into its outputs, two frames per wave (sums, solve on two
-//                lanes, all feature records, aux rows, a quarter of the slot copy), meet at an LDS counter and flush the staged
-//                features together - while the streaming waves are already capturing group n + 1 into the other LDS buffer.
-// The roles meet at counters in LDS (in the kernel).
+//   wave 8       tail: the group's eight 3x3 solves (a lane each), the rotation rows, the features that need the rotation;
+//   waves 9..11  tail: the other features, the slot copy - and the feature stores: the features of FOUR consecutive groups wait in
+//                their registers and leave as whole 128-byte lines (see THE FLUSH in the kernel: group-by-group 32-byte pieces cost
+//                250 us of a 1220-us launch) - while the streaming waves are already capturing the next group into the other LDS buffer.
+// The roles meet at counters in LDS (in the kernel), never at the workgroup barrier.  Measured (tools/k1_ab.sh, 100 000 frames of 5000
+// atoms, both kernels in one lease, two kinds of box): 1031-1042 us against 1131-1146 (features only: 0.74 of 8 TB/s, 0.92 of a read
+// sweep of the same bytes), 1117 against 1221 on the slower kind (0.69); with the generator-mode extras 1213-1224 against 1247-1269;
+// row-major output 1043-1055 against 1120-1136.  Every output is bit for bit the slice kernel's
+// (tests/test_gpu_parity.py::test_k1_pipelined_kernel_equals_the_slice_kernel_and_the_oracle).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kStream = 8, kTail = 4;
 // developer aid (tools/k1_large_probe.hip, -DCVF_STAMPS): cycles a wave spends between two marks, summed over its groups
@@ -841,6 +846,11 @@ __global__ __launch_bounds__(64 * (kStream + kTail)) void k1_large_pipe_kernel(c
   };
   if (tw == 0) {
     // ------------------------------------------------- tail wave 0: sums, solve, aux rows, position features
+    constexpr int kAuxHold = CVF_AUX_ROWS * 32 / 64;   // 18 rows x 32 frames over the 64 lanes
+    static_assert(CVF_AUX_ROWS * 32 % 64 == 0, "whole items per lane");
+    float auxh[kAuxHold];
+#pragma unroll
+    for (int k = 0; k < kAuxHold; ++k) auxh[k] = 0.0f;
 #pragma unroll 1
     for (int n = 0; n < nit; ++n) {
       PIPE_T(8);
@@ -893,11 +903,30 @@ __global__ __launch_bounds__(64 * (kStream + kTail)) void k1_large_pipe_kernel(c
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       PIPE_T(3);
       if (aux_tiled != nullptr) {
-        const int64_t tile = f0 / CVF_TILE;
-        const int l0 = (int)(f0 % CVF_TILE);
-        for (int i = lane; i < kGroup * CVF_AUX_ROWS; i += 64) {
-          const int row = i / kGroup, j = i - row * kGroup;
-          aux_tiled[(tile * CVF_AUX_ROWS + row) * CVF_TILE + l0 + j] = bc[j][row];
+        if (n < 4 * nq_mine) {   // like the features (below): a quad's rotation rows leave as whole 128-byte lines, 32 frames of a row
+          const int gq = n & 3;
+#pragma unroll
+          for (int k = 0; k < kAuxHold; ++k) {
+            const int i = lane + 64 * k, row = i >> 5, fr = i & 31;
+            if ((fr >> 3) == gq) auxh[k] = bc[fr & 7][row];
+          }
+          if (gq == 3) {
+            const int64_t f0q = f0 - 3 * kGroup;
+            float* a0p = aux_tiled + (f0q / CVF_TILE) * CVF_AUX_ROWS * CVF_TILE + (int)(f0q % CVF_TILE);
+#pragma unroll
+            for (int k = 0; k < kAuxHold; ++k) {
+              int i = lane + 64 * k;
+              asm volatile("" : "+v"(i));
+              a0p[(i >> 5) * CVF_TILE + (i & 31)] = auxh[k];
+            }
+          }
+        } else {
+          const int64_t tile = f0 / CVF_TILE;
+          const int l0 = (int)(f0 % CVF_TILE);
+          for (int i = lane; i < kGroup * CVF_AUX_ROWS; i += 64) {
+            const int row = i / kGroup, j = i - row * kGroup;
+            aux_tiled[(tile * CVF_AUX_ROWS + row) * CVF_TILE + l0 + j] = bc[j][row];
+          }
         }
       }
       if (n >= 1) await(kTaken, (kTail - 1) * n);   // the staging area still held group n - 1
@@ -995,6 +1024,7 @@ __global__ __launch_bounds__(64 * (kStream + kTail)) void k1_large_pipe_kernel(c
         for (int k = 0; k < kHold; ++k) {
           int idx = hl + 192 * k;
           asm volatile("" : "+v"(idx));   // (the address is formed here: hoisted out of the group loop the sixteen 64-bit addresses were spilled)
+          // (cache-policy bits on these stores - nt, sc1, sc0 sc1 - change nothing: 1042 / 1043 / 1047 / 1043 us)
           if (idx < d8) *reinterpret_cast<float4*>(row0 + (idx >> 3) * CVF_TILE + 4 * (idx & 7)) = hold[k];
         }
       } else {
