@@ -42,6 +42,9 @@ for rnd in range(3):
     for pb in (1, 8):
         os.environ["CVF_K1_PIPE_PROBE"] = str(pb)
         row["feat_pipe_probe%d" % pb] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, None, None, s)), 1)
+    for pb in (8,):
+        os.environ["CVF_K1_PIPE_PROBE"] = str(pb)
+        row["gen_pipe_probe%d" % pb] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, P(a_tmp), P(sc5), s)), 1)
     os.environ.pop("CVF_K1_PIPE_PROBE", None)
     os.environ["CVF_K1_XCD"] = "2"; os.environ["CVF_K1_NOPIPE"] = "1"
     row["feat_slice_streamonly"] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, None, None, s)), 1)

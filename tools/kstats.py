@@ -10,7 +10,7 @@ with open(sys.argv[1]) as f:
         d[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = 0
 for n, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
-    if n.startswith("at::") or n.startswith("__amd"):
+    if n.startswith("at::") or n.startswith("__amd") or n.startswith("Cijk_"):   # (torch's own kernels: the synthetic frames are generated on the device)
         continue
     vv = v[skip:] if len(v) > skip else v
     avg = sum(vv) / len(vv)

@@ -8,7 +8,7 @@ with open(sys.argv[1]) as f:
         name = re.sub(r"\(.*", "", name).replace("void ", "")
         rows[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, cs in sorted(rows.items()):
-    if name.startswith("at::") or name.startswith("__amd"):
+    if name.startswith("at::") or name.startswith("__amd") or name.startswith("Cijk_"):
         continue
     print(name)
     for c, v in sorted(cs.items()):
