@@ -11,6 +11,7 @@
 //             feature launch re-fetched more sectors from HBM than the frame itself holds).
 //   flush     features of the 16 frames are staged in LDS and leave as full 64-byte segments of the tiled layout.
 #include "cvf_kabsch.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -1072,6 +1073,11 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
   //  with the tile on one XCD on one box, equal on another - the slot copy has been one contiguous run per workgroup since round 3,
   //  which is what the placement was for.  Default: blockIdx order.)
   const int same_xcd = xcd_env >= 0 ? xcd_env : 0;
+  if (same_xcd & 6) {
+    static bool told = false;
+    if (!told) fprintf(stderr, "[cvf] CVF_K1_XCD=%d: developer timing probe - the outputs of cvf_align_feature_fwd are WRONG\n", same_xcd);
+    told = true;
+  }
   const int64_t groups = feat_tiled || aux_tiled || slot_xyz ? cvf_ntiles(B) * (CVF_TILE / kGroup) : (B + kGroup - 1) / kGroup;
   const bool staged = feat_tiled != nullptr || feat_rows != nullptr;   // features leave through an LDS staging area
   if (capture_ok(pp, staged)) {
@@ -1104,6 +1110,11 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
         auto go = [&](auto kernel) {
           (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe);
           const int probe = getenv("CVF_K1_PIPE_PROBE") ? atoi(getenv("CVF_K1_PIPE_PROBE")) : 0;
+          if (probe != 0) {
+            static bool told = false;
+            if (!told) fprintf(stderr, "[cvf] CVF_K1_PIPE_PROBE=%d: developer timing probe - the outputs of cvf_align_feature_fwd are WRONG\n", probe);
+            told = true;
+          }
           hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * (kStream + kTail)), lds_pipe, s, *pp, x, B, nquads, groups, rounds,
                              feat_tiled, feat_rows, aux_tiled, slot_xyz, probe);
         };
