@@ -615,21 +615,23 @@ def _device_molecule_frames(n_atoms, B, seed, dev, scale=8.0, sigma=0.4):
     return x.float().contiguous(), ref
 
 
-@pytest.mark.parametrize("n_atoms,B", [(1000, 8192 + 37), (2600, 8192 + 64), (5000, 8192 + 5), (1000, 16000 + 19), (1000, 25000)])
-def test_k1_pipelined_kernel_equals_the_slice_kernel_and_the_oracle(dev, n_atoms, B, monkeypatch):
+@pytest.mark.parametrize("n_atoms,B,n_align,angles", [(1000, 8192 + 37, 1000, False), (2600, 8192 + 64, 2600, False), (5000, 8192 + 5, 5000, False),
+                                                      (1000, 16000 + 19, 1000, False), (1000, 25000, 1000, False), (1000, 8192 + 37, 600, True)])
+def test_k1_pipelined_kernel_equals_the_slice_kernel_and_the_oracle(dev, n_atoms, B, n_align, angles, monkeypatch):
     """Batches of >= 1024 frame groups take the resident, role-split kernel (streaming waves + tail waves, csrc/k1_large.hip): every
     output flavour bit for bit what the one-group-per-workgroup kernel writes, ragged last tile included, and the oracle's numbers."""
     from colvarsfinder import _hip
     rs = np.random.RandomState(n_atoms)
-    feats = [("position", tuple(int(i) for i in rs.choice(n_atoms, 16, replace=False)))]
+    feats = [("position", tuple(int(i) for i in rs.choice(n_atoms, 40 if angles else 16, replace=False)))]
     feats += [("dihedral", tuple(int(i) for i in rs.choice(n_atoms, 4, replace=False))) for _ in range(100)]
     feats += [("bond", tuple(int(i) for i in rs.choice(n_atoms, 2, replace=False))) for _ in range(60)]
     feats += [("angle", tuple(int(i) for i in rs.choice(n_atoms, 3, replace=False))) for _ in range(10)]
     x, ref = _device_molecule_frames(n_atoms, B, 4100 + n_atoms, dev)
-    spec = dict(align_idx=list(range(n_atoms)), ref_pos=ref, features=feats, use_angle_value=False)
+    # (the last case: alignment on the first 600 atoms only, angle-valued angles and dihedrals - one output per dihedral)
+    spec = dict(align_idx=list(range(n_align)), ref_pos=ref[:n_align], features=feats, use_angle_value=angles)
     layer = make_layer(spec, n_atoms, dev)
     desc, T, d_r = layer.pp_desc(), _hip.ntiles(B), layer.d_r
-    assert d_r >= 272
+    assert d_r >= 272   # (fewer features would send the comparison launch to another kernel: other summation order)
     scratch = _hip.align_scratch(desc, B, dev)
     lib, P, st = _hip.lib(), _hip.ptr, _hip.stream()
 
