@@ -1099,14 +1099,22 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
       const int ncu = cvf_cu_count();
       const size_t lds_pipe = (2 * (size_t)kGroup * pp->n_slot * 3 + (size_t)pp->d_r * kGroup + (size_t)kStream * 4 * kRedPitchP +
                                6 * (size_t)(pp->n_rec_slot > 0 ? pp->n_rec_slot : pp->n_rec)) * sizeof(float);   // (+ 14.4 KB of static arrays: 160 KB in all)
-      if (vec4 && ni <= 3 && staged && groups >= 4 * (int64_t)ncu && lds_pipe <= 145 * 1024 && 3 * pp->n_slot < 0xffff && pp->d_r <= 384 &&
+      // (developer switch CVF_K1_PIPE_MIN_GROUPS: this kernel - with single groups only - below four groups per compute unit; measured with the
+      //  generator-mode outputs, tools/k1_small_ab.sh: 2000 frames 41 us against 34, 4000: 64.5 / 62, 8000: 120 / 120.5, 12 000: 170 / 177)
+      const int64_t pipe_min = getenv("CVF_K1_PIPE_MIN_GROUPS") ? atoll(getenv("CVF_K1_PIPE_MIN_GROUPS")) : -1;
+      if (vec4 && ni <= 3 && staged && groups >= (pipe_min >= 0 ? pipe_min : 4 * (int64_t)ncu) && lds_pipe <= 145 * 1024 && 3 * pp->n_slot < 0xffff && pp->d_r <= 384 &&
           (feat_tiled != nullptr || ((uintptr_t)feat_rows & 15) == 0) && getenv("CVF_K1_NOPIPE") == nullptr) {
         const int64_t nquads = (groups + 3) / 4;   // (tiled outputs: groups is a multiple of 8)
-        const int64_t grid = nquads < ncu ? nquads : ncu;
-        // quads only, or whole rounds of quads and the groups behind them one at a time - whichever gives the busiest workgroup fewer groups
+        // quads only, or whole rounds of quads and the groups behind them one at a time - whichever gives the busiest workgroup fewer groups;
+        // fewer than four groups per compute unit: single groups only
+        int64_t grid = nquads < ncu ? nquads : ncu;
         const int64_t r_all = (nquads + grid - 1) / grid, r_full = nquads / grid;
         const int64_t left = groups - 4 * grid * r_full, with_singles = 4 * r_full + (left + grid - 1) / grid;
-        const int rounds = r_full >= 1 && with_singles < 4 * r_all ? (int)r_full : -1;
+        int rounds = r_full >= 1 && with_singles < 4 * r_all ? (int)r_full : -1;
+        if (groups < 4 * (int64_t)ncu) {
+          grid = groups < ncu ? groups : ncu;
+          rounds = 0;
+        }
         auto go = [&](auto kernel) {
           (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe);
           const int probe = getenv("CVF_K1_PIPE_PROBE") ? atoi(getenv("CVF_K1_PIPE_PROBE")) : 0;
