@@ -83,6 +83,25 @@ def test_rotation_is_optimal():
         assert (pert >= base - 1e-10).all()
 
 
+def test_kabsch_rotation_equals_an_independent_published_implementation():
+    """The oracle's rotation against SciPy's Rotation.align_vectors (Kabsch / Wahba by SVD, an implementation nobody here wrote):
+    the same proper rotation for generic, for nearly planar and for mirrored frames.  (Not a pin in the contract's sense - the
+    third-party layer the reference calls is absent - but a second, published statement of the algorithm SURVEY 8 a15 names.)"""
+    from scipy.spatial.transform import Rotation
+    for n, seed, squash, mirror in ((9, 11, 1.0, False), (40, 12, 1.0, False), (12, 13, 1e-3, False), (10, 14, 1.0, True)):
+        traj, _, ref = make_molecule_traj(n, 7, seed, dtype=np.float64)
+        ref = ref * np.array([1.0, 1.0, squash])
+        traj = traj * np.array([1.0, 1.0, squash])
+        if mirror:
+            traj = traj * np.array([1.0, 1.0, -1.0])
+        L = layer(n, ref)
+        R, c = opp.kabsch_rotation(torch.tensor(traj), L.align_idx, L.ref_c)
+        for b in range(traj.shape[0]):
+            # x_al = (x - c) R as row vectors: the rotation that takes the centred frame onto the reference is R^T as a matrix on columns
+            rot, _ = Rotation.align_vectors(L.ref_c.numpy(), traj[b] - c[b].numpy())
+            np.testing.assert_allclose(R[b].numpy().T, rot.as_matrix(), atol=5e-9 if squash == 1.0 else 5e-6)
+
+
 def test_feature_known_answers():
     x = torch.tensor([[[0.0, 0, 0], [1.0, 0, 0], [1.0, 1.0, 0], [1.0, 1.0, 1.0], [2.0, 1.0, 1.0]]])
     f = opp.features_of(x, [("bond", (0, 1)), ("angle", (0, 1, 2)), ("dihedral", (0, 1, 2, 3)), ("dihedral", (1, 2, 3, 4))])
