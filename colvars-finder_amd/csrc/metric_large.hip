@@ -544,8 +544,26 @@ int cvf_metric_large_launch(const cvf_pp_desc* pp, int64_t B, const float* aux_t
   CVF_REQUIRE(lds <= kBudget, "cvf_metric_apply: %d feature-atom references need %zu B of LDS (> 158 KiB)", pp->n_ref, lds);
   const int64_t groups = cvf_ntiles(B) * (CVF_TILE / F) * k;
   CVF_REQUIRE(groups < (int64_t)1 << 31, "cvf_metric_apply: batch too large");
-  // all k nets of a frame group in one workgroup once that still leaves every CU two workgroups and more (see the kernel)
-  int npb = groups / k >= 512 ? k : 1;
+  // nets per workgroup (a divisor of k): a workgroup that walks several nets evaluates the records' geometry once (~7 us of a round at
+  // the config-5 shape, ~17.5 us per net behind it; one workgroup per CU), but fewer, longer workgroups fill the chip in coarser rounds.
+  // Measured at 5000 atoms, k = 6 (round 4, CVF_METRIC_NPB sweep, us per launch for 1 / 2 / 3 / 6 nets): 2000 frames 73 / 84 / 64 / 100,
+  // 4000: 132 / 129 / 119 / 107, 8000: 238 / 231 / 212 / 193 (until then: all k nets from 8192 frames on, else one).  The count with the
+  // smallest rounds x (geometry + nets) wins; a chip filled more than twice over counts fractional rounds.
+  int npb = 1;
+  {
+    const int ncu = cvf_cu_count();
+    double best = 0.0;
+    for (int c = 1; c <= k; ++c) {
+      if (k % c != 0) continue;
+      const double wgs = (double)(groups / k) * (k / c);
+      const double rounds = wgs <= 2.0 * ncu ? (double)(((int64_t)wgs + ncu - 1) / ncu) : wgs / ncu;
+      const double cost = rounds * (7.0 + 17.5 * c);
+      if (c == 1 || cost < best) {
+        best = cost;
+        npb = c;
+      }
+    }
+  }
   if (getenv("CVF_METRIC_NPB") && k % atoi(getenv("CVF_METRIC_NPB")) == 0 && atoi(getenv("CVF_METRIC_NPB")) > 0) npb = atoi(getenv("CVF_METRIC_NPB"));   // developer switch
   MetricFuse mf = {};
   if (fuse != nullptr && fuse->on && groups / k <= 384) {   // one row per frame group, while the finishing launch reads them in one trip
