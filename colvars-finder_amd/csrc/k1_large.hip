@@ -602,7 +602,7 @@ constexpr int kStream = 8, kTail = 4;
 #define PIPE_T(i) do {} while (0)
 #define PIPE_T_OUT() do {} while (0)
 #endif
-static_assert(kStream == kGroup && kGroup == 2 * kTail, "slice mapping: eight streaming waves; two frames per tail wave");
+static_assert(kStream == kGroup && kTail == 4, "slice mapping: eight streaming waves; one solving + three holding tail waves");
 constexpr int kRedPitchP = 68;
 
 template <int NI>
