@@ -436,8 +436,11 @@ __global__ __launch_bounds__(64 * kGroup) void k1_large_capture_kernel(cvf_pp_de
 // Per frame a wave reduces its twelve partial sums through a small wave-private LDS transpose (4 values a round:
 // 4 writes, one 16-byte read, four DPP steps) instead of twelve full-wave butterflies.
 // ---------------------------------------------------------------------------------------------------------
+// (min. 4 waves per SIMD = 128 registers = TWO workgroups per CU, which this kernel's loop without prefetch relies on.  Round 4's first edits of
+//  the tail took it to 130 registers - 3 waves per SIMD, ONE 8-wave workgroup per CU - unnoticed for most of the round: 1131-1221 us per 100 000
+//  frames of 5000 atoms instead of 1078-1153.  NI = 4 (6145..8192 atoms) would spill 17 registers at 128 and stays at one workgroup per CU.)
 template <int NI, bool NT>
-__global__ __launch_bounds__(64 * kGroup) void k1_large_slice_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
+__global__ __launch_bounds__(64 * kGroup, NI <= 3 ? 4 : 2) void k1_large_slice_kernel(cvf_pp_desc pp, const float* __restrict__ x, int64_t B,
                                                                      float* __restrict__ feat_tiled,
                                                                      float* __restrict__ feat_rows,
                                                                      float* __restrict__ aux_tiled,
@@ -1025,7 +1028,8 @@ __global__ __launch_bounds__(64 * (kStream + kTail)) void k1_large_pipe_kernel(c
         for (int k = 0; k < kHold; ++k) {
           int idx = hl + 192 * k;
           asm volatile("" : "+v"(idx));   // (the address is formed here: hoisted out of the group loop the sixteen 64-bit addresses were spilled)
-          // (cache-policy bits on these stores - nt, sc1, sc0 sc1 - change nothing: 1042 / 1043 / 1047 / 1043 us)
+          // (cache-policy bits on these stores - nt, sc1, sc0 sc1 - change nothing: 1042 / 1043 / 1047 / 1043 us; neither does putting every
+          //  workgroup's flush on a chip-wide time grid (s_memrealtime), with or without the bits: 1037 / 1040 / 1047 us for no grid / 10 / 20 us)
           if (idx < d8) *reinterpret_cast<float4*>(row0 + (idx >> 3) * CVF_TILE + 4 * (idx & 7)) = hold[k];
         }
       } else {
@@ -1099,10 +1103,15 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
       const int ncu = cvf_cu_count();
       const size_t lds_pipe = (2 * (size_t)kGroup * pp->n_slot * 3 + (size_t)pp->d_r * kGroup + (size_t)kStream * 4 * kRedPitchP +
                                6 * (size_t)(pp->n_rec_slot > 0 ? pp->n_rec_slot : pp->n_rec)) * sizeof(float);   // (+ 14.4 KB of static arrays: 160 KB in all)
-      // (developer switch CVF_K1_PIPE_MIN_GROUPS: this kernel - with single groups only - below four groups per compute unit; measured with the
-      //  generator-mode outputs, tools/k1_small_ab.sh: 2000 frames 41 us against 34, 4000: 64.5 / 62, 8000: 120 / 120.5, 12 000: 170 / 177)
+      // Where it pays against the one-group-per-workgroup kernel at two workgroups per CU (tools/k1_ab2.sh, both in one lease, two kinds of box,
+      // us per launch pipelined / other): tiled features only - 16 000 frames 194 / 192, 24 000: 279 / 284, 32 768: 372 / 383, 100 000: 1065-1118 /
+      // 1078-1153; with the generator-mode outputs (slot copy: 11 % of the bytes, written whole by either kernel) - 16 000: 225 / 218, 50 000: 675 / 667,
+      // 100 000: 1254-1326 / 1271-1343; row-major output alone (one 12-KB run per group either way) - never: 1067-1123 / 1032-1110.
+      // (developer switches: CVF_K1_PIPE_MIN_GROUPS - with single groups only below four groups per compute unit: 2000 frames 41 us / 34, 8000: 120 / 113;
+      //  CVF_K1_NOPIPE)
       const int64_t pipe_min = getenv("CVF_K1_PIPE_MIN_GROUPS") ? atoll(getenv("CVF_K1_PIPE_MIN_GROUPS")) : -1;
-      if (vec4 && ni <= 3 && staged && groups >= (pipe_min >= 0 ? pipe_min : 4 * (int64_t)ncu) && lds_pipe <= 145 * 1024 && 3 * pp->n_slot < 0xffff && pp->d_r <= 384 &&
+      const int64_t pipe_from = pipe_min >= 0 ? pipe_min : (feat_tiled == nullptr ? INT64_MAX : (aux_tiled || slot_xyz) ? 32 * (int64_t)ncu : 12 * (int64_t)ncu);
+      if (vec4 && ni <= 3 && staged && groups >= pipe_from && lds_pipe <= 145 * 1024 && 3 * pp->n_slot < 0xffff && pp->d_r <= 384 &&
           (feat_tiled != nullptr || ((uintptr_t)feat_rows & 15) == 0) && getenv("CVF_K1_NOPIPE") == nullptr) {
         const int64_t nquads = (groups + 3) / 4;   // (tiled outputs: groups is a multiple of 8)
         // quads only, or whole rounds of quads and the groups behind them one at a time - whichever gives the busiest workgroup fewer groups;

@@ -618,8 +618,8 @@ def _device_molecule_frames(n_atoms, B, seed, dev, scale=8.0, sigma=0.4):
 @pytest.mark.parametrize("n_atoms,B,n_align,angles", [(1000, 8192 + 37, 1000, False), (2600, 8192 + 64, 2600, False), (5000, 8192 + 5, 5000, False),
                                                       (1000, 16000 + 19, 1000, False), (1000, 25000, 1000, False), (1000, 8192 + 37, 600, True)])
 def test_k1_pipelined_kernel_equals_the_slice_kernel_and_the_oracle(dev, n_atoms, B, n_align, angles, monkeypatch):
-    """Batches of >= 1024 frame groups take the resident, role-split kernel (streaming waves + tail waves, csrc/k1_large.hip): every
-    output flavour bit for bit what the one-group-per-workgroup kernel writes, ragged last tile included, and the oracle's numbers."""
+    """Large batches take the resident, role-split kernel (streaming waves + tail waves, csrc/k1_large.hip; forced here from 1024 frame
+    groups on): every output flavour bit for bit what the one-group-per-workgroup kernel writes, ragged last tile included, and the oracle's numbers."""
     from colvarsfinder import _hip
     rs = np.random.RandomState(n_atoms)
     feats = [("position", tuple(int(i) for i in rs.choice(n_atoms, 40 if angles else 16, replace=False)))]
@@ -651,7 +651,9 @@ def test_k1_pipelined_kernel_equals_the_slice_kernel_and_the_oracle(dev, n_atoms
 
     for flavour in ("features", "generator", "rows", "both"):
         monkeypatch.delenv("CVF_K1_NOPIPE", raising=False)
+        monkeypatch.setenv("CVF_K1_PIPE_MIN_GROUPS", "1024")   # (by default the kernel takes larger batches only, and never the row-major flavour)
         got = run(flavour)
+        monkeypatch.delenv("CVF_K1_PIPE_MIN_GROUPS")
         monkeypatch.setenv("CVF_K1_NOPIPE", "1")
         want = run(flavour)
         for g, w_ in zip(got, want):
@@ -659,6 +661,7 @@ def test_k1_pipelined_kernel_equals_the_slice_kernel_and_the_oracle(dev, n_atoms
             assert torch.equal(g.view(torch.int32) if g.dtype == torch.float32 else g.view(torch.int64),
                                w_.view(torch.int32) if w_.dtype == torch.float32 else w_.view(torch.int64)), flavour
     monkeypatch.delenv("CVF_K1_NOPIPE", raising=False)
+    monkeypatch.setenv("CVF_K1_PIPE_MIN_GROUPS", "1024")
     rows = run("rows")[0].view(B, d_r)
     pick = list(range(40)) + list(range(B - 40, B))
     torch.set_default_dtype(torch.float64)

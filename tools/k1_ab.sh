@@ -32,13 +32,16 @@ for rnd in range(3):
     for tag, nopipe in (("pipe", None), ("slice", "1")):
         if nopipe is None:
             os.environ.pop("CVF_K1_NOPIPE", None)
+            os.environ["CVF_K1_PIPE_MIN_GROUPS"] = "1024"   # (forced: by default it takes the flavours / sizes where it pays)
         else:
+            os.environ.pop("CVF_K1_PIPE_MIN_GROUPS", None)
             os.environ["CVF_K1_NOPIPE"] = nopipe
         row["feat_" + tag] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, None, None, s)), 1)
         row["gen_" + tag] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, P(a_tmp), P(sc5), s)), 1)
         row["rows_" + tag] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, None, P(rows_out), None, None, s)), 1)
         row["c5step16k_" + tag] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), 16000, P(f_tmp), None, P(a_tmp), P(sc5), s)), 1)
     os.environ.pop("CVF_K1_NOPIPE", None)
+    os.environ["CVF_K1_PIPE_MIN_GROUPS"] = "1024"
     for pb in (1, 8):
         os.environ["CVF_K1_PIPE_PROBE"] = str(pb)
         row["feat_pipe_probe%d" % pb] = round(t(lambda: lib.cvf_align_feature_fwd(d5, P(x5), n5, P(f_tmp), None, None, None, s)), 1)

@@ -56,10 +56,12 @@ for case in range(cases):
         os.environ["CVF_K1_NOPIPE"] = "1"
         want = run(flavour)
         del os.environ["CVF_K1_NOPIPE"]
+        os.environ["CVF_K1_PIPE_MIN_GROUPS"] = "1024"
         miss = 0
         for _ in range(repeats):
             got = run(flavour)
             miss += int(not all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(got, want)))
+        del os.environ["CVF_K1_PIPE_MIN_GROUPS"]
         bad += miss
         print(f"case {case}: atoms {n_atoms} align {n_align} frames {B} d_r {d_r} angles {angles} {flavour}: {miss} of {repeats} launches differ", flush=True)
 print("TOTAL mismatching launches:", bad)
