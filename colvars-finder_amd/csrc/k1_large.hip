@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64 * kGroup, NI <= 3 ? 4 : 2) void k1_large_slice_k
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Pipelined variant of the slice kernel (round 4; large batches: >= 4 frame groups per compute unit).  In the slice kernel a workgroup
+// Pipelined variant of the slice kernel (round 4; large batches, tiled outputs).  In the slice kernel a workgroup
 // streams its eight frames and then spends a fifth of its life in the tail (sums -> 3x3 solves -> features -> flush) with no load in
 // flight; two workgroups per CU overlap that only by chance, and the streaming loop alone (CVF_K1_XCD=2) runs at the read sweep's rate
 // while the whole kernel is 10-15 % below it.  Here ONE workgroup per CU stays for the whole launch and is split by role:
@@ -579,13 +579,17 @@ __global__ __launch_bounds__(64 * kGroup, NI <= 3 ? 4 : 2) void k1_large_slice_k
 //                boundary, so the memory pipe never drains;
 //   wave 8       tail: the group's eight 3x3 solves (a lane each), the rotation rows, the features that need the rotation;
 //   waves 9..11  tail: the other features, the slot copy - and the feature stores: the features of FOUR consecutive groups wait in
-//                their registers and leave as whole 128-byte lines (see THE FLUSH in the kernel: group-by-group 32-byte pieces cost
-//                250 us of a 1220-us launch) - while the streaming waves are already capturing the next group into the other LDS buffer.
-// The roles meet at counters in LDS (in the kernel), never at the workgroup barrier.  Measured (tools/k1_ab.sh, 100 000 frames of 5000
-// atoms, both kernels in one lease, two kinds of box): 1031-1042 us against 1131-1146 (features only: 0.74 of 8 TB/s, 0.92 of a read
-// sweep of the same bytes), 1117 against 1221 on the slower kind (0.69); with the generator-mode extras 1213-1224 against 1247-1269;
-// row-major output 1043-1055 against 1120-1136.  Every output is bit for bit the slice kernel's
-// (tests/test_gpu_parity.py::test_k1_pipelined_kernel_equals_the_slice_kernel_and_the_oracle).
+//                their registers and leave as whole 128-byte lines (see THE FLUSH in the kernel) - while the streaming waves are already
+//                capturing the next group into the other LDS buffer.
+// The roles meet at counters in LDS (in the kernel), never at the workgroup barrier.  Measured against the slice kernel AT TWO WORKGROUPS PER CU
+// (tools/k1_ab.sh / k1_ab2.sh, 100 000 frames of 5000 atoms, both kernels in one lease, two kinds of box): tiled features 1065 / 1118-1122 us
+// against 1078 / 1153-1156 (0.72-0.735 and 0.685-0.69 of 8 TB/s); with the generator-mode extras 1254 / 1327-1331 against 1271 / 1343-1350;
+// row-major output 1067 / 1123-1129 against 1032 / 1110-1115 (the slice kernel's 12-KB runs are whole lines already) - so it runs where it pays
+// (see the launch code), a 1-3 % matter.  (For most of round 4 the comparison read "-9 %": the slice kernel had grown to 130 registers - one
+// workgroup per CU - in the same round.)  What the probes of this kernel established holds for both: without their feature stores the slice
+// kernel runs at 949 us = the read sweep of the same bytes (950-960), this one at 983-989 (streaming waves alone 968-975); the stores - 2.5 % of
+// the bytes - are the whole distance to the sweep, 200 us as 32-byte pieces, 135 as whole lines.  Every output is bit for bit the slice kernel's
+// (tests/test_gpu_parity.py::test_k1_pipelined_kernel_equals_the_slice_kernel_and_the_oracle, tools/k1_pipe_fuzz.py).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kStream = 8, kTail = 4;
 // developer aid (tools/k1_large_probe.hip, -DCVF_STAMPS): cycles a wave spends between two marks, summed over its groups

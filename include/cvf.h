@@ -154,7 +154,7 @@ const char* cvf_last_error(void);
 /* --- K1: alignment + features, forward.  Replaces pp_layer(X) at core.py:403,414,635.
  * x [B, n_coord] row-major fp32.  feat_tiled [T][d_r][64] and/or feat_rows [B][d_r]
  * (either may be NULL); aux_tiled [T][18][64] (may be NULL; identity mode ignores it).
- * Frames of thousands of atoms take the streaming path (groups of 8 frames; batches of >= 4 groups per compute unit run the resident
+ * Frames of thousands of atoms take the streaming path (groups of 8 frames; large batches with a tiled output run the resident
  * role-split kernel of csrc/k1_large.hip - same numbers, bit for bit - which writes every tiled row of 32 consecutive frames as one
  * 128-byte line: feat_tiled / aux_tiled / scratch must cover the padded frame count, ceil(B / 64) * 64, as documented).
  * `scratch` (may be NULL; cvf_align_feature_scratch_bytes() bytes): on the streaming path it receives the compact
