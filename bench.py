@@ -50,7 +50,7 @@ FLOP_OF_CALL = {"cvf_ef16_front": FLOP_FWD + FLOP_METRIC + FLOP_K1, "cvf_ef16_ba
 KERNEL_OF_CALL = {"cvf_ef16_front": "ef16_front_kernel", "cvf_ef16_backward": "ef16_back_kernel", "cvf_ef_backward": "ef_bwd_mfma_kernel", "cvf_ef_mlp_fwd": "ef_fwd_wide_kernel", "cvf_metric_apply": "metric_rows_kernel",
                   "cvf_ef_fwd_metric_stats": "ef_fwd_metric_kernel", "cvf_ef_align_fwd_metric_stats": "ef_fwd_metric_kernel",
                   "cvf_align_feature_fwd": "k1_align_quad_kernel", "cvf_align_feature_fwd@1M": "k1_stream_kernel",
-                  "cvf_align_feature_fwd@c5": "k1_large_pipe_kernel"}
+                  "cvf_align_feature_fwd@c5": "k1_large_kernel"}   # (slice or pipelined kernel: the same traffic per frame; the PMC pass runs 20 000 frames)
 PROFILE_TAG = "r4"   # profiles/<tag>_pmc_traffic.json is the committed PMC summary `roofline.traffic` is read from
 
 

@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64 * kGroup, NI <= 3 ? 4 : 2) void k1_large_slice_k
 // (tools/k1_ab.sh / k1_ab2.sh, 100 000 frames of 5000 atoms, both kernels in one lease, two kinds of box): tiled features 1065 / 1118-1122 us
 // against 1078 / 1153-1156 (0.72-0.735 and 0.685-0.69 of 8 TB/s); with the generator-mode extras 1254 / 1327-1331 against 1271 / 1343-1350;
 // row-major output 1067 / 1123-1129 against 1032 / 1110-1115 (the slice kernel's 12-KB runs are whole lines already) - so it runs where it pays
-// (see the launch code), a 1-3 % matter.  (For most of round 4 the comparison read "-9 %": the slice kernel had grown to 130 registers - one
+// (tiled features alone, large batches: see the launch code), a 1-4 % matter.  (For most of round 4 the comparison read "-9 %": the slice kernel had grown to 130 registers - one
 // workgroup per CU - in the same round.)  What the probes of this kernel established holds for both: without their feature stores the slice
 // kernel runs at 949 us = the read sweep of the same bytes (950-960), this one at 983-989 (streaming waves alone 968-975); the stores - 2.5 % of
 // the bytes - are the whole distance to the sweep, 200 us as 32-byte pieces, 135 as whole lines.  Every output is bit for bit the slice kernel's
@@ -1110,11 +1110,12 @@ int cvf_k1_large_launch(const cvf_pp_desc* pp, const float* x, int64_t B, float*
       // Where it pays against the one-group-per-workgroup kernel at two workgroups per CU (tools/k1_ab2.sh, both in one lease, two kinds of box,
       // us per launch pipelined / other): tiled features only - 16 000 frames 194 / 192, 24 000: 279 / 284, 32 768: 372 / 383, 100 000: 1065-1118 /
       // 1078-1153; with the generator-mode outputs (slot copy: 11 % of the bytes, written whole by either kernel) - 16 000: 225 / 218, 50 000: 675 / 667,
-      // 100 000: 1254-1326 / 1271-1343; row-major output alone (one 12-KB run per group either way) - never: 1067-1123 / 1032-1110.
+      // 100 000: 1254-1336 / 1240-1343 (by box: from 1.3 % faster to 7 % slower); row-major output alone (one 12-KB run per group either way):
+      // 1067-1123 / 1032-1110.  So: tiled features alone from 24 576 frames on; never with the generator-mode outputs or for the row-major output.
       // (developer switches: CVF_K1_PIPE_MIN_GROUPS - with single groups only below four groups per compute unit: 2000 frames 41 us / 34, 8000: 120 / 113;
       //  CVF_K1_NOPIPE)
       const int64_t pipe_min = getenv("CVF_K1_PIPE_MIN_GROUPS") ? atoll(getenv("CVF_K1_PIPE_MIN_GROUPS")) : -1;
-      const int64_t pipe_from = pipe_min >= 0 ? pipe_min : (feat_tiled == nullptr ? INT64_MAX : (aux_tiled || slot_xyz) ? 32 * (int64_t)ncu : 12 * (int64_t)ncu);
+      const int64_t pipe_from = pipe_min >= 0 ? pipe_min : (feat_tiled == nullptr || aux_tiled || slot_xyz ? INT64_MAX : 12 * (int64_t)ncu);
       if (vec4 && ni <= 3 && staged && groups >= pipe_from && lds_pipe <= 145 * 1024 && 3 * pp->n_slot < 0xffff && pp->d_r <= 384 &&
           (feat_tiled != nullptr || ((uintptr_t)feat_rows & 15) == 0) && getenv("CVF_K1_NOPIPE") == nullptr) {
         const int64_t nquads = (groups + 3) / 4;   // (tiled outputs: groups is a multiple of 8)

@@ -48,9 +48,9 @@ try:
     fk = per_launch(f"gpurun_out/{TAG}/pmc_k1_FETCH_SIZE/k1_counter_collection.csv", "FETCH_SIZE")
     wk = per_launch(f"gpurun_out/{TAG}/pmc_k1_WRITE_SIZE/k1_counter_collection.csv", "WRITE_SIZE")
     half = len(fk) // 2
-    out["kernels"]["k1_large_pipe_kernel"] = {"FETCH_SIZE_KiB": sum(fk[:half]) / half, "WRITE_SIZE_KiB": sum(wk[:half]) / half,
+    out["kernels"]["k1_large_kernel"] = {"FETCH_SIZE_KiB": sum(fk[:half]) / half, "WRITE_SIZE_KiB": sum(wk[:half]) / half,
                                                "frames_per_launch": 20000, "flavour": "features only (config-5 shape, 5000 atoms, d_r 384)"}
-    out["kernels"]["k1_large_pipe_kernel+extras"] = {"FETCH_SIZE_KiB": sum(fk[half:]) / (len(fk) - half), "WRITE_SIZE_KiB": sum(wk[half:]) / (len(wk) - half),
+    out["kernels"]["k1_large_kernel+extras"] = {"FETCH_SIZE_KiB": sum(fk[half:]) / (len(fk) - half), "WRITE_SIZE_KiB": sum(wk[half:]) / (len(wk) - half),
                                                       "frames_per_launch": 20000, "flavour": "+ rotation rows and slot copy"}
 except Exception as exc:
     print("no K1 PMC passes:", exc)
